@@ -1,0 +1,140 @@
+"""ctypes binding of include/ndt_hip.h (the C-ABI shared library libndt_hip.so).
+
+The library is built in-tree by ``gtsam_ndt_amd.build.build_all()`` (hipcc, gfx950) and
+travels to the GPU box with the repo snapshot.  Loading fails loudly when it is missing:
+there is no CPU or PyTorch fallback for the matcher.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libndt_hip.so")
+
+NDT_OK = 0
+NDT_NOT_CONVERGED = 1
+NDT_DEGENERATE_HESSIAN = 2
+NDT_TOO_FEW_HITS = 3
+NDT_TOO_FEW_CELLS = 4
+NDT_ERR_INVALID_ARG = -1
+NDT_ERR_NO_TARGET = -2
+NDT_ERR_HIP = -3
+NDT_ERR_NO_DEVICE = -4
+NDT_ERR_CAPACITY = -5
+NDT_ERR_ALLOC = -6
+
+HESSIAN_GAUSS_NEWTON = 0
+HESSIAN_NEWTON = 1
+
+
+class Params2D(C.Structure):
+    _fields_ = [
+        ("cell_size", C.c_double),
+        ("min_points", C.c_int32),
+        ("hessian_mode", C.c_int32),
+        ("eig_ratio", C.c_double),
+        ("d1", C.c_double),
+        ("d2", C.c_double),
+        ("max_iterations", C.c_int32),
+        ("fixed_iterations", C.c_int32),
+        ("eps_trans", C.c_double),
+        ("eps_rot", C.c_double),
+        ("step_max_trans", C.c_double),
+        ("step_max_rot", C.c_double),
+        ("min_hits", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Result2D(C.Structure):
+    _fields_ = [
+        ("pose", C.c_double * 3),
+        ("H", C.c_double * 9),
+        ("g", C.c_double * 3),
+        ("score", C.c_double),
+        ("iterations", C.c_int32),
+        ("n_hit", C.c_int32),
+        ("status", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Eval2D(C.Structure):
+    _fields_ = [
+        ("H", C.c_double * 9),
+        ("g", C.c_double * 3),
+        ("score", C.c_double),
+        ("n_hit", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class GridInfo2D(C.Structure):
+    _fields_ = [
+        ("ox", C.c_float), ("oy", C.c_float), ("inv_cell", C.c_float), ("cell", C.c_float),
+        ("width", C.c_int32), ("height", C.c_int32), ("n_valid", C.c_int32), ("n_points", C.c_int32),
+    ]
+
+
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); the CPU test checks every one of these is exported and that
+# the list matches the declarations in include/ndt_hip.h.
+SIGNATURES = {
+    "ndt_abi_version": (C.c_int32, []),
+    "ndt_status_string": (C.c_char_p, [C.c_int32]),
+    "ndt_last_error": (C.c_char_p, []),
+    "ndt_device_count": (C.c_int32, []),
+    "ndt2d_default_params": (None, [C.POINTER(Params2D)]),
+    "ndt2d_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),
+    "ndt2d_destroy": (C.c_int32, [_vp]),
+    "ndt2d_set_target": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
+    "ndt2d_set_target_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "ndt2d_add_target_points": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ndt2d_get_grid_info": (C.c_int32, [_vp, C.POINTER(GridInfo2D)]),
+    "ndt2d_get_grid": (C.c_int32, [_vp, _vp, _vp, _vp]),
+    "ndt2d_evaluate": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval2D)]),
+    "ndt2d_align": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result2D)]),
+    "ndt2d_align_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result2D)]),
+    "ndt2d_align_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp]),
+    "ndt2d_align_finish": (C.c_int32, [_vp, C.POINTER(Result2D)]),
+    "ndt2d_stream": (_vp, [_vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libndt_hip.so (once) and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The NDT matcher has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class NdtError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        lib = load()
+        msg = lib.ndt_status_string(code).decode()
+        detail = lib.ndt_last_error().decode()
+        super().__init__(f"{where}: {msg} ({code})" + (f": {detail}" if detail else ""))
+        self.code = code
+
+
+def check(code: int, where: str) -> int:
+    if code < 0:
+        raise NdtError(code, where)
+    return code

@@ -1,0 +1,478 @@
+// C-ABI host side of the 2D NDT matcher (include/ndt_hip.h).  Owns device memory and one
+// HIP stream per handle; every compute entry point launches the gfx950 kernels of
+// ndt2d_kernels.hpp.  There is deliberately no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/ndt_hip.h"
+#include "ndt2d_kernels.hpp"
+#include "ndt_host.hpp"
+
+using namespace ndt;
+
+struct ndt2d_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  ndt2d_params prm{};
+  // target grid
+  GridDev grid{};
+  size_t cell_capacity = 0;
+  bool has_target = false;
+  int n_valid = 0;
+  size_t n_points = 0;
+  unsigned int* d_bounds = nullptr;        // [4]
+  int* d_counters = nullptr;               // [2] valid cells, overflowed cells
+  unsigned long long* d_outside = nullptr; // [1]
+  void* h_small = nullptr;                 // pinned scratch (64 B)
+  // staging for host-pointer entry points
+  float* d_tx = nullptr; float* d_ty = nullptr; size_t tcap = 0;
+  float* d_sx = nullptr; float* d_sy = nullptr; size_t scap = 0;
+  // alignment context
+  AlignCtx* d_ctx = nullptr;
+  AlignCtx* h_ctx = nullptr;               // pinned; only the header (up to partials) is used
+  IterState* h_state = nullptr;            // pinned
+  int last_parity = 0;
+  bool pending = false;
+};
+
+namespace {
+
+constexpr size_t kCtxHeaderBytes = offsetof(AlignCtx, partials);
+constexpr size_t kMaxCells = (size_t)1 << 27;
+
+int32_t check_params(const ndt2d_params* p) {
+  if (!p) return NDT_ERR_INVALID_ARG;
+  if (!(p->cell_size > 0.0) || !std::isfinite(p->cell_size)) return NDT_ERR_INVALID_ARG;
+  if (p->min_points < 2 || p->max_iterations < 1 || p->fixed_iterations < 0) return NDT_ERR_INVALID_ARG;
+  if (!(p->eig_ratio > 0.0) || !(p->eig_ratio <= 1.0)) return NDT_ERR_INVALID_ARG;
+  if (p->hessian_mode != NDT_HESSIAN_GAUSS_NEWTON && p->hessian_mode != NDT_HESSIAN_NEWTON)
+    return NDT_ERR_INVALID_ARG;
+  if (!(p->step_max_trans > 0.0) || !(p->step_max_rot > 0.0)) return NDT_ERR_INVALID_ARG;
+  return NDT_OK;
+}
+
+int32_t ensure_points(float** dx, float** dy, size_t* cap, size_t n) {
+  if (n <= *cap) return NDT_OK;
+  if (*dx) (void)hipFree(*dx);
+  if (*dy) (void)hipFree(*dy);
+  *dx = *dy = nullptr; *cap = 0;
+  const size_t want = n + n / 4 + 1024;
+  HIP_TRY(hipMalloc((void**)dx, want * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)dy, want * sizeof(float)));
+  *cap = want;
+  return NDT_OK;
+}
+
+int blocks_for(size_t n) {
+  size_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+int stream_blocks(size_t n) {   // streaming kernels: up to 8 blocks per CU
+  size_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+int32_t finalise_grid(ndt2d_handle* h) {
+  const size_t ncell = (size_t)h->grid.W * h->grid.H;
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_finalise, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     h->stream, h->grid, h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+  HIP_TRY(hipGetLastError());
+  int* hc = (int*)h->h_small;
+  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->n_valid = hc[0];
+  if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+  return NDT_OK;
+}
+
+int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n) {
+  h->has_target = false;
+  if (n == 0) return NDT_ERR_INVALID_ARG;
+  // a1: bounding box on the device, geometry on the host (oracle/ndt2d.py grid_geometry)
+  unsigned int init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+  unsigned int* hb = (unsigned int*)h->h_small;
+  std::memcpy(hb, init, sizeof(init));
+  HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, sizeof(init), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (hb[0] == 0xFFFFFFFFu || hb[1] == 0u) { set_error("target has no finite point"); return NDT_ERR_INVALID_ARG; }
+  const float xmin = ordered_to_float(hb[0]), xmax = ordered_to_float(hb[1]);
+  const float ymin = ordered_to_float(hb[2]), ymax = ordered_to_float(hb[3]);
+  const double c = h->prm.cell_size;
+  GridDev& g = h->grid;
+  g.cell = c;
+  g.cell32 = (float)c;
+  g.inv_c = (float)(1.0 / c);
+  g.ox = (float)((std::floor((double)xmin / c) - 1.0) * c);
+  g.oy = (float)((std::floor((double)ymin / c) - 1.0) * c);
+  const volatile float fx = (xmax - g.ox) * g.inv_c;   // float32 arithmetic, as the kernels
+  const volatile float fy = (ymax - g.oy) * g.inv_c;
+  const double kx = std::floor((double)fx), ky = std::floor((double)fy);
+  if (!(kx >= 0.0) || !(ky >= 0.0) || (kx + 2.0) * (ky + 2.0) > (double)kMaxCells) {
+    set_error("target extent / cell_size needs more than 2^27 cells");
+    return NDT_ERR_CAPACITY;
+  }
+  g.W = (int)kx + 2;
+  g.H = (int)ky + 2;
+  g.fix_scale = std::ldexp(1.0, kFixShift) / c;
+  const size_t ncell = (size_t)g.W * g.H;
+  if (ncell > h->cell_capacity) {
+    if (g.recA) (void)hipFree(g.recA);
+    if (g.recB) (void)hipFree(g.recB);
+    if (g.acc) (void)hipFree(g.acc);
+    g.recA = nullptr; g.recB = nullptr; g.acc = nullptr; h->cell_capacity = 0;
+    const size_t want = ncell + ncell / 8;
+    HIP_TRY(hipMalloc((void**)&g.recA, want * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&g.recB, want * sizeof(float2)));
+    HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc)));
+    h->cell_capacity = want;
+  }
+  // a2: exact per-cell sums
+  HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc), h->stream));
+  hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, g,
+                     (unsigned long long*)nullptr);
+  HIP_TRY(hipGetLastError());
+  // a3
+  const int32_t st = finalise_grid(h);
+  if (st != NDT_OK) return st;
+  h->n_points = n;
+  h->has_target = true;
+  return NDT_OK;
+}
+
+void fill_ctx_header(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
+                     const double pose[3], int fixed_override) {
+  AlignCtx* c = h->h_ctx;
+  c->grid = h->grid;
+  SolveParams& p = c->prm;
+  p.d1 = (float)h->prm.d1;
+  p.d2 = (float)h->prm.d2;
+  p.hessian_mode = h->prm.hessian_mode;
+  p.max_iterations = h->prm.max_iterations;
+  p.fixed_iterations = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
+  p.min_hits = h->prm.min_hits;
+  p.eps_trans = h->prm.eps_trans;
+  p.eps_rot = h->prm.eps_rot;
+  p.step_max_trans = h->prm.step_max_trans;
+  p.step_max_rot = h->prm.step_max_rot;
+  c->sx = d_sx;
+  c->sy = d_sy;
+  c->n = (int)n;
+  c->pad = 0;
+  std::memset(c->state, 0, sizeof(c->state));
+  IterState& s = c->state[1];           // launch 0 has parity 0 and reads slot 1
+  s.pose[0] = pose[0]; s.pose[1] = pose[1]; s.pose[2] = pose[2];
+}
+
+void launch_iter(ndt2d_handle* h, int blocks, int k) {
+  if (h->prm.hessian_mode == NDT_HESSIAN_NEWTON)
+    hipLaunchKernelGGL(k_iterate<1>, dim3(blocks), dim3(kBlock), 0, h->stream, h->d_ctx, k & 1);
+  else
+    hipLaunchKernelGGL(k_iterate<0>, dim3(blocks), dim3(kBlock), 0, h->stream, h->d_ctx, k & 1);
+}
+
+// Enqueue the Gauss-Newton loop.  check_every > 0: poll the done flag every that many
+// launches (synchronous early exit); 0: enqueue all launches, finished ones are no-ops.
+int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n, const double pose[3],
+                  int fixed_override, int check_every) {
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  if (n == 0 || n > 0x7fffffffull || !pose) return NDT_ERR_INVALID_ARG;
+  if (h->n_valid < 1) {
+    h->pending = false;
+    std::memset(h->h_state, 0, sizeof(IterState));
+    h->h_state->pose[0] = pose[0]; h->h_state->pose[1] = pose[1]; h->h_state->pose[2] = pose[2];
+    h->h_state->status = NDT_TOO_FEW_CELLS;
+    h->h_state->done = 2;               // marks "result already on the host"
+    return NDT_OK;
+  }
+  fill_ctx_header(h, d_sx, d_sy, n, pose, fixed_override);
+  HIP_TRY(hipMemcpyAsync(h->d_ctx, h->h_ctx, kCtxHeaderBytes, hipMemcpyHostToDevice, h->stream));
+  const int fixed = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
+  const int K = fixed > 0 ? fixed : h->prm.max_iterations;
+  const int blocks = blocks_for(n);
+  int k = 0;
+  for (; k <= K; ++k) {
+    launch_iter(h, blocks, k);
+    if (check_every > 0 && fixed == 0 && k < K && (k % check_every) == check_every - 1) {
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_ctx->state[k & 1], sizeof(IterState), hipMemcpyDeviceToHost,
+                             h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->h_state->done) { ++k; break; }
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  h->last_parity = (k - 1) & 1;
+  h->h_state->done = 0;
+  h->pending = true;
+  return NDT_OK;
+}
+
+int32_t fetch_state(ndt2d_handle* h) {
+  if (h->pending) {
+    HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_ctx->state[h->last_parity], sizeof(IterState),
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->pending = false;
+  }
+  return NDT_OK;
+}
+
+void sym6_to_9(const double* s, double* H) {
+  H[0] = s[0]; H[1] = s[1]; H[2] = s[3];
+  H[3] = s[1]; H[4] = s[2]; H[5] = s[4];
+  H[6] = s[3]; H[7] = s[4]; H[8] = s[5];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int32_t ndt_abi_version(void) { return NDT_ABI_VERSION; }
+
+const char* ndt_status_string(int32_t s) {
+  switch (s) {
+    case NDT_OK: return "ok";
+    case NDT_NOT_CONVERGED: return "not converged (max_iterations reached)";
+    case NDT_DEGENERATE_HESSIAN: return "degenerate Hessian";
+    case NDT_TOO_FEW_HITS: return "too few source points in valid cells";
+    case NDT_TOO_FEW_CELLS: return "target grid has no valid cell";
+    case NDT_ERR_INVALID_ARG: return "invalid argument";
+    case NDT_ERR_NO_TARGET: return "no target set";
+    case NDT_ERR_HIP: return "HIP error";
+    case NDT_ERR_NO_DEVICE: return "no HIP device";
+    case NDT_ERR_CAPACITY: return "capacity limit exceeded";
+    case NDT_ERR_ALLOC: return "allocation failed";
+    default: return "unknown status";
+  }
+}
+
+const char* ndt_last_error(void) { return last_error().c_str(); }
+
+int32_t ndt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+void ndt2d_default_params(ndt2d_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->cell_size = 0.5;
+  p->min_points = 3;
+  p->hessian_mode = NDT_HESSIAN_GAUSS_NEWTON;
+  p->eig_ratio = 1e-3;
+  p->d1 = 1.0;
+  p->d2 = 1.0;
+  p->max_iterations = 100;
+  p->fixed_iterations = 0;
+  p->eps_trans = 1e-5;
+  p->eps_rot = 1e-5;
+  p->step_max_trans = 0.5;
+  p->step_max_rot = 0.2;
+  p->min_hits = 3;
+}
+
+int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** out) {
+  if (!out) return NDT_ERR_INVALID_ARG;
+  *out = nullptr;
+  const int32_t st = check_params(p);
+  if (st != NDT_OK) return st;
+  const int ndev = ndt_device_count();
+  if (ndev <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }
+  if (device_id < 0 || device_id >= ndev) return NDT_ERR_INVALID_ARG;
+  ndt2d_handle* h = new (std::nothrow) ndt2d_handle();
+  if (!h) return NDT_ERR_ALLOC;
+  h->device = device_id;
+  h->prm = *p;
+  auto fail = [&](int32_t code) { ndt2d_destroy(h); return code; };
+  if (hipSetDevice(device_id) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipMalloc((void**)&h->d_bounds, 4 * sizeof(unsigned int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_counters, 2 * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_outside, sizeof(unsigned long long)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_ctx, sizeof(AlignCtx)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc((void**)&h->h_ctx, kCtxHeaderBytes, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc((void**)&h->h_state, sizeof(IterState), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMemset(h->d_ctx, 0, sizeof(AlignCtx)) != hipSuccess) return fail(NDT_ERR_HIP);
+  *out = h;
+  return NDT_OK;
+}
+
+int32_t ndt2d_destroy(ndt2d_handle* h) {
+  if (!h) return NDT_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_ctx, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
+                 h->grid.recA, h->grid.recB, h->grid.acc};
+  for (void* p : dev) if (p) (void)hipFree(p);
+  void* host[] = {h->h_ctx, h->h_state, h->h_small};
+  for (void* p : host) if (p) (void)hipHostFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return NDT_OK;
+}
+
+void* ndt2d_stream(ndt2d_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int32_t ndt2d_set_target(ndt2d_handle* h, const float* x, const float* y, size_t n) {
+  if (!h || !x || !y || n == 0) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = ensure_points(&h->d_tx, &h->d_ty, &h->tcap, n);
+  if (st != NDT_OK) return st;
+  HIP_TRY(hipMemcpyAsync(h->d_tx, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_ty, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  return set_target_impl(h, h->d_tx, h->d_ty, n);
+}
+
+int32_t ndt2d_set_target_dev(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n, void* stream) {
+  if (!h || !d_x || !d_y || n == 0) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // producer of d_x/d_y
+  return set_target_impl(h, d_x, d_y, n);
+}
+
+int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y, size_t n, size_t* n_outside) {
+  if (!h || !x || !y || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = ensure_points(&h->d_tx, &h->d_ty, &h->tcap, n);
+  if (st != NDT_OK) return st;
+  HIP_TRY(hipMemcpyAsync(h->d_tx, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_ty, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_outside, 0, sizeof(unsigned long long), h->stream));
+  hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, h->d_tx, h->d_ty, n,
+                     h->grid, h->d_outside);
+  HIP_TRY(hipGetLastError());
+  unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 32);
+  HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  const int32_t fs = finalise_grid(h);
+  if (n_outside) *n_outside = (size_t)*ho;
+  if (fs != NDT_OK) { h->has_target = false; return fs; }
+  h->n_points += n - (size_t)*ho;
+  return NDT_OK;
+}
+
+int32_t ndt2d_get_grid_info(ndt2d_handle* h, ndt2d_grid_info* info) {
+  if (!h || !info) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  info->ox = h->grid.ox; info->oy = h->grid.oy;
+  info->inv_cell = h->grid.inv_c; info->cell = h->grid.cell32;
+  info->width = h->grid.W; info->height = h->grid.H;
+  info->n_valid = h->n_valid; info->n_points = (int32_t)h->n_points;
+  return NDT_OK;
+}
+
+int32_t ndt2d_get_grid(ndt2d_handle* h, int32_t* count, float* mean_xy, float* icov_abc) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t ncell = (size_t)h->grid.W * h->grid.H;
+  float4* a = new (std::nothrow) float4[ncell];
+  float2* b = new (std::nothrow) float2[ncell];
+  CellAcc* acc = count ? new (std::nothrow) CellAcc[ncell] : nullptr;
+  int32_t rc = NDT_OK;
+  if (!a || !b || (count && !acc)) rc = NDT_ERR_ALLOC;
+  if (rc == NDT_OK && hipMemcpyAsync(a, h->grid.recA, ncell * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK && hipMemcpyAsync(b, h->grid.recB, ncell * sizeof(float2), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK && acc && hipMemcpyAsync(acc, h->grid.acc, ncell * sizeof(CellAcc), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK) {
+    for (size_t k = 0; k < ncell; ++k) {
+      if (count) count[k] = (int32_t)acc[k].n;
+      if (mean_xy) { mean_xy[2 * k] = a[k].x; mean_xy[2 * k + 1] = a[k].y; }
+      if (icov_abc) {
+        const bool valid = b[k].y > 0.f;
+        icov_abc[3 * k] = valid ? a[k].z : 0.f;
+        icov_abc[3 * k + 1] = valid ? a[k].w : 0.f;
+        icov_abc[3 * k + 2] = valid ? b[k].x : 0.f;
+      }
+    }
+  } else if (rc == NDT_ERR_HIP) {
+    set_error(hipGetErrorString(hipGetLastError()));
+  }
+  delete[] a; delete[] b; delete[] acc;
+  return rc;
+}
+
+int32_t ndt2d_evaluate(ndt2d_handle* h, const float* sx, const float* sy, size_t n, const double pose[3],
+                       ndt2d_eval* out) {
+  if (!h || !sx || !sy || !pose || !out || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  int32_t st = ensure_points(&h->d_sx, &h->d_sy, &h->scap, n);
+  if (st != NDT_OK) return st;
+  HIP_TRY(hipMemcpyAsync(h->d_sx, sx, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_sy, sy, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  st = run_align(h, h->d_sx, h->d_sy, n, pose, /*fixed_override=*/1, /*check_every=*/0);
+  if (st != NDT_OK) return st;
+  st = fetch_state(h);
+  if (st != NDT_OK) return st;
+  std::memset(out, 0, sizeof(*out));
+  sym6_to_9(h->h_state->H, out->H);
+  for (int j = 0; j < 3; ++j) out->g[j] = h->h_state->g[j];
+  out->score = h->h_state->score;
+  out->n_hit = h->h_state->n_hit;
+  return NDT_OK;
+}
+
+int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = fetch_state(h);
+  if (st != NDT_OK) return st;
+  const IterState& s = *h->h_state;
+  std::memset(out, 0, sizeof(*out));
+  for (int j = 0; j < 3; ++j) { out->pose[j] = s.pose[j]; out->g[j] = s.g[j]; }
+  sym6_to_9(s.H, out->H);
+  out->score = s.score;
+  out->iterations = s.iter;
+  out->n_hit = s.n_hit;
+  out->status = s.status;
+  return NDT_OK;
+}
+
+int32_t ndt2d_align_dev_async(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
+                              const double init_pose[3]) {
+  if (!h || !d_sx || !d_sy || !init_pose) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  return run_align(h, d_sx, d_sy, n, init_pose, -1, 0);
+}
+
+int32_t ndt2d_align_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
+                        const double init_pose[3], ndt2d_result* out) {
+  if (!h || !d_sx || !d_sy || !init_pose || !out) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = run_align(h, d_sx, d_sy, n, init_pose, -1, 8);
+  if (st != NDT_OK) return st;
+  return ndt2d_align_finish(h, out);
+}
+
+int32_t ndt2d_align(ndt2d_handle* h, const float* sx, const float* sy, size_t n, const double init_pose[3],
+                    ndt2d_result* out) {
+  if (!h || !sx || !sy || !init_pose || !out || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = ensure_points(&h->d_sx, &h->d_sy, &h->scap, n);
+  if (st != NDT_OK) return st;
+  HIP_TRY(hipMemcpyAsync(h->d_sx, sx, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_sy, sy, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  return ndt2d_align_dev(h, h->d_sx, h->d_sy, n, init_pose, out);
+}
+
+}  // extern "C"

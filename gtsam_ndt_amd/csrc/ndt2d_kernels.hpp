@@ -1,0 +1,399 @@
+// 2D NDT kernels for gfx950 (MI355X).  Hand-written HIP; wave64, DPP reductions, no MFMA
+// (point-wise gather + reduction, HBM/latency bound - BASELINE.json north_star).
+//
+// Stage map (the reference has no source to cite,
+// /root/reference/README.md:1 is its only line):
+//   k_bounds        a1  bounding box of the target cloud
+//   k_accumulate    a1+a2  cell key + exact fixed-point per-cell sums (n, Su, Suu')
+//   k_finalise      a3  sums -> Welford form (n, mean, M2) -> Sigma -> clamp -> Sigma^-1 record
+//   k_iterate<MODE> a4-a8  one launch per Gauss-Newton iteration:
+//                       prologue  = fixed-order reduction of the previous launch's block
+//                                   partials + 3x3 solve + pose update (every block, redundantly)
+//                       body      = transform, lookup, score, Jacobian, per-thread sums
+//                       epilogue  = wave DPP tree -> LDS -> one partial row per block
+#pragma once
+#include "ndt_device.hpp"
+
+namespace ndt {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 waves)
+constexpr int kMaxBlocks = 256;    // one workgroup per CU; also rows in the partials table
+constexpr int kNumAcc = 12;        // Hxx Hxy Hyy Hxt Hyt Htt gx gy gt score nhit (pad)
+constexpr int kFixShift = 22;      // fixed-point: U = rint(u * 2^22 / c), |U| <= 2^21
+constexpr unsigned kMaxCellCount = 1u << 20;  // n*U^2 < 2^63 needs n <= 2^20 per cell
+
+// ---- per-cell exact sums (48 B) -----------------------------------------------------
+struct CellAcc {
+  long long sx, sy, sxx, sxy, syy;
+  unsigned int n;
+  unsigned int pad;
+};
+
+struct GridDev {
+  float ox, oy, inv_c, cell32;
+  int W, H;
+  double cell;       // params.cell_size
+  double fix_scale;  // 2^kFixShift / cell
+  float4* recA;      // (mean_x, mean_y, a, b)
+  float2* recB;      // (c, n as float; 0 = invalid)
+  CellAcc* acc;
+};
+
+struct SolveParams {
+  float d1, d2;
+  int hessian_mode;
+  int max_iterations;
+  int fixed_iterations;
+  int min_hits;
+  double eps_trans, eps_rot, step_max_trans, step_max_rot;
+};
+
+// State handed from launch k-1 to launch k through HBM (kernel boundary = the only
+// inter-workgroup synchronisation; no in-launch hand-off, no atomics).
+struct IterState {
+  double pose[3];
+  double H[6];   // xx xy yy xt yt tt of the last evaluation
+  double g[3];
+  double score;
+  int n_hit;
+  int iter;
+  int status;
+  int done;
+  int have_partials;
+  int pad;
+};
+
+struct AlignCtx {
+  GridDev grid;
+  SolveParams prm;
+  const float* sx;
+  const float* sy;
+  int n;
+  int pad;
+  IterState state[2];
+  float partials[2][kNumAcc][kMaxBlocks];
+};
+
+// ---------------------------------------------------------------------------- a1 bounds
+__global__ __launch_bounds__(kBlock) void k_bounds(const float* __restrict__ x,
+                                                    const float* __restrict__ y, size_t n,
+                                                    unsigned int* __restrict__ out /*[4]*/) {
+  float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float a = x[i], b = y[i];
+    if (isfinite(a) && isfinite(b)) {
+      xmin = fminf(xmin, a); xmax = fmaxf(xmax, a);
+      ymin = fminf(ymin, b); ymax = fmaxf(ymax, b);
+    }
+  }
+  xmin = wave_min(xmin); xmax = wave_max(xmax);
+  ymin = wave_min(ymin); ymax = wave_max(ymax);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&out[0], float_to_ordered(xmin));
+    atomicMax(&out[1], float_to_ordered(xmax));
+    atomicMin(&out[2], float_to_ordered(ymin));
+    atomicMax(&out[3], float_to_ordered(ymax));
+  }
+}
+
+// ------------------------------------------------------------------ a1+a2 accumulate
+// Exact, order-independent per-cell sufficient statistics: cell-centred coordinates
+// quantised to c*2^-22 and summed with 64-bit integer atomics.  Integer addition is
+// associative, so the sums (and everything derived from them) are bitwise identical from
+// run to run and under any point order; merging two clouds' sums is the exact form of the
+// Chan/Welford pairwise update.
+__global__ __launch_bounds__(kBlock) void k_accumulate(const float* __restrict__ x,
+                                                        const float* __restrict__ y, size_t n,
+                                                        GridDev g,
+                                                        unsigned long long* __restrict__ n_outside) {
+  unsigned int outside = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float px = x[i], py = y[i];
+    const float fx = (px - g.ox) * g.inv_c;
+    const float fy = (py - g.oy) * g.inv_c;
+    const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H);
+    if (in) {
+      const int ix = (int)fx, iy = (int)fy;
+      const double cx = (double)g.ox + ((double)ix + 0.5) * g.cell;
+      const double cy = (double)g.oy + ((double)iy + 0.5) * g.cell;
+      const long long ux = __double2ll_rn(((double)px - cx) * g.fix_scale);
+      const long long uy = __double2ll_rn(((double)py - cy) * g.fix_scale);
+      CellAcc* c = g.acc + ((size_t)iy * g.W + ix);
+      atomicAdd(&c->n, 1u);
+      atomicAdd((unsigned long long*)&c->sx, (unsigned long long)ux);
+      atomicAdd((unsigned long long*)&c->sy, (unsigned long long)uy);
+      atomicAdd((unsigned long long*)&c->sxx, (unsigned long long)(ux * ux));
+      atomicAdd((unsigned long long*)&c->sxy, (unsigned long long)(ux * uy));
+      atomicAdd((unsigned long long*)&c->syy, (unsigned long long)(uy * uy));
+    } else {
+      outside++;
+    }
+  }
+  if (n_outside && outside) atomicAdd(n_outside, (unsigned long long)outside);
+}
+
+// ------------------------------------------------------------------------- a3 finalise
+// One thread per cell.  float64 scalar code in the order of oracle/ndt2d.py finalise_cell().
+__global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, double eig_ratio,
+                                                      int* __restrict__ counters /*[2]: valid, overflow*/) {
+  const size_t ncell = (size_t)g.W * g.H;
+  const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= ncell) return;
+  const CellAcc c = g.acc[k];
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 rb = make_float2(0.f, 0.f);
+  const int n = (int)c.n;
+  if (c.n > kMaxCellCount) atomicAdd(&counters[1], 1);
+  if (n >= min_points && n >= 2 && c.n <= kMaxCellCount) {
+    const int ix = (int)(k % g.W), iy = (int)(k / g.W);
+    const double cx = (double)g.ox + ((double)ix + 0.5) * g.cell;
+    const double cy = (double)g.oy + ((double)iy + 0.5) * g.cell;
+    const double inv_s = 1.0 / g.fix_scale;
+    const double dn = (double)n;
+    const double mx = cx + ((double)c.sx / dn) * inv_s;
+    const double my = cy + ((double)c.sy / dn) * inv_s;
+    // M2 = (n*Suu - Su*Su) / (n * S^2), numerator exact in 128-bit
+    const double den = 1.0 / (dn * g.fix_scale * g.fix_scale);
+    const double m2xx = to_double(sub128(mul_s64(n, c.sxx), mul_s64(c.sx, c.sx))) * den;
+    const double m2xy = to_double(sub128(mul_s64(n, c.sxy), mul_s64(c.sx, c.sy))) * den;
+    const double m2yy = to_double(sub128(mul_s64(n, c.syy), mul_s64(c.sy, c.sy))) * den;
+    const double sxx = m2xx / (dn - 1.0), sxy = m2xy / (dn - 1.0), syy = m2yy / (dn - 1.0);
+    const double half_tr = 0.5 * (sxx + syy);
+    const double half_df = 0.5 * (sxx - syy);
+    const double disc = sqrt(half_df * half_df + sxy * sxy);
+    const double l1 = half_tr + disc;
+    const double l2 = half_tr - disc;
+    if (l1 > 0.0) {
+      const double l2c = fmax(l2, eig_ratio * l1);
+      double ex, ey;
+      if (half_df >= 0.0) { ex = half_df + disc; ey = sxy; }
+      else                { ex = sxy; ey = disc - half_df; }
+      const double nrm = sqrt(ex * ex + ey * ey);
+      if (nrm > 0.0) { ex /= nrm; ey /= nrm; } else { ex = 1.0; ey = 0.0; }
+      const double i1 = 1.0 / l1, i2 = 1.0 / l2c, d = i1 - i2;
+      ra = make_float4((float)mx, (float)my, (float)(i2 + d * ex * ex), (float)(d * ex * ey));
+      rb = make_float2((float)(i2 + d * ey * ey), (float)n);
+      atomicAdd(&counters[0], 1);
+    }
+  }
+  g.recA[k] = ra;
+  g.recB[k] = rb;
+}
+
+// ---------------------------------------------------------------------- a8 solve/update
+// Scalar float64, same order as oracle/ndt2d.py solve3()/gn_update().
+__device__ __forceinline__ bool solve3(const double* H /*xx xy yy xt yt tt*/, const double* g,
+                                       double* d) {
+  const double h00 = H[0], h01 = H[1], h11 = H[2], h02 = H[3], h12 = H[4], h22 = H[5];
+  const double d0 = fmax(fabs(h00), 1e-12), d1 = fmax(fabs(h11), 1e-12), d2 = fmax(fabs(h22), 1e-12);
+  double lam = 0.0;
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    const double a00 = h00 + lam * d0, a11 = h11 + lam * d1, a22 = h22 + lam * d2;
+    if (a00 > 1e-12 * d0) {
+      const double l00 = sqrt(a00);
+      const double l10 = h01 / l00, l20 = h02 / l00;
+      const double p1 = a11 - l10 * l10;
+      if (p1 > 1e-12 * d1) {
+        const double l11 = sqrt(p1);
+        const double l21 = (h12 - l20 * l10) / l11;
+        const double p2 = a22 - l20 * l20 - l21 * l21;
+        if (p2 > 1e-12 * d2) {
+          const double l22 = sqrt(p2);
+          const double y0 = -g[0] / l00;
+          const double y1 = (-g[1] - l10 * y0) / l11;
+          const double y2 = (-g[2] - l20 * y0 - l21 * y1) / l22;
+          const double x2 = y2 / l22;
+          const double x1 = (y1 - l21 * x2) / l11;
+          const double x0 = (y0 - l10 * x1 - l20 * x2) / l00;
+          if (isfinite(x0) && isfinite(x1) && isfinite(x2)) {
+            d[0] = x0; d[1] = x1; d[2] = x2;
+            return true;
+          }
+        }
+      }
+    }
+    lam = (lam == 0.0) ? 1e-6 : lam * 10.0;
+  }
+  return false;
+}
+
+__device__ __forceinline__ double wrap_angle(double t) {
+  const double pi = 3.141592653589793;
+  if (t > pi || t <= -pi) {
+    t = t - 2.0 * pi * floor((t + pi) / (2.0 * pi));
+    if (t <= -pi) t += 2.0 * pi;
+  }
+  return t;
+}
+
+// returns done; updates pose/iter/status in place
+__device__ __forceinline__ bool gn_update(double* pose, const double* H, const double* g, int n_hit,
+                                          int& iter, int& status, const SolveParams& p) {
+  if (n_hit < p.min_hits) { status = 3; return true; }
+  double d[3];
+  if (!solve3(H, g, d)) { status = 2; return true; }
+  const double nt = sqrt(d[0] * d[0] + d[1] * d[1]);
+  const double nr = fabs(d[2]);
+  double alpha = 1.0;
+  if (nt > p.step_max_trans) alpha = p.step_max_trans / nt;
+  if (nr * alpha > p.step_max_rot) alpha = p.step_max_rot / nr;
+  pose[0] += d[0] * alpha;
+  pose[1] += d[1] * alpha;
+  pose[2] = wrap_angle(pose[2] + d[2] * alpha);
+  iter += 1;
+  status = 0;
+  if (p.fixed_iterations > 0) return iter >= p.fixed_iterations;
+  if (nt * alpha < p.eps_trans && nr * alpha < p.eps_rot) return true;
+  if (iter >= p.max_iterations) { status = 1; return true; }
+  return false;
+}
+
+// ---------------------------------------------------------------- a4-a8 iterate kernel
+// Launch k (parity = k & 1) consumes state[parity^1] and partials[parity^1] written by
+// launch k-1 and produces state[parity], partials[parity].
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_iterate(AlignCtx* __restrict__ ctx, int parity) {
+  __shared__ double s_red[kNumAcc];
+  __shared__ float s_wave[kBlock / 64][kNumAcc];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const IterState* prev = &ctx->state[parity ^ 1];
+  IterState* cur = &ctx->state[parity];
+  const bool writer = (blockIdx.x == 0) && (tid == 0);
+
+  if (prev->done) {                      // uniform: a finished alignment just carries its state
+    if (writer) *cur = *prev;
+    return;
+  }
+  const int n = ctx->n;
+  const float* __restrict__ sx = ctx->sx;
+  const float* __restrict__ sy = ctx->sy;
+  const int stride = gridDim.x * kBlock;
+  int i = blockIdx.x * kBlock + tid;
+  // issue the first point load before the prologue so its latency hides under the solve
+  float x = 0.f, y = 0.f;
+  if (i < n) { x = sx[i]; y = sy[i]; }
+
+  double pose[3] = {prev->pose[0], prev->pose[1], prev->pose[2]};
+  int iter = prev->iter;
+  if (prev->have_partials) {
+    // ---- prologue: reduce previous partials in a fixed order (wave w owns sums 3w..3w+2)
+    const float* part = &ctx->partials[parity ^ 1][0][0];
+    const int P = gridDim.x;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int j = wave * 3 + v;
+      double a = 0.0;
+      for (int b = lane; b < P; b += 64) a += (double)part[j * kMaxBlocks + b];
+      a = wave_sum_lane63(a);
+      if (lane == 63) s_red[j] = a;
+    }
+    __syncthreads();
+    double H[6], g[3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) H[j] = s_red[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[j] = s_red[6 + j];
+    const double score = s_red[9];
+    const int n_hit = (int)(s_red[10] + 0.5);
+    int status = 0;
+    const bool done = gn_update(pose, H, g, n_hit, iter, status, ctx->prm);
+    if (writer) {
+      cur->pose[0] = pose[0]; cur->pose[1] = pose[1]; cur->pose[2] = pose[2];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) cur->H[j] = H[j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cur->g[j] = g[j];
+      cur->score = score;
+      cur->n_hit = n_hit;
+      cur->iter = iter;
+      cur->status = status;
+      cur->done = done ? 1 : 0;
+      cur->have_partials = 1;
+    }
+    if (done) return;                    // uniform
+  } else if (writer) {
+    *cur = *prev;
+    cur->have_partials = 1;
+  }
+
+  // ---- body: per-point terms at `pose`
+  double sn_d, cs_d;
+  sincos(pose[2], &sn_d, &cs_d);
+  const float cs = (float)cs_d, sn = (float)sn_d;
+  const float tx = (float)pose[0], ty = (float)pose[1];
+  const GridDev& G = ctx->grid;
+  const float ox = G.ox, oy = G.oy, inv_c = G.inv_c;
+  const int W = G.W, Hh = G.H;
+  const float fW = (float)W, fH = (float)Hh;
+  const float4* __restrict__ recA = G.recA;
+  const float2* __restrict__ recB = G.recB;
+  const float d1 = ctx->prm.d1, d2 = ctx->prm.d2;
+  const float nhd2 = -0.5f * d2 * 1.44269504088896340736f;   // exp(-d2/2 m) = exp2(nhd2*m)
+
+  float acc[kNumAcc];
+#pragma unroll
+  for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.f;
+
+  while (i < n) {
+    const int inext = i + stride;
+    float xn = 0.f, yn = 0.f;
+    if (inext < n) { xn = sx[inext]; yn = sy[inext]; }
+    float px = fmaf(cs, x, fmaf(-sn, y, tx));
+    float py = fmaf(sn, x, fmaf(cs, y, ty));
+    const float fx = (px - ox) * inv_c;
+    const float fy = (py - oy) * inv_c;
+    const bool in = (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH);   // false for NaN/inf
+    const int key = in ? ((int)fy * W + (int)fx) : 0;
+    if (!in) { px = 0.f; py = 0.f; x = 0.f; y = 0.f; }   // keep 0*NaN out of the sums
+    const float4 A = recA[key];
+    const float2 B = recB[key];
+    const bool hit = in & (B.y > 0.f);
+    const float qx = px - A.x, qy = py - A.y;
+    const float a = A.z, b = A.w, c = B.x;
+    const float vx = fmaf(a, qx, b * qy);
+    const float vy = fmaf(b, qx, c * qy);
+    const float m = fmaf(qx, vx, qy * vy);
+    const float s = hit ? d1 * __builtin_amdgcn_exp2f(nhd2 * m) : 0.f;
+    const float w = s * d2;
+    const float jx = fmaf(-sn, x, -cs * y);
+    const float jy = fmaf(cs, x, -sn * y);
+    const float vt = fmaf(vx, jx, vy * jy);
+    const float ux = fmaf(a, jx, b * jy);
+    const float uy = fmaf(b, jx, c * jy);
+    float hxx = a, hxy = b, hyy = c, hxt = ux, hyt = uy, htt = fmaf(jx, ux, jy * uy);
+    if (MODE == 1) {   // full Newton Hessian (Biber / Magnusson)
+      hxx = fmaf(-d2 * vx, vx, hxx);
+      hxy = fmaf(-d2 * vx, vy, hxy);
+      hyy = fmaf(-d2 * vy, vy, hyy);
+      hxt = fmaf(-d2 * vx, vt, hxt);
+      hyt = fmaf(-d2 * vy, vt, hyt);
+      htt = fmaf(-d2 * vt, vt, htt) + fmaf(vy, jx, -vx * jy);
+    }
+    acc[0] = fmaf(w, hxx, acc[0]);
+    acc[1] = fmaf(w, hxy, acc[1]);
+    acc[2] = fmaf(w, hyy, acc[2]);
+    acc[3] = fmaf(w, hxt, acc[3]);
+    acc[4] = fmaf(w, hyt, acc[4]);
+    acc[5] = fmaf(w, htt, acc[5]);
+    acc[6] = fmaf(w, vx, acc[6]);
+    acc[7] = fmaf(w, vy, acc[7]);
+    acc[8] = fmaf(w, vt, acc[8]);
+    acc[9] += s;
+    acc[10] += hit ? 1.f : 0.f;
+    x = xn; y = yn; i = inext;
+  }
+
+  // ---- epilogue: wave tree -> LDS -> one partial row per block
+#pragma unroll
+  for (int j = 0; j < kNumAcc - 1; ++j) {
+    const float r = wave_sum_lane63(acc[j]);
+    if (lane == 63) s_wave[wave][j] = r;
+  }
+  __syncthreads();
+  if (tid < kNumAcc - 1) {
+    const float r = ((s_wave[0][tid] + s_wave[1][tid]) + s_wave[2][tid]) + s_wave[3][tid];
+    ctx->partials[parity][tid][blockIdx.x] = r;
+  }
+}
+
+}  // namespace ndt

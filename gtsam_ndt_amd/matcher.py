@@ -1,0 +1,181 @@
+"""Host-side mirror of the scan-matcher interface, over the C-ABI (include/ndt_hip.h).
+
+``NdtMatcher2D`` is the Python twin of the C++ adapter ``ndt::NdtMatcherHip``
+(include/ndt_matcher_hip.hpp): set a target scan/submap, align a source scan from an
+initial SE(2) guess, get back pose + information matrix - the quantities a
+scan-matcher -> GTSAM BetweenFactor<Pose2> bridge needs (BASELINE.json north_star; the
+reference's own interface is not observable, /root/reference/README.md:1).
+
+numpy arrays go through the host-pointer entry points; torch CUDA tensors (or any object
+with ``data_ptr()``) go through the ``_dev`` entry points without a copy.  PyTorch is only
+plumbing for device memory here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+
+@dataclass
+class AlignResult:
+    pose: tuple            # (tx, ty, theta)
+    H: np.ndarray          # 3x3 Hessian of -score (information up to score scaling)
+    g: np.ndarray
+    score: float
+    iterations: int
+    n_hit: int
+    status: int
+
+    @property
+    def converged(self) -> bool:
+        return self.status == L.NDT_OK
+
+    def covariance(self) -> np.ndarray:
+        """H^-1: the covariance a BetweenFactor noise model would be built from."""
+        return np.linalg.inv(self.H)
+
+
+def default_params(**overrides) -> L.Params2D:
+    p = L.Params2D()
+    L.load().ndt2d_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(f"ndt2d_params has no field {k!r}")
+        setattr(p, k, v)
+    return p
+
+
+def _is_dev(a) -> bool:
+    return hasattr(a, "data_ptr")
+
+
+def _host_f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _dev_ptr(t, n: int):
+    import torch
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+        raise ValueError("device arrays must be contiguous float32 CUDA tensors of equal length")
+    return C.c_void_p(t.data_ptr())
+
+
+def _to_result(r: L.Result2D) -> AlignResult:
+    return AlignResult(tuple(r.pose), np.array(r.H, dtype=np.float64).reshape(3, 3),
+                       np.array(r.g, dtype=np.float64), float(r.score), int(r.iterations),
+                       int(r.n_hit), int(r.status))
+
+
+class NdtMatcher2D:
+    """One handle = one device stream + one cached target grid."""
+
+    def __init__(self, device: int = 0, params: L.Params2D | None = None, **overrides):
+        self._lib = L.load()
+        self.params = params if params is not None else default_params(**overrides)
+        if params is not None:
+            for k, v in overrides.items():
+                setattr(self.params, k, v)
+        h = C.c_void_p()
+        L.check(self._lib.ndt2d_create(C.byref(self.params), int(device), C.byref(h)), "ndt2d_create")
+        self._h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndt2d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- (i) target grid
+    def set_target(self, x, y):
+        if _is_dev(x):
+            import torch
+            n = x.numel()
+            st = self._lib.ndt2d_set_target_dev(self._h, _dev_ptr(x, n), _dev_ptr(y, n), n,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        else:
+            x, y = _host_f32(x), _host_f32(y)
+            if x.shape != y.shape or x.ndim != 1:
+                raise ValueError("x and y must be 1-D arrays of equal length")
+            st = self._lib.ndt2d_set_target(self._h, x.ctypes.data, y.ctypes.data, x.size)
+        L.check(st, "ndt2d_set_target")
+        return self.grid_info()
+
+    def add_target_points(self, x, y) -> int:
+        x, y = _host_f32(x), _host_f32(y)
+        out = C.c_size_t(0)
+        L.check(self._lib.ndt2d_add_target_points(self._h, x.ctypes.data, y.ctypes.data, x.size, C.byref(out)),
+                "ndt2d_add_target_points")
+        return int(out.value)
+
+    def grid_info(self) -> L.GridInfo2D:
+        info = L.GridInfo2D()
+        L.check(self._lib.ndt2d_get_grid_info(self._h, C.byref(info)), "ndt2d_get_grid_info")
+        return info
+
+    def grid(self):
+        """(count int32 [H*W], mean float32 [H*W,2], icov float32 [H*W,3]) of the cached grid."""
+        info = self.grid_info()
+        nc = info.width * info.height
+        count = np.zeros(nc, dtype=np.int32)
+        mean = np.zeros((nc, 2), dtype=np.float32)
+        icov = np.zeros((nc, 3), dtype=np.float32)
+        L.check(self._lib.ndt2d_get_grid(self._h, count.ctypes.data, mean.ctypes.data, icov.ctypes.data),
+                "ndt2d_get_grid")
+        return count, mean, icov
+
+    # ---- (ii)+(iii) one evaluation
+    def evaluate(self, sx, sy, pose):
+        sx, sy = _host_f32(sx), _host_f32(sy)
+        p = (C.c_double * 3)(*[float(v) for v in pose])
+        out = L.Eval2D()
+        L.check(self._lib.ndt2d_evaluate(self._h, sx.ctypes.data, sy.ctypes.data, sx.size, p, C.byref(out)),
+                "ndt2d_evaluate")
+        return (np.array(out.H, dtype=np.float64).reshape(3, 3), np.array(out.g, dtype=np.float64),
+                float(out.score), int(out.n_hit))
+
+    # ---- full alignment
+    def align(self, sx, sy, init_pose=(0.0, 0.0, 0.0)) -> AlignResult:
+        p = (C.c_double * 3)(*[float(v) for v in init_pose])
+        r = L.Result2D()
+        if _is_dev(sx):
+            n = sx.numel()
+            st = self._lib.ndt2d_align_dev(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), n, p, C.byref(r))
+        else:
+            sx, sy = _host_f32(sx), _host_f32(sy)
+            st = self._lib.ndt2d_align(self._h, sx.ctypes.data, sy.ctypes.data, sx.size, p, C.byref(r))
+        L.check(st, "ndt2d_align")
+        return _to_result(r)
+
+    def align_async(self, sx, sy, init_pose=(0.0, 0.0, 0.0)):
+        """Enqueue the whole loop on the handle's stream (device tensors only)."""
+        p = (C.c_double * 3)(*[float(v) for v in init_pose])
+        n = sx.numel()
+        self._keep = (sx, sy)
+        L.check(self._lib.ndt2d_align_dev_async(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), n, p),
+                "ndt2d_align_dev_async")
+
+    def finish(self) -> AlignResult:
+        r = L.Result2D()
+        L.check(self._lib.ndt2d_align_finish(self._h, C.byref(r)), "ndt2d_align_finish")
+        self._keep = None
+        return _to_result(r)
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.ndt2d_stream(self._h) or 0)

@@ -1,0 +1,154 @@
+/*
+ * ndt_hip.h - C ABI of the MI355X (gfx950) NDT scan matcher.
+ *
+ * Drop-in boundary.  BASELINE.json's north_star names the interface
+ * this library sits behind - "the repo's existing scan-matcher -> GTSAM-factor interface" -
+ * but the reference checkout contains no header, class or signature for it:
+ * /root/reference/README.md:1 ("# GTSAM-NDT") is the only line of the only file.  Each
+ * entry point below therefore cites the SURVEY.md section 8 row it implements instead of a
+ * reference file:line; INTEGRATION.md shows the adapter a maintainer of the reference
+ * would write against this header once the real interface is visible.
+ *
+ * Conventions
+ *   - extern "C", opaque handles, plain pointers and sizes, POD structs.  No C++ or torch
+ *     types cross this boundary.
+ *   - Every function returns an int32 status: 0 = NDT_OK; > 0 = numerical outcome of an
+ *     alignment (also stored in ndt2d_result.status); < 0 = usage / HIP error.  No
+ *     exception crosses the ABI; HIP errors are captured and returned.
+ *   - Host-pointer entry points borrow the caller's buffers for the duration of the call
+ *     and are synchronous.  "_dev" entry points take device pointers (any allocator:
+ *     hipMalloc, torch) and enqueue on the given hipStream_t (passed as void*); results
+ *     written to device memory are valid after that stream is synchronised.
+ *   - A handle is single-threaded; distinct handles may be used from distinct threads.
+ *   - Points are SoA float32 arrays (x[], y[]); poses are double (tx, ty, theta).
+ *   - There is NO CPU fallback: every entry point that computes needs a gfx950 device.
+ */
+#ifndef NDT_HIP_H_
+#define NDT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDT_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------- */
+enum {
+  NDT_OK = 0,
+  NDT_NOT_CONVERGED = 1,      /* max_iterations reached                              */
+  NDT_DEGENERATE_HESSIAN = 2, /* H + lambda*diag(H) never became positive definite    */
+  NDT_TOO_FEW_HITS = 3,       /* fewer than min_hits source points fell in valid cells */
+  NDT_TOO_FEW_CELLS = 4,      /* target grid has no valid cell                        */
+  NDT_ERR_INVALID_ARG = -1,
+  NDT_ERR_NO_TARGET = -2,
+  NDT_ERR_HIP = -3,
+  NDT_ERR_NO_DEVICE = -4,
+  NDT_ERR_CAPACITY = -5,      /* a per-cell or per-grid capacity limit was exceeded   */
+  NDT_ERR_ALLOC = -6
+};
+
+enum { NDT_HESSIAN_GAUSS_NEWTON = 0, NDT_HESSIAN_NEWTON = 1 };
+
+/* ---- parameters (SURVEY.md section 5 "Config/flags": one POD at handle creation) -- */
+typedef struct ndt2d_params {
+  double cell_size;        /* c, metres                                   (row a1) */
+  int32_t min_points;      /* a cell is valid iff n >= min_points          (row a3) */
+  int32_t hessian_mode;    /* NDT_HESSIAN_*                                (row a6) */
+  double eig_ratio;        /* lambda_min clamped to eig_ratio*lambda_max   (row a3) */
+  double d1, d2;           /* score = sum d1*exp(-d2/2 * q' S^-1 q)        (row a5) */
+  int32_t max_iterations;  /* cap on Gauss-Newton updates                  (row a8) */
+  int32_t fixed_iterations;/* > 0: run exactly this many updates, no convergence test */
+  double eps_trans;        /* converged when |dt| < eps_trans and ...      (row a8) */
+  double eps_rot;          /* ... |dtheta| < eps_rot                               */
+  double step_max_trans;   /* step is scaled so |dt| <= step_max_trans     (row a8) */
+  double step_max_rot;     /* ... and |dtheta| <= step_max_rot                     */
+  int32_t min_hits;        /* fewer hits than this => NDT_TOO_FEW_HITS             */
+  int32_t reserved;
+} ndt2d_params;
+
+/* ---- result (row a9) ------------------------------------------------------------ */
+typedef struct ndt2d_result {
+  double pose[3];     /* tx, ty, theta: maps source-frame points into the target frame */
+  double H[9];        /* row-major 3x3 Hessian of -score at the last evaluated pose     */
+  double g[3];        /* gradient of -score at the last evaluated pose                  */
+  double score;       /* sum of per-point scores at the last evaluated pose             */
+  int32_t iterations; /* Gauss-Newton updates applied                                   */
+  int32_t n_hit;      /* source points that fell in a valid cell at the last evaluation */
+  int32_t status;     /* NDT_OK / NDT_NOT_CONVERGED / ...                               */
+  int32_t reserved;
+} ndt2d_result;
+
+/* one evaluation at a fixed pose (rows a4-a7), for stage parity tests and callers that
+ * run their own optimiser */
+typedef struct ndt2d_eval {
+  double H[9];
+  double g[3];
+  double score;
+  int32_t n_hit;
+  int32_t reserved;
+} ndt2d_eval;
+
+/* geometry of the cached target grid (rows a1-a3) */
+typedef struct ndt2d_grid_info {
+  float ox, oy;       /* origin (lower-left corner of cell 0)  */
+  float inv_cell;     /* float32(1/cell_size)                  */
+  float cell;
+  int32_t width, height;
+  int32_t n_valid;    /* cells with n >= min_points and a usable covariance */
+  int32_t n_points;   /* target points binned                                */
+} ndt2d_grid_info;
+
+typedef struct ndt2d_handle ndt2d_handle;
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+int32_t ndt_abi_version(void);
+const char* ndt_status_string(int32_t status);
+/* last HIP error text captured on this thread ("" if none) */
+const char* ndt_last_error(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int32_t ndt_device_count(void);
+
+void ndt2d_default_params(ndt2d_params* p);
+int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** out);
+int32_t ndt2d_destroy(ndt2d_handle* h);
+
+/* ---- (i) target voxel grid: rows a1-a3 ---------------------------------------------- */
+/* Builds and caches the NDT grid of a target cloud. */
+int32_t ndt2d_set_target(ndt2d_handle* h, const float* x, const float* y, size_t n);
+int32_t ndt2d_set_target_dev(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n,
+                             void* stream);
+/* Incremental submap update: bins n more points into the
+ * cached grid's exact per-cell sums and re-finalises.  Points outside the cached extent
+ * are counted in *n_outside (may be NULL) and ignored. */
+int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y, size_t n,
+                                size_t* n_outside);
+int32_t ndt2d_get_grid_info(ndt2d_handle* h, ndt2d_grid_info* info);
+/* Copies the finalised cell records to host arrays of width*height entries each
+ * (any pointer may be NULL): count, mean (x,y interleaved), icov (a,b,c interleaved). */
+int32_t ndt2d_get_grid(ndt2d_handle* h, int32_t* count, float* mean_xy, float* icov_abc);
+
+/* ---- (ii)+(iii) evaluation at a fixed pose: rows a4-a7 ------------------------------- */
+int32_t ndt2d_evaluate(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
+                       const double pose[3], ndt2d_eval* out);
+
+/* ---- full alignment: rows a4-a9 ------------------------------------------------------ */
+int32_t ndt2d_align(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
+                    const double init_pose[3], ndt2d_result* out);
+/* Source already on the device.  Synchronous in the result (out is host memory). */
+int32_t ndt2d_align_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
+                        const double init_pose[3], ndt2d_result* out);
+/* Fully asynchronous form for timing and pipelining: enqueues the whole Gauss-Newton
+ * loop on the handle's stream and returns; ndt2d_align_finish() waits and fetches. */
+int32_t ndt2d_align_dev_async(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
+                              const double init_pose[3]);
+int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out);
+/* hipStream_t the handle enqueues on (as void*), for event timing by the caller */
+void* ndt2d_stream(ndt2d_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDT_HIP_H_ */
