@@ -33,9 +33,11 @@ struct ndt2d_handle {
   // staging for host-pointer entry points
   float* d_tx = nullptr; float* d_ty = nullptr; size_t tcap = 0;
   float* d_sx = nullptr; float* d_sy = nullptr; size_t scap = 0;
-  // alignment context
-  AlignCtx* d_ctx = nullptr;
-  AlignCtx* h_ctx = nullptr;               // pinned; only the header (up to partials) is used
+  // alignment context (see ndt2d_kernels.hpp: who writes what)
+  AlignStatic* d_static = nullptr;
+  AlignCall* d_call = nullptr;
+  AlignDyn* d_dyn = nullptr;
+  AlignStatic* h_static = nullptr;         // pinned
   IterState* h_state = nullptr;            // pinned
   int last_parity = 0;
   bool pending = false;
@@ -48,7 +50,6 @@ struct ndt2d_handle {
 
 namespace {
 
-constexpr size_t kStaticBytes = offsetof(AlignCtx, sx);
 constexpr size_t kMaxCells = (size_t)1 << 27;
 
 int32_t check_params(const ndt2d_params* p) {
@@ -74,12 +75,7 @@ int32_t ensure_points(float** dx, float** dy, size_t* cap, size_t n) {
   return NDT_OK;
 }
 
-int blocks_for(size_t n) {
-  size_t b = (n + kBlock - 1) / kBlock;
-  if (b < 1) b = 1;
-  if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
-  return (int)b;
-}
+int blocks_for(size_t) { return kMaxBlocks; }   // one workgroup per CU, always (see k_iterate)
 
 int stream_blocks(size_t n) {   // streaming kernels: up to 8 blocks per CU
   size_t b = (n + kBlock - 1) / kBlock;
@@ -165,29 +161,29 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
 // whenever the target changes; the per-call part is written by k_begin from kernel arguments,
 // so no host buffer has to outlive an asynchronous call.
 int32_t upload_static(ndt2d_handle* h) {
-  AlignCtx* c = h->h_ctx;
+  AlignStatic* c = h->h_static;
   c->grid = h->grid;
   SolveParams& p = c->prm;
   p.d1 = (float)h->prm.d1;
   p.d2 = (float)h->prm.d2;
   p.hessian_mode = h->prm.hessian_mode;
   p.max_iterations = h->prm.max_iterations;
-  p.fixed_iterations = h->prm.fixed_iterations;
   p.min_hits = h->prm.min_hits;
+  p.pad = 0;
   p.eps_trans = h->prm.eps_trans;
   p.eps_rot = h->prm.eps_rot;
   p.step_max_trans = h->prm.step_max_trans;
   p.step_max_rot = h->prm.step_max_rot;
-  HIP_TRY(hipMemcpyAsync(h->d_ctx, c, kStaticBytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_static, c, sizeof(AlignStatic), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NDT_OK;
 }
 
 void launch_iter(ndt2d_handle* h, int blocks, int k) {
   if (h->prm.hessian_mode == NDT_HESSIAN_NEWTON)
-    hipLaunchKernelGGL(k_iterate<1>, dim3(blocks), dim3(kBlock), 0, h->stream, h->d_ctx, k & 1);
+    hipLaunchKernelGGL((k_iterate<1, 0>), dim3(blocks), dim3(kBlock), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
   else
-    hipLaunchKernelGGL(k_iterate<0>, dim3(blocks), dim3(kBlock), 0, h->stream, h->d_ctx, k & 1);
+    hipLaunchKernelGGL((k_iterate<0, 0>), dim3(blocks), dim3(kBlock), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
 }
 
 void drop_graph(ndt2d_handle* h) {
@@ -197,8 +193,8 @@ void drop_graph(ndt2d_handle* h) {
 }
 
 // Graph of `launches` consecutive k_iterate launches starting at parity 0.  The kernels read
-// everything (grid, source pointers, n, parameters, state) from *d_ctx, so one graph serves
-// every target and source of the same block count.
+// everything (grid, source pointers, n, parameters, state) from device memory, so one graph
+// serves every target and every source.
 int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
   if (h->graph_exec && h->graph_launches == launches && h->graph_blocks == blocks &&
       h->graph_mode == h->prm.hessian_mode)
@@ -229,7 +225,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
     h->h_state->done = 2;               // marks "result already on the host"
     return NDT_OK;
   }
-  hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_ctx, d_sx, d_sy, (int)n, pose[0], pose[1],
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, d_sx, d_sy, (int)n, pose[0], pose[1],
                      pose[2], fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations);
   const int fixed = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
   const int K = fixed > 0 ? fixed : h->prm.max_iterations;
@@ -245,7 +241,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
         HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
         k += chunk;
         if (k > K) break;
-        HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_ctx->state[1], sizeof(IterState), hipMemcpyDeviceToHost,
+        HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[1], sizeof(IterState), hipMemcpyDeviceToHost,
                                h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->h_state->done) break;
@@ -261,7 +257,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
       launch_iter(h, blocks, k);
       if (check_every > 0 && fixed == 0 && k < K && (k % check_every) == check_every - 1) {
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_ctx->state[k & 1], sizeof(IterState), hipMemcpyDeviceToHost,
+        HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[k & 1], sizeof(IterState), hipMemcpyDeviceToHost,
                                h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->h_state->done) { ++k; break; }
@@ -277,7 +273,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
 
 int32_t fetch_state(ndt2d_handle* h) {
   if (h->pending) {
-    HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_ctx->state[h->last_parity], sizeof(IterState),
+    HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[h->last_parity], sizeof(IterState),
                            hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->pending = false;
@@ -359,11 +355,13 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipMalloc((void**)&h->d_bounds, 4 * sizeof(unsigned int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_counters, 2 * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_outside, sizeof(unsigned long long)) != hipSuccess) return fail(NDT_ERR_ALLOC);
-  if (hipMalloc((void**)&h->d_ctx, sizeof(AlignCtx)) != hipSuccess) return fail(NDT_ERR_ALLOC);
-  if (hipHostMalloc((void**)&h->h_ctx, kStaticBytes, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_static, sizeof(AlignStatic)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_call, sizeof(AlignCall)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_dyn, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc((void**)&h->h_static, sizeof(AlignStatic), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_state, sizeof(IterState), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
-  if (hipMemset(h->d_ctx, 0, sizeof(AlignCtx)) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
   { const char* e = std::getenv("NDT_DEBUG_NO_GRAPH"); h->use_graph = !(e && e[0] == '1'); }
   *out = h;
   return NDT_OK;
@@ -374,10 +372,10 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
-  void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_ctx, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
+  void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
                  h->grid.recA, h->grid.recB, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {h->h_ctx, h->h_state, h->h_small};
+  void* host[] = {h->h_static, h->h_state, h->h_small};
   for (void* p : host) if (p) (void)hipHostFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

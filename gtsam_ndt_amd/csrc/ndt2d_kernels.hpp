@@ -43,8 +43,8 @@ struct SolveParams {
   float d1, d2;
   int hessian_mode;
   int max_iterations;
-  int fixed_iterations;
   int min_hits;
+  int pad;
   double eps_trans, eps_rot, step_max_trans, step_max_rot;
 };
 
@@ -63,13 +63,22 @@ struct IterState {
   int pad;
 };
 
-struct AlignCtx {
+// Device context, split by who writes it so that the read-only parts can be fetched with
+// scalar loads in one batch at kernel entry:
+//   AlignStatic  grid + solver parameters; uploaded by the host when the target changes
+//   AlignCall    per-alignment arguments; written by k_begin
+//   AlignDyn     iteration state and block partials; written by k_iterate
+struct AlignStatic {
   GridDev grid;
   SolveParams prm;
+};
+struct AlignCall {
   const float* sx;
   const float* sy;
   int n;
-  int pad;
+  int fixed_iterations;
+};
+struct AlignDyn {
   IterState state[2];
   float partials[2][kNumAcc][kMaxBlocks];
 };
@@ -270,7 +279,7 @@ __device__ __forceinline__ void sincos_wrapped(double t, double* sn, double* cs)
 
 // returns done; updates pose/iter/status in place
 __device__ __forceinline__ bool gn_update(double* pose, const double* H, const double* g, int n_hit,
-                                          int& iter, int& status, const SolveParams& p) {
+                                          int& iter, int& status, const SolveParams& p, int fixed_iterations) {
   if (n_hit < p.min_hits) { status = 3; return true; }
   double d[3];
   if (!solve3(H, g, d)) { status = 2; return true; }
@@ -284,92 +293,206 @@ __device__ __forceinline__ bool gn_update(double* pose, const double* H, const d
   pose[2] = wrap_angle(pose[2] + d[2] * alpha);
   iter += 1;
   status = 0;
-  if (p.fixed_iterations > 0) return iter >= p.fixed_iterations;
+  if (fixed_iterations > 0) return iter >= fixed_iterations;
   if (nt2 * alpha * alpha < p.eps_trans * p.eps_trans && nr * alpha < p.eps_rot) return true;
   if (iter >= p.max_iterations) { status = 1; return true; }
   return false;
 }
 
 // Per-call part of the context, written from kernel arguments (no host buffer lifetime).
-__global__ void k_begin(AlignCtx* __restrict__ ctx, const float* sx, const float* sy, int n, double p0,
-                        double p1, double p2, int fixed_iterations) {
+__global__ void k_begin(AlignCall* __restrict__ call, AlignDyn* __restrict__ dyn, const float* sx,
+                        const float* sy, int n, double p0, double p1, double p2, int fixed_iterations) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  ctx->sx = sx;
-  ctx->sy = sy;
-  ctx->n = n;
-  ctx->prm.fixed_iterations = fixed_iterations;
+  call->sx = sx;
+  call->sy = sy;
+  call->n = n;
+  call->fixed_iterations = fixed_iterations;
   IterState s = {};
   s.pose[0] = p0; s.pose[1] = p1; s.pose[2] = wrap_angle(p2);
-  ctx->state[1] = s;            // launch 0 has parity 0 and reads slot 1
-  ctx->state[0] = IterState{};
+  dyn->state[1] = s;            // launch 0 has parity 0 and reads slot 1
+  dyn->state[0] = IterState{};
+}
+
+// ---- per-point pieces of the body (rows a4-a6) ------------------------------------------
+struct PoseF {
+  float cs, sn, tx, ty, ox, oy, inv_c, fW, fH;
+  int W;
+  float d1, d2, nhd2;
+};
+struct PointRec {
+  float x, y, px, py;   // source point (zeroed when it misses the grid) and its image
+  float4 A;             // mean_x, mean_y, a, b
+  float2 B;             // c, n
+  bool in;
+};
+
+// a4: transform + cell key + record gather (loads only; nothing is consumed here)
+__device__ __forceinline__ void lookup_point(const PoseF& P, const float4* __restrict__ recA,
+                                             const float2* __restrict__ recB, float x, float y, bool live,
+                                             PointRec& r) {
+  float px = fmaf(P.cs, x, fmaf(-P.sn, y, P.tx));
+  float py = fmaf(P.sn, x, fmaf(P.cs, y, P.ty));
+  const float fx = (px - P.ox) * P.inv_c;
+  const float fy = (py - P.oy) * P.inv_c;
+  const bool in = live & (fx >= 0.f) & (fx < P.fW) & (fy >= 0.f) & (fy < P.fH);   // false for NaN/inf
+  const int key = in ? ((int)fy * P.W + (int)fx) : 0;
+  if (!in) { px = 0.f; py = 0.f; x = 0.f; y = 0.f; }   // keep 0*NaN out of the sums
+  r.x = x; r.y = y; r.px = px; r.py = py; r.in = in;
+  r.A = recA[key];
+  r.B = recB[key];
+}
+
+// a5+a6: Mahalanobis score, SE(2) Jacobian, gradient / Hessian terms into the thread's sums
+template <int MODE>
+__device__ __forceinline__ void accumulate_point(const PoseF& P, const PointRec& r, float* acc) {
+  const bool hit = r.in & (r.B.y > 0.f);
+  const float qx = r.px - r.A.x, qy = r.py - r.A.y;
+  const float a = r.A.z, b = r.A.w, c = r.B.x;
+  const float vx = fmaf(a, qx, b * qy);
+  const float vy = fmaf(b, qx, c * qy);
+  const float m = fmaf(qx, vx, qy * vy);
+  const float s = hit ? P.d1 * __builtin_amdgcn_exp2f(P.nhd2 * m) : 0.f;
+  const float w = s * P.d2;
+  const float jx = fmaf(-P.sn, r.x, -P.cs * r.y);
+  const float jy = fmaf(P.cs, r.x, -P.sn * r.y);
+  const float vt = fmaf(vx, jx, vy * jy);
+  const float ux = fmaf(a, jx, b * jy);
+  const float uy = fmaf(b, jx, c * jy);
+  float hxx = a, hxy = b, hyy = c, hxt = ux, hyt = uy, htt = fmaf(jx, ux, jy * uy);
+  if (MODE == 1) {   // full Newton Hessian (Biber / Magnusson)
+    hxx = fmaf(-P.d2 * vx, vx, hxx);
+    hxy = fmaf(-P.d2 * vx, vy, hxy);
+    hyy = fmaf(-P.d2 * vy, vy, hyy);
+    hxt = fmaf(-P.d2 * vx, vt, hxt);
+    hyt = fmaf(-P.d2 * vy, vt, hyt);
+    htt = fmaf(-P.d2 * vt, vt, htt) + fmaf(vy, jx, -vx * jy);
+  }
+  acc[0] = fmaf(w, hxx, acc[0]);
+  acc[1] = fmaf(w, hxy, acc[1]);
+  acc[2] = fmaf(w, hyy, acc[2]);
+  acc[3] = fmaf(w, hxt, acc[3]);
+  acc[4] = fmaf(w, hyt, acc[4]);
+  acc[5] = fmaf(w, htt, acc[5]);
+  acc[6] = fmaf(w, vx, acc[6]);
+  acc[7] = fmaf(w, vy, acc[7]);
+  acc[8] = fmaf(w, vt, acc[8]);
+  acc[9] += s;
+  acc[10] += hit ? 1.f : 0.f;
+}
+
+// 128-byte state copy without a struct temporary (a by-value IterState lands in scratch)
+__device__ __forceinline__ void copy_state(IterState* dst, const IterState* src, int have_partials) {
+  static_assert(sizeof(IterState) == 128, "IterState is copied as 8 x 16 bytes");
+  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+  uint4* d4 = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d4[j] = s4[j];
+  if (have_partials >= 0) dst->have_partials = have_partials;
 }
 
 // ---------------------------------------------------------------- a4-a8 iterate kernel
 // Launch k (parity = k & 1) consumes state[parity^1] and partials[parity^1] written by
-// launch k-1 and produces state[parity], partials[parity].
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_iterate(AlignCtx* __restrict__ ctx, int parity) {
+// launch k-1 and produces state[parity], partials[parity].  Always kMaxBlocks workgroups
+// (one per CU); a workgroup without points contributes a zero partial row.
+//
+// The iteration is a serial dependence chain (reduce -> solve -> transform -> gather ->
+// reduce), so the kernel is written to keep the number of dependent memory round trips at
+// two: everything the prologue needs (previous state, partial rows, first source point) is
+// requested up front in one batch, then the cell-record gather.
+// EXP is an ablation mask for tools/exp_iter.hip only (1: no reduce/solve, 2: no body,
+// 4: no epilogue tree, 8: empty); the library instantiates EXP = 0.
+template <int MODE, int EXP = 0>
+__global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restrict__ st,
+                                                    const AlignCall* __restrict__ call,
+                                                    AlignDyn* __restrict__ dyn, int parity) {
   __shared__ double s_red[kNumAcc];
   __shared__ float s_wave[kBlock / 64][kNumAcc];
+  if (EXP & 8) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const IterState* prev = &ctx->state[parity ^ 1];
-  IterState* cur = &ctx->state[parity];
+  const IterState* prev = &dyn->state[parity ^ 1];
+  IterState* cur = &dyn->state[parity];
   const bool writer = (blockIdx.x == 0) && (tid == 0);
 
-  if (prev->done) {                      // uniform: a finished alignment just carries its state
-    if (writer) *cur = *prev;
+  // ---- batch 1 of loads: previous state (scalar), partial rows (vector), first point
+  const double ps_pose0 = prev->pose[0], ps_pose1 = prev->pose[1], ps_pose2 = prev->pose[2];
+  const int ps_iter = prev->iter, ps_done = prev->done, ps_have = prev->have_partials;
+  const SolveParams prm = st->prm;       // read-only: scalar loads, all in this first batch
+  const GridDev G = st->grid;
+  const int n = call->n;
+  const int fixed_iterations = call->fixed_iterations;
+  const float* __restrict__ sx = call->sx;
+  const float* __restrict__ sy = call->sy;
+  float4 pv[3];
+  if (!(EXP & 1)) {
+    const float* part = &dyn->partials[parity ^ 1][0][0];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+      pv[v] = *reinterpret_cast<const float4*>(part + (wave * 3 + v) * kMaxBlocks + lane * 4);
+  }
+  // Pin the read-only scalars here: without this hipcc sinks their s_loads below the
+  // `done` branch and they become a third dependent round trip.
+  asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.recA), "s"(G.recB),
+               "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations), "s"(prm.eps_trans),
+               "s"(prm.eps_rot), "s"(prm.step_max_trans), "s"(prm.step_max_rot), "s"(ps_pose0), "s"(ps_pose1),
+               "s"(ps_pose2), "s"(ps_iter), "s"(ps_done), "s"(ps_have), "s"(fixed_iterations));
+  const int stride = kMaxBlocks * kBlock;
+  int i = blockIdx.x * kBlock + tid;
+  float x = 0.f, y = 0.f, x1 = 0.f, y1 = 0.f;
+  if (i < n) { x = sx[i]; y = sy[i]; }
+  if (i + stride < n) { x1 = sx[i + stride]; y1 = sy[i + stride]; }
+
+  if (ps_done) {                         // uniform: a finished alignment just carries its state
+    if (writer) copy_state(cur, prev, -1);
     return;
   }
-  const int n = ctx->n;
-  const float* __restrict__ sx = ctx->sx;
-  const float* __restrict__ sy = ctx->sy;
-  const int stride = gridDim.x * kBlock;
-  int i = blockIdx.x * kBlock + tid;
-  // issue the first point load before the prologue so its latency hides under the solve
-  float x = 0.f, y = 0.f;
-  if (i < n) { x = sx[i]; y = sy[i]; }
-
-  double pose[3] = {prev->pose[0], prev->pose[1], prev->pose[2]};
-  int iter = prev->iter;
-  if (prev->have_partials) {
-    // ---- prologue: reduce previous partials in a fixed order (wave w owns sums 3w..3w+2)
-    const float* part = &ctx->partials[parity ^ 1][0][0];
-    const int P = gridDim.x;
+  double pose[3] = {ps_pose0, ps_pose1, ps_pose2};
+  int iter = ps_iter;
+  if (ps_have) {
+    double H[6], g[3], score = 0.0;
+    int n_hit = 0, status = 0;
+    bool done = false;
+    if (!(EXP & 1)) {
+      // ---- prologue: fixed-order reduction (wave w owns sums 3w..3w+2), then the solve
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      const int j = wave * 3 + v;
-      double a = 0.0;
-      for (int b = lane; b < P; b += 64) a += (double)part[j * kMaxBlocks + b];
-      a = wave_sum_lane63(a);
-      if (lane == 63) s_red[j] = a;
+      for (int v = 0; v < 3; ++v) {
+        double a = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
+        a = wave_sum_lane63(a);
+        if (lane == 63) s_red[wave * 3 + v] = a;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 6; ++j) H[j] = s_red[j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) g[j] = s_red[6 + j];
+      score = s_red[9];
+      n_hit = (int)(s_red[10] + 0.5);
+      done = gn_update(pose, H, g, n_hit, iter, status, prm, fixed_iterations);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) H[j] = 0.0;
+      g[0] = g[1] = g[2] = 0.0;
+      iter += 1;
+      done = iter >= fixed_iterations;
     }
-    __syncthreads();
-    double H[6], g[3];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) H[j] = s_red[j];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) g[j] = s_red[6 + j];
-    const double score = s_red[9];
-    const int n_hit = (int)(s_red[10] + 0.5);
-    int status = 0;
-    const bool done = gn_update(pose, H, g, n_hit, iter, status, ctx->prm);
     if (writer) {
-      cur->pose[0] = pose[0]; cur->pose[1] = pose[1]; cur->pose[2] = pose[2];
+      IterState o;
+      o.pose[0] = pose[0]; o.pose[1] = pose[1]; o.pose[2] = pose[2];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) cur->H[j] = H[j];
+      for (int j = 0; j < 6; ++j) o.H[j] = H[j];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) cur->g[j] = g[j];
-      cur->score = score;
-      cur->n_hit = n_hit;
-      cur->iter = iter;
-      cur->status = status;
-      cur->done = done ? 1 : 0;
-      cur->have_partials = 1;
+      for (int j = 0; j < 3; ++j) o.g[j] = g[j];
+      o.score = score;
+      o.n_hit = n_hit;
+      o.iter = iter;
+      o.status = status;
+      o.done = done ? 1 : 0;
+      o.have_partials = 1;
+      o.pad = 0;
+      *cur = o;
     }
     if (done) return;                    // uniform
   } else if (writer) {
-    *cur = *prev;
-    cur->have_partials = 1;
+    copy_state(cur, prev, 1);
   }
 
   // ---- body: per-point terms at `pose`
@@ -377,78 +500,50 @@ __global__ __launch_bounds__(kBlock) void k_iterate(AlignCtx* __restrict__ ctx, 
   sincos_wrapped(pose[2], &sn_d, &cs_d);
   const float cs = (float)cs_d, sn = (float)sn_d;
   const float tx = (float)pose[0], ty = (float)pose[1];
-  const GridDev& G = ctx->grid;
   const float ox = G.ox, oy = G.oy, inv_c = G.inv_c;
   const int W = G.W, Hh = G.H;
   const float fW = (float)W, fH = (float)Hh;
   const float4* __restrict__ recA = G.recA;
   const float2* __restrict__ recB = G.recB;
-  const float d1 = ctx->prm.d1, d2 = ctx->prm.d2;
+  const float d1 = prm.d1, d2 = prm.d2;
   const float nhd2 = -0.5f * d2 * 1.44269504088896340736f;   // exp(-d2/2 m) = exp2(nhd2*m)
 
   float acc[kNumAcc];
 #pragma unroll
   for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.f;
+  const PoseF P = {cs, sn, tx, ty, ox, oy, inv_c, fW, fH, W, d1, d2, nhd2};
 
-  while (i < n) {
-    const int inext = i + stride;
-    float xn = 0.f, yn = 0.f;
-    if (inext < n) { xn = sx[inext]; yn = sy[inext]; }
-    float px = fmaf(cs, x, fmaf(-sn, y, tx));
-    float py = fmaf(sn, x, fmaf(cs, y, ty));
-    const float fx = (px - ox) * inv_c;
-    const float fy = (py - oy) * inv_c;
-    const bool in = (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH);   // false for NaN/inf
-    const int key = in ? ((int)fy * W + (int)fx) : 0;
-    if (!in) { px = 0.f; py = 0.f; x = 0.f; y = 0.f; }   // keep 0*NaN out of the sums
-    const float4 A = recA[key];
-    const float2 B = recB[key];
-    const bool hit = in & (B.y > 0.f);
-    const float qx = px - A.x, qy = py - A.y;
-    const float a = A.z, b = A.w, c = B.x;
-    const float vx = fmaf(a, qx, b * qy);
-    const float vy = fmaf(b, qx, c * qy);
-    const float m = fmaf(qx, vx, qy * vy);
-    const float s = hit ? d1 * __builtin_amdgcn_exp2f(nhd2 * m) : 0.f;
-    const float w = s * d2;
-    const float jx = fmaf(-sn, x, -cs * y);
-    const float jy = fmaf(cs, x, -sn * y);
-    const float vt = fmaf(vx, jx, vy * jy);
-    const float ux = fmaf(a, jx, b * jy);
-    const float uy = fmaf(b, jx, c * jy);
-    float hxx = a, hxy = b, hyy = c, hxt = ux, hyt = uy, htt = fmaf(jx, ux, jy * uy);
-    if (MODE == 1) {   // full Newton Hessian (Biber / Magnusson)
-      hxx = fmaf(-d2 * vx, vx, hxx);
-      hxy = fmaf(-d2 * vx, vy, hxy);
-      hyy = fmaf(-d2 * vy, vy, hyy);
-      hxt = fmaf(-d2 * vx, vt, hxt);
-      hyt = fmaf(-d2 * vy, vt, hyt);
-      htt = fmaf(-d2 * vt, vt, htt) + fmaf(vy, jx, -vx * jy);
-    }
-    acc[0] = fmaf(w, hxx, acc[0]);
-    acc[1] = fmaf(w, hxy, acc[1]);
-    acc[2] = fmaf(w, hyy, acc[2]);
-    acc[3] = fmaf(w, hxt, acc[3]);
-    acc[4] = fmaf(w, hyt, acc[4]);
-    acc[5] = fmaf(w, htt, acc[5]);
-    acc[6] = fmaf(w, vx, acc[6]);
-    acc[7] = fmaf(w, vy, acc[7]);
-    acc[8] = fmaf(w, vt, acc[8]);
-    acc[9] += s;
-    acc[10] += hit ? 1.f : 0.f;
-    x = xn; y = yn; i = inext;
+  // two points in flight per thread: both gathers are issued before either is consumed
+  while (!(EXP & 2) && i < n) {
+    const int i2 = i + 2 * stride;
+    float xn0 = 0.f, yn0 = 0.f, xn1 = 0.f, yn1 = 0.f;
+    if (i2 < n) { xn0 = sx[i2]; yn0 = sy[i2]; }
+    if (i2 + stride < n) { xn1 = sx[i2 + stride]; yn1 = sy[i2 + stride]; }
+    PointRec r0, r1;
+    const bool two = (i + stride) < n;
+    lookup_point(P, recA, recB, x, y, true, r0);
+    lookup_point(P, recA, recB, x1, y1, two, r1);
+    accumulate_point<MODE>(P, r0, acc);
+    accumulate_point<MODE>(P, r1, acc);
+    x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
   }
 
   // ---- epilogue: wave tree -> LDS -> one partial row per block
+  if (EXP & 4) {
+    if (tid < kNumAcc) dyn->partials[parity][tid][blockIdx.x] = acc[tid & 1];
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < kNumAcc - 1; ++j) {
     const float r = wave_sum_lane63(acc[j]);
     if (lane == 63) s_wave[wave][j] = r;
   }
   __syncthreads();
-  if (tid < kNumAcc - 1) {
-    const float r = ((s_wave[0][tid] + s_wave[1][tid]) + s_wave[2][tid]) + s_wave[3][tid];
-    ctx->partials[parity][tid][blockIdx.x] = r;
+  if (tid < kNumAcc) {
+    const float r = tid < kNumAcc - 1
+                        ? ((s_wave[0][tid] + s_wave[1][tid]) + s_wave[2][tid]) + s_wave[3][tid]
+                        : 0.f;
+    dyn->partials[parity][tid][blockIdx.x] = r;
   }
 }
 
