@@ -1,0 +1,76 @@
+"""Committed golden vectors (tests/golden/ndt2d_config1.npz, made by tests/golden/make_golden.py
+from this repo's oracle - the reference holds no fixtures; parity unpinned).
+
+CPU: the oracle and the generator still reproduce them (guards against silent drift).
+GPU: the HIP path matches them without importing the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ndt2d_config1.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)            # allow_pickle stays False
+
+
+def test_generator_reproduces_golden_inputs(gold):
+    from gtsam_ndt_amd import synth
+    d = synth.make_pair(1)
+    for k in ("tx", "ty", "sx", "sy"):
+        np.testing.assert_array_equal(d[k], gold[k])
+    assert tuple(gold["init"]) == d["init"] and tuple(gold["true_pose"]) == d["pose"]
+
+
+def test_oracle_reproduces_golden_outputs(gold):
+    from oracle import ndt2d as o
+    prm = o.NdtParams()
+    g = o.build_grid(gold["tx"], gold["ty"], prm)
+    assert [float(g.ox), float(g.oy), float(g.inv_c), g.W, g.H, g.n_valid] == list(gold["grid_geom"])
+    np.testing.assert_array_equal(g.count, gold["grid_count"])
+    np.testing.assert_array_equal(g.valid, gold["grid_valid"])
+    np.testing.assert_allclose(g.mean, gold["grid_mean"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(g.icov, gold["grid_icov"], rtol=1e-12)
+    trace = []
+    r = o.align(g, gold["sx"], gold["sy"], tuple(gold["init"]), prm, trace=trace)
+    assert r["iterations"] == int(gold["final_iterations"]) and r["status"] == int(gold["final_status"])
+    np.testing.assert_allclose(r["pose"], gold["final_pose"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.array([t["pose"] for t in trace]), gold["trace_pose"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(np.array([t["H"] for t in trace]), gold["trace_H"], rtol=1e-9)
+    np.testing.assert_array_equal(np.array([t["n_hit"] for t in trace]), gold["trace_n_hit"])
+    for p, H, Hn in zip(gold["eval_pose"], gold["eval_H"], gold["eval_H_newton"]):
+        np.testing.assert_allclose(o.evaluate(g, gold["sx"], gold["sy"], p, prm)[0], H, rtol=1e-11)
+        np.testing.assert_allclose(
+            o.evaluate(g, gold["sx"], gold["sy"], p, o.NdtParams(hessian_mode=1))[0], Hn, rtol=1e-9,
+            atol=1e-9 * np.abs(Hn).max())
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_golden(gold, gpu_lib):
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    with NdtMatcher2D() as m:
+        info = m.set_target(gold["tx"], gold["ty"])
+        assert [info.ox, info.oy, info.inv_cell, info.width, info.height, info.n_valid] == list(gold["grid_geom"])
+        count, mean, icov = m.grid()
+        np.testing.assert_array_equal(count, gold["grid_count"])          # bit-exact integer work
+        v = gold["grid_valid"]
+        np.testing.assert_array_equal(icov[:, 0] != 0, v)
+        np.testing.assert_allclose(mean[v], gold["grid_mean"][v], rtol=0, atol=2e-6)
+        nrm = np.linalg.norm(gold["grid_icov"][v], axis=1, keepdims=True)
+        assert np.max(np.abs(icov[v] - gold["grid_icov"][v]) / nrm) < 1e-5
+        for p, H, g, s, nh in zip(gold["eval_pose"], gold["eval_H"], gold["eval_g"], gold["eval_score"],
+                                  gold["eval_n_hit"]):
+            Hd, gd, sd, nd = m.evaluate(gold["sx"], gold["sy"], p)
+            assert abs(nd - nh) <= 2
+            assert np.abs(Hd - H).max() / np.abs(H).max() < 5e-3       # a boundary point may change cell
+            assert abs(sd - s) / s < 5e-3
+        r = m.align(gold["sx"], gold["sy"], tuple(gold["init"]))
+        assert r.status == int(gold["final_status"])
+        e = np.abs(np.array(r.pose) - gold["final_pose"])
+        assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 1e-4          # BASELINE.json: 1e-4 m / 1e-4 rad
+    with NdtMatcher2D(fixed_iterations=5) as m:
+        m.set_target(gold["tx"], gold["ty"])
+        r = m.align(gold["sx"], gold["sy"], tuple(gold["init"]))
+        assert r.iterations == 5 and np.abs(np.array(r.pose) - gold["fixed5_pose"]).max() < 1e-4
