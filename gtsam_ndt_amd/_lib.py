@@ -102,6 +102,11 @@ SIGNATURES = {
     "ndt2d_align_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp]),
     "ndt2d_align_finish": (C.c_int32, [_vp, C.POINTER(Result2D)]),
     "ndt2d_stream": (_vp, [_vp]),
+    "ndt2d_batch_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),
+    "ndt2d_batch_destroy": (C.c_int32, [_vp]),
+    "ndt2d_batch_align": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ndt2d_batch_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "ndt2d_batch_stream": (_vp, [_vp]),
 }
 
 _lib = None

@@ -1,0 +1,393 @@
+// Loop-closure candidate batch (BASELINE config 4): one persistent 1024-thread workgroup per
+// CU pulls scan pairs from a queue and runs the WHOLE alignment of a pair on chip:
+//   - the target's NDT grid is built and kept in LDS (dense cell -> slot index table plus
+//     compact per-slot records), so the per-point cell lookup of every Gauss-Newton
+//     iteration is an LDS read ("LDS-staged cell stats", BASELINE.json north_star);
+//   - source points are streamed from HBM/L2 with coalesced SoA loads, once per iteration;
+//   - the 11 sums are reduced wave (DPP) -> LDS -> one wave, which also does the 3x3 solve,
+//     so an iteration costs three workgroup barriers and no kernel boundary, no grid
+//     barrier, no atomics on floats.
+// Same arithmetic as the single-pair path (shared device functions of ndt2d_kernels.hpp):
+// the LDS grid holds bit-identical records to k_accumulate/k_finalise.
+#pragma once
+#include "ndt2d_kernels.hpp"
+
+namespace ndt {
+
+constexpr int kBatchThreads = 1024;
+constexpr int kBatchWaves = kBatchThreads / 64;
+constexpr int kBatchMaxCells = 16384;   // dense index table: e.g. 128 x 128 cells
+constexpr int kBatchMaxSlots = 2304;    // cells with n >= min_points (<= 3 per thread at finalise)
+constexpr int kBatchUnroll = 4;         // source points in flight per thread
+
+struct ResultDev {   // layout of ndt2d_result (include/ndt_hip.h); static_assert in the API file
+  double pose[3];
+  double H[9];
+  double g[3];
+  double score;
+  int iterations, n_hit, status, reserved;
+};
+
+struct BatchArgs {
+  const float* tx; const float* ty; const unsigned long long* toff;   // targets, concatenated SoA
+  const float* sx; const float* sy; const unsigned long long* soff;   // sources
+  const double* init;        // [n_pairs][3]
+  ResultDev* out;            // [n_pairs]
+  unsigned int* queue;       // zeroed before the launch
+  int n_pairs;
+  int min_points;
+  int fixed_iterations;
+  int pad;
+  double cell;
+  double eig_ratio;
+  SolveParams prm;
+};
+
+// LDS carve (bytes); everything in one dynamic array, every offset a multiple of 16
+constexpr int kLdsIdx = 0;                                            // u16 [MaxCells]
+constexpr int kLdsSlotN = kLdsIdx + kBatchMaxCells * 2;               // u32 [MaxSlots]
+constexpr int kLdsSlotKey = kLdsSlotN + kBatchMaxSlots * 4;           // u16 [MaxSlots]
+constexpr int kLdsSums = kLdsSlotKey + kBatchMaxSlots * 2;            // u64 [5][MaxSlots]; aliases:
+                                                                      //   u32 cnt[MaxCells] (build)
+                                                                      //   float4 recA[MaxSlots], float2 recB[MaxSlots]
+constexpr int kLdsRed = kLdsSums + 5 * kBatchMaxSlots * 8;            // float [Waves][kNumAcc]
+constexpr int kLdsBc = kLdsRed + kBatchWaves * kNumAcc * 4;           // double [16] broadcast
+constexpr int kLdsMisc = kLdsBc + 16 * 8;                             // int [16]
+constexpr int kLdsScan = kLdsMisc + 16 * 4;                           // int [Waves]
+constexpr int kBatchLdsBytes = kLdsScan + kBatchWaves * 4;
+static_assert(kBatchMaxCells * 4 <= 5 * kBatchMaxSlots * 8, "cnt must fit in the sums region");
+static_assert(kBatchMaxSlots * 24 <= 5 * kBatchMaxSlots * 8, "records must fit in the sums region");
+static_assert(kBatchMaxSlots <= 3 * kBatchThreads, "finalise keeps at most 3 slots per thread in registers");
+static_assert(kBatchLdsBytes <= 160 * 1024, "CDNA4 LDS is 160 KiB per CU");
+static_assert((kLdsSlotN % 16) == 0 && (kLdsSlotKey % 16) == 0 && (kLdsSums % 16) == 0 && (kLdsRed % 16) == 0 &&
+              (kLdsBc % 16) == 0 && (kLdsMisc % 16) == 0, "16-byte aligned carve");
+
+// exclusive scan of one int per thread over the 1024-thread workgroup; *total = sum
+__device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_scan[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBatchWaves; ++w) {
+    const int t = s_scan[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__device__ __forceinline__ void write_result(ResultDev* o, const double* pose, const double* H6, const double* g,
+                                             double score, int iter, int n_hit, int status) {
+  o->pose[0] = pose[0]; o->pose[1] = pose[1]; o->pose[2] = pose[2];
+  o->H[0] = H6[0]; o->H[1] = H6[1]; o->H[2] = H6[3];
+  o->H[3] = H6[1]; o->H[4] = H6[2]; o->H[5] = H6[4];
+  o->H[6] = H6[3]; o->H[7] = H6[4]; o->H[8] = H6[5];
+  o->g[0] = g[0]; o->g[1] = g[1]; o->g[2] = g[2];
+  o->score = score;
+  o->iterations = iter; o->n_hit = n_hit; o->status = status; o->reserved = 0;
+}
+
+// a4 with the record served from LDS: dense index table -> slot -> (recA, recB)
+__device__ __forceinline__ void lookup_point_lds(const PoseF& P, const unsigned short* __restrict__ idx,
+                                                 const float4* __restrict__ recA,
+                                                 const float2* __restrict__ recB, float x, float y, bool live,
+                                                 PointRec& r) {
+  float px = fmaf(P.cs, x, fmaf(-P.sn, y, P.tx));
+  float py = fmaf(P.sn, x, fmaf(P.cs, y, P.ty));
+  const float fx = (px - P.ox) * P.inv_c;
+  const float fy = (py - P.oy) * P.inv_c;
+  const bool in = live & (fx >= 0.f) & (fx < P.fW) & (fy >= 0.f) & (fy < P.fH);
+  const int key = in ? ((int)fy * P.W + (int)fx) : 0;
+  const int slot = idx[key];                       // unconditional read: no exec-mask branch
+  const bool hit = in & (slot > 0);
+  if (!in) { px = 0.f; py = 0.f; x = 0.f; y = 0.f; }
+  r.x = x; r.y = y; r.px = px; r.py = py; r.in = hit;
+  const int s = hit ? slot - 1 : 0;
+  r.A = recA[s];
+  r.B = recB[s];
+}
+
+constexpr int kStatusCapacity = -5;   // NDT_ERR_CAPACITY: pair needs the global-memory path
+
+// One pair, start to finish, on the calling workgroup.  Early outs are plain returns: the
+// caller's queue loop then has a single back edge (with `continue`s inside the loop body
+// hipcc's loop restructuring produced a kernel that re-read the same queue slot forever).
+template <int MODE>
+__device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair, unsigned char* smem) {
+  unsigned short* idx = reinterpret_cast<unsigned short*>(smem + kLdsIdx);
+  unsigned int* slot_n = reinterpret_cast<unsigned int*>(smem + kLdsSlotN);
+  unsigned short* slot_key = reinterpret_cast<unsigned short*>(smem + kLdsSlotKey);
+  unsigned long long* sums = reinterpret_cast<unsigned long long*>(smem + kLdsSums);
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + kLdsSums);
+  float4* recA = reinterpret_cast<float4*>(smem + kLdsSums);
+  float2* recB = reinterpret_cast<float2*>(smem + kLdsSums + kBatchMaxSlots * 16);
+  float* red = reinterpret_cast<float*>(smem + kLdsRed);
+  double* bc = reinterpret_cast<double*>(smem + kLdsBc);
+  int* misc = reinterpret_cast<int*>(smem + kLdsMisc);
+  int* s_scan = reinterpret_cast<int*>(smem + kLdsScan);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int minpts = a.min_points < 2 ? 2 : a.min_points;
+  const double zero6[6] = {0, 0, 0, 0, 0, 0};
+  {
+    const unsigned long long t0 = a.toff[pair], s0 = a.soff[pair];
+    const int nt = (int)(a.toff[pair + 1] - t0), ns = (int)(a.soff[pair + 1] - s0);
+    const float* __restrict__ tx = a.tx + t0;
+    const float* __restrict__ ty = a.ty + t0;
+    const float* __restrict__ sx = a.sx + s0;
+    const float* __restrict__ sy = a.sy + s0;
+    double pose[3] = {a.init[3 * pair], a.init[3 * pair + 1], wrap_angle(a.init[3 * pair + 2])};
+    ResultDev* out = a.out + pair;
+
+    // ---- a1: bounding box of the target and grid geometry (oracle/ndt2d.py grid_geometry)
+    {
+      float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+      for (int i = tid; i < nt; i += kBatchThreads) {
+        const float u = tx[i], v = ty[i];
+        if (isfinite(u) && isfinite(v)) {
+          xmin = fminf(xmin, u); xmax = fmaxf(xmax, u);
+          ymin = fminf(ymin, v); ymax = fmaxf(ymax, v);
+        }
+      }
+      xmin = wave_min(xmin); xmax = wave_max(xmax);
+      ymin = wave_min(ymin); ymax = wave_max(ymax);
+      if (lane == 0) { red[wave * 4 + 0] = xmin; red[wave * 4 + 1] = xmax; red[wave * 4 + 2] = ymin; red[wave * 4 + 3] = ymax; }
+      __syncthreads();
+      if (tid == 0) {
+        for (int w = 1; w < kBatchWaves; ++w) {
+          xmin = fminf(xmin, red[w * 4 + 0]); xmax = fmaxf(xmax, red[w * 4 + 1]);
+          ymin = fminf(ymin, red[w * 4 + 2]); ymax = fmaxf(ymax, red[w * 4 + 3]);
+        }
+        int st = 0, W = 0, H = 0;
+        float ox = 0.f, oy = 0.f;
+        const float inv_c = (float)(1.0 / a.cell);
+        if (!(xmin <= xmax) || !(ymin <= ymax)) {
+          st = 4;                                   // no finite target point -> no valid cell
+        } else {
+          ox = (float)((floor((double)xmin / a.cell) - 1.0) * a.cell);
+          oy = (float)((floor((double)ymin / a.cell) - 1.0) * a.cell);
+          const float kx = floorf((xmax - ox) * inv_c), ky = floorf((ymax - oy) * inv_c);
+          if (!(kx >= 0.f) || !(ky >= 0.f) || (double)(kx + 2.f) * (double)(ky + 2.f) > (double)kBatchMaxCells) {
+            st = kStatusCapacity;
+          } else {
+            W = (int)kx + 2; H = (int)ky + 2;
+          }
+        }
+        misc[1] = W; misc[2] = H; misc[3] = st;
+        reinterpret_cast<float*>(misc)[4] = ox;
+        reinterpret_cast<float*>(misc)[5] = oy;
+      }
+      __syncthreads();
+    }
+    const int W = __builtin_amdgcn_readfirstlane(misc[1]), Hh = __builtin_amdgcn_readfirstlane(misc[2]);
+    int status = __builtin_amdgcn_readfirstlane(misc[3]);
+    const float ox = reinterpret_cast<float*>(misc)[4], oy = reinterpret_cast<float*>(misc)[5];
+    const float inv_c = (float)(1.0 / a.cell);
+    const float fW = (float)W, fH = (float)Hh;
+    const int ncell = W * Hh;
+    const double fix_scale = 4194304.0 / a.cell;     // 2^kFixShift / c
+    static_assert(kFixShift == 22, "fix_scale literal");
+    __syncthreads();                                 // misc is rewritten below
+    if (status != 0) {                               // uniform
+      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, 0, 0, status);
+      return;
+    }
+
+    // ---- a2 (1/2): per-cell counts
+    for (int k = tid; k < ncell; k += kBatchThreads) cnt[k] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nt; i += kBatchThreads) {
+      const float fx = (tx[i] - ox) * inv_c, fy = (ty[i] - oy) * inv_c;
+      if ((fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH)) atomicAdd(&cnt[(int)fy * W + (int)fx], 1u);
+    }
+    __syncthreads();
+
+    // ---- compaction: cells with n >= min_points get a slot, in cell order (deterministic)
+    const int chunk = (ncell + kBatchThreads - 1) / kBatchThreads;
+    const int c0 = tid * chunk < ncell ? tid * chunk : ncell;
+    const int c1 = c0 + chunk < ncell ? c0 + chunk : ncell;
+    int local = 0;
+    for (int k = c0; k < c1; ++k) local += (cnt[k] >= (unsigned)minpts) ? 1 : 0;
+    int nslot = 0;
+    int s = block_excl_scan(local, s_scan, &nslot);
+    nslot = __builtin_amdgcn_readfirstlane(nslot);
+    if (nslot > kBatchMaxSlots || nslot < 1) {       // uniform
+      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, 0, 0, nslot < 1 ? 4 : kStatusCapacity);
+      return;
+    }
+    for (int k = c0; k < c1; ++k) {
+      const unsigned int n = cnt[k];
+      if (n >= (unsigned)minpts) {
+        idx[k] = (unsigned short)(s + 1);
+        slot_n[s] = n;
+        slot_key[s] = (unsigned short)k;
+        ++s;
+      } else {
+        idx[k] = 0;
+      }
+    }
+    __syncthreads();                                 // cnt is dead; its bytes become the sums
+    for (int j = tid; j < 5 * kBatchMaxSlots; j += kBatchThreads)
+      if ((j % kBatchMaxSlots) < nslot) sums[j] = 0ull;
+    __syncthreads();
+
+    // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics)
+    for (int i = tid; i < nt; i += kBatchThreads) {
+      const float px = tx[i], py = ty[i];
+      const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
+      if ((fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH)) {
+        const int ix = (int)fx, iy = (int)fy;
+        const int slot = idx[iy * W + ix];
+        if (slot) {
+          const long long ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
+          const long long uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
+          unsigned long long* q = sums + (slot - 1);
+          atomicAdd(q, (unsigned long long)ux);
+          atomicAdd(q + kBatchMaxSlots, (unsigned long long)uy);
+          atomicAdd(q + 2 * kBatchMaxSlots, (unsigned long long)(ux * ux));
+          atomicAdd(q + 3 * kBatchMaxSlots, (unsigned long long)(ux * uy));
+          atomicAdd(q + 4 * kBatchMaxSlots, (unsigned long long)(uy * uy));
+        }
+      }
+    }
+    if (tid == 0) misc[6] = 0;
+    __syncthreads();
+
+    // ---- a3: finalise (<= 3 slots per thread held in registers, then overwrite the sums)
+    {
+      float4 ra[3];
+      float2 rb[3];
+      int nvalid = 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int sl = tid + j * kBatchThreads;
+        ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[j] = make_float2(0.f, 0.f);
+        if (sl < nslot) {
+          const int key = slot_key[sl];
+          const int n = (int)slot_n[sl];
+          const bool ok = n <= (int)kMaxCellCount &&
+                          finalise_sums(n, (long long)sums[sl], (long long)sums[sl + kBatchMaxSlots],
+                                        (long long)sums[sl + 2 * kBatchMaxSlots],
+                                        (long long)sums[sl + 3 * kBatchMaxSlots],
+                                        (long long)sums[sl + 4 * kBatchMaxSlots],
+                                        cell_centre(ox, key % W, a.cell), cell_centre(oy, key / W, a.cell),
+                                        fix_scale, a.min_points, a.eig_ratio, ra[j], rb[j]);
+          nvalid += ok ? 1 : 0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int sl = tid + j * kBatchThreads;
+        if (sl < nslot) { recA[sl] = ra[j]; recB[sl] = rb[j]; }
+      }
+      if (nvalid) atomicAdd(&misc[6], nvalid);
+      __syncthreads();
+    }
+    if (__builtin_amdgcn_readfirstlane(misc[6]) < 1) {   // uniform
+      __syncthreads();
+      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, 0, 0, 4);
+      return;
+    }
+
+    // ---- a4-a8: Gauss-Newton loop, all on this CU.  Only wave 0 touches the float64 sums and
+    // the solve; what the other waves need (pose, done) and what the final result needs
+    // (H, g, score, counters) lives in LDS, not in registers that would be held across the
+    // point loop.
+    if (tid == 0) { misc[9] = 0; misc[10] = 0; }     // iter, status
+    __syncthreads();
+    for (;;) {
+      float acc[kNumAcc];
+#pragma unroll
+      for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.f;
+      {
+        double sn_d, cs_d;
+        sincos_wrapped(pose[2], &sn_d, &cs_d);
+        const float d1 = a.prm.d1, d2 = a.prm.d2;
+        const PoseF P = {(float)cs_d, (float)sn_d, (float)pose[0], (float)pose[1], ox, oy, inv_c, fW, fH, W,
+                         d1, d2, -0.5f * d2 * 1.44269504088896340736f};
+        // kBatchUnroll points in flight per thread; every load of a wave is 256 contiguous bytes
+        for (int i = tid; i < ns; i += kBatchUnroll * kBatchThreads) {
+          float x[kBatchUnroll], y[kBatchUnroll];
+          bool live[kBatchUnroll];
+#pragma unroll
+          for (int u = 0; u < kBatchUnroll; ++u) {
+            const int ii = i + u * kBatchThreads;
+            live[u] = ii < ns;
+            const int ic = live[u] ? ii : ns - 1;     // clamped, always a valid address: no branch
+            x[u] = sx[ic];
+            y[u] = sy[ic];
+          }
+          PointRec r[kBatchUnroll];
+#pragma unroll
+          for (int u = 0; u < kBatchUnroll; ++u) lookup_point_lds(P, idx, recA, recB, x[u], y[u], live[u], r[u]);
+#pragma unroll
+          for (int u = 0; u < kBatchUnroll; ++u) accumulate_point<MODE>(P, r[u], acc);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kNumAcc - 1; ++j) {
+        const float rsum = wave_sum_lane63(acc[j]);
+        if (lane == 63) red[wave * kNumAcc + j] = rsum;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        // lane j < 11 sums column j over the 16 waves in a fixed order, in float64
+        double tot = 0.0;
+        if (lane < kNumAcc - 1) {
+#pragma unroll
+          for (int w = 0; w < kBatchWaves; ++w) tot += (double)red[w * kNumAcc + lane];
+        }
+        double H[6], g[3];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) H[j] = __shfl(tot, j, 64);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g[j] = __shfl(tot, 6 + j, 64);
+        const int n_hit = (int)(__shfl(tot, 10, 64) + 0.5);
+        int iter = misc[9], st = 0;
+        const bool done = gn_update(pose, H, g, n_hit, iter, st, a.prm, a.fixed_iterations);
+        if (lane < kNumAcc - 1) bc[3 + lane] = tot;          // H(6) g(3) score n_hit of this evaluation
+        if (lane == 0) {
+          bc[0] = pose[0]; bc[1] = pose[1]; bc[2] = pose[2];
+          misc[8] = done ? 1 : 0;
+          misc[9] = iter;
+          misc[10] = st;
+        }
+      }
+      __syncthreads();
+      pose[0] = bc[0]; pose[1] = bc[1]; pose[2] = bc[2];
+      const int done = __builtin_amdgcn_readfirstlane(misc[8]);
+      if (done) break;
+      __syncthreads();
+    }
+    if (tid == 0)
+      write_result(out, pose, &bc[3], &bc[9], bc[12], misc[9], (int)(bc[13] + 0.5), misc[10]);
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBatchThreads) void k_batch(BatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* misc = reinterpret_cast<int*>(smem + kLdsMisc);
+  for (;;) {
+    // dequeue one pair (every wave reaches this; the loop ends for all of them together)
+    if (threadIdx.x == 0) misc[0] = (int)atomicAdd(a.queue, 1u);
+    __syncthreads();
+    const int pair = __builtin_amdgcn_readfirstlane(misc[0]);   // wave-uniform by construction
+    __syncthreads();
+    if (pair >= a.n_pairs) break;
+    process_pair<MODE>(a, pair, smem);
+    __syncthreads();                                 // LDS is rewritten by the next pair
+  }
+}
+
+}  // namespace ndt

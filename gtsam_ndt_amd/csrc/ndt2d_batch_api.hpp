@@ -1,0 +1,173 @@
+// C-ABI of the loop-closure batch (included at the end of ndt2d_api.hip: one translation unit,
+// so the kernels of ndt2d_kernels.hpp are defined once).
+#pragma once
+#include "ndt2d_batch.hpp"
+
+struct ndt2d_batch {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  ndt2d_params prm{};
+  int n_cu = 0;
+  unsigned int* d_queue = nullptr;
+  // staging for the host-pointer entry point
+  float *d_tx = nullptr, *d_ty = nullptr, *d_sx = nullptr, *d_sy = nullptr;
+  size_t tcap = 0, scap = 0;
+  unsigned long long *d_toff = nullptr, *d_soff = nullptr;
+  double* d_init = nullptr;
+  ndt2d_result* d_out = nullptr;
+  size_t pcap = 0;
+  ndt2d_handle* fallback = nullptr;   // global-memory path for pairs over the LDS capacity
+};
+
+static_assert(sizeof(ndt::ResultDev) == sizeof(ndt2d_result), "ResultDev mirrors ndt2d_result");
+static_assert(offsetof(ndt::ResultDev, score) == offsetof(ndt2d_result, score), "ResultDev layout");
+static_assert(offsetof(ndt::ResultDev, status) == offsetof(ndt2d_result, status), "ResultDev layout");
+
+namespace {
+
+int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const unsigned long long* d_toff,
+                     const float* d_sx, const float* d_sy, const unsigned long long* d_soff,
+                     const double* d_init, size_t n_pairs, ndt2d_result* d_out, hipStream_t st) {
+  ndt::BatchArgs a{};
+  a.tx = d_tx; a.ty = d_ty; a.toff = d_toff;
+  a.sx = d_sx; a.sy = d_sy; a.soff = d_soff;
+  a.init = d_init;
+  a.out = reinterpret_cast<ndt::ResultDev*>(d_out);
+  a.queue = b->d_queue;
+  a.n_pairs = (int)n_pairs;
+  a.min_points = b->prm.min_points;
+  a.fixed_iterations = b->prm.fixed_iterations;
+  a.cell = b->prm.cell_size;
+  a.eig_ratio = b->prm.eig_ratio;
+  a.prm.d1 = (float)b->prm.d1; a.prm.d2 = (float)b->prm.d2;
+  a.prm.hessian_mode = b->prm.hessian_mode;
+  a.prm.max_iterations = b->prm.max_iterations;
+  a.prm.min_hits = b->prm.min_hits;
+  a.prm.eps_trans = b->prm.eps_trans; a.prm.eps_rot = b->prm.eps_rot;
+  a.prm.step_max_trans = b->prm.step_max_trans; a.prm.step_max_rot = b->prm.step_max_rot;
+  HIP_TRY(hipMemsetAsync(b->d_queue, 0, 16, st));
+  const int blocks = (int)(n_pairs < (size_t)b->n_cu ? n_pairs : (size_t)b->n_cu);
+  if (b->prm.hessian_mode == NDT_HESSIAN_NEWTON)
+    hipLaunchKernelGGL(ndt::k_batch<1>, dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
+  else
+    hipLaunchKernelGGL(ndt::k_batch<0>, dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
+  HIP_TRY(hipGetLastError());
+  return NDT_OK;
+}
+
+template <typename T>
+int32_t ensure_dev(T** p, size_t* cap, size_t n) {
+  if (n <= *cap) return NDT_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  HIP_TRY(hipMalloc((void**)p, (n + n / 4 + 64) * sizeof(T)));
+  *cap = n + n / 4 + 64;
+  return NDT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ndt2d_batch_create(const ndt2d_params* p, int32_t device_id, ndt2d_batch** out) {
+  if (!out) return NDT_ERR_INVALID_ARG;
+  *out = nullptr;
+  const int32_t st = check_params(p);
+  if (st != NDT_OK) return st;
+  const int ndev = ndt_device_count();
+  if (ndev <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }
+  if (device_id < 0 || device_id >= ndev) return NDT_ERR_INVALID_ARG;
+  ndt2d_batch* b = new (std::nothrow) ndt2d_batch();
+  if (!b) return NDT_ERR_ALLOC;
+  b->device = device_id;
+  b->prm = *p;
+  auto fail = [&](int32_t code) { ndt2d_batch_destroy(b); return code; };
+  if (hipSetDevice(device_id) != hipSuccess) return fail(NDT_ERR_HIP);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(NDT_ERR_HIP);
+  b->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipMalloc((void**)&b->d_queue, 16) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::kBatchLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::kBatchLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  *out = b;
+  return NDT_OK;
+}
+
+int32_t ndt2d_batch_destroy(ndt2d_batch* b) {
+  if (!b) return NDT_OK;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  void* dev[] = {b->d_queue, b->d_tx, b->d_ty, b->d_sx, b->d_sy, b->d_toff, b->d_soff, b->d_init, b->d_out};
+  for (void* p : dev) if (p) (void)hipFree(p);
+  if (b->fallback) ndt2d_destroy(b->fallback);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return NDT_OK;
+}
+
+void* ndt2d_batch_stream(ndt2d_batch* b) { return b ? (void*)b->stream : nullptr; }
+
+int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_ty, const uint64_t* d_toff,
+                              const float* d_sx, const float* d_sy, const uint64_t* d_soff,
+                              const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream) {
+  if (!b || !d_tx || !d_ty || !d_toff || !d_sx || !d_sy || !d_soff || !d_init || !d_results) return NDT_ERR_INVALID_ARG;
+  if (n_pairs == 0 || n_pairs > 0x7fffffffull) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  return batch_launch(b, d_tx, d_ty, reinterpret_cast<const unsigned long long*>(d_toff), d_sx, d_sy,
+                      reinterpret_cast<const unsigned long long*>(d_soff), d_init, n_pairs, d_results,
+                      stream ? (hipStream_t)stream : b->stream);
+}
+
+int32_t ndt2d_batch_align(ndt2d_batch* b, const float* tx, const float* ty, const uint64_t* toff,
+                          const float* sx, const float* sy, const uint64_t* soff, const double* init,
+                          size_t n_pairs, ndt2d_result* results) {
+  if (!b || !tx || !ty || !toff || !sx || !sy || !soff || !init || !results || n_pairs == 0) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t nt = toff[n_pairs], ns = soff[n_pairs];
+  for (size_t k = 0; k < n_pairs; ++k) {
+    if (toff[k + 1] < toff[k] || soff[k + 1] < soff[k] || toff[k + 1] - toff[k] > 0x7fffffffull ||
+        soff[k + 1] - soff[k] > 0x7fffffffull) return NDT_ERR_INVALID_ARG;
+  }
+  int32_t st;
+  size_t c2 = b->tcap;
+  if ((st = ensure_dev(&b->d_tx, &b->tcap, nt)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_ty, &c2, nt)) != NDT_OK) return st;
+  c2 = b->scap;
+  if ((st = ensure_dev(&b->d_sx, &b->scap, ns)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_sy, &c2, ns)) != NDT_OK) return st;
+  size_t c3 = b->pcap, c4 = b->pcap, c5 = b->pcap;
+  if ((st = ensure_dev(&b->d_toff, &b->pcap, n_pairs + 1)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_soff, &c3, n_pairs + 1)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_init, &c4, 3 * (n_pairs + 1))) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_out, &c5, n_pairs + 1)) != NDT_OK) return st;
+  hipStream_t s = b->stream;
+  HIP_TRY(hipMemcpyAsync(b->d_tx, tx, nt * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(b->d_ty, ty, nt * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(b->d_sx, sx, ns * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(b->d_sy, sy, ns * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(b->d_toff, toff, (n_pairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(b->d_soff, soff, (n_pairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(b->d_init, init, 3 * n_pairs * sizeof(double), hipMemcpyHostToDevice, s));
+  st = batch_launch(b, b->d_tx, b->d_ty, b->d_toff, b->d_sx, b->d_sy, b->d_soff, b->d_init, n_pairs, b->d_out, s);
+  if (st != NDT_OK) return st;
+  HIP_TRY(hipMemcpyAsync(results, b->d_out, n_pairs * sizeof(ndt2d_result), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  // pairs whose grid does not fit the on-chip capacity go through the global-memory path
+  for (size_t k = 0; k < n_pairs; ++k) {
+    if (results[k].status != NDT_ERR_CAPACITY) continue;
+    if (!b->fallback) {
+      st = ndt2d_create(&b->prm, b->device, &b->fallback);
+      if (st != NDT_OK) return st;
+    }
+    st = ndt2d_set_target(b->fallback, tx + toff[k], ty + toff[k], toff[k + 1] - toff[k]);
+    if (st == NDT_OK) st = ndt2d_align(b->fallback, sx + soff[k], sy + soff[k], soff[k + 1] - soff[k], init + 3 * k, &results[k]);
+    if (st < 0) return st;
+  }
+  return NDT_OK;
+}
+
+}  // extern "C"

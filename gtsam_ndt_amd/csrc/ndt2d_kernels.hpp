@@ -113,6 +113,53 @@ __global__ __launch_bounds__(kBlock) void k_bounds(const float* __restrict__ x,
   }
 }
 
+// ---------------------------------------------------------------- shared cell arithmetic
+// Used verbatim by the global-memory path (k_accumulate/k_finalise) and by the LDS-resident
+// batch kernel, so both build bit-identical cell records from the same points.
+__device__ __forceinline__ double cell_centre(float o, int i, double cell) {
+  return fma((double)i + 0.5, cell, (double)o);
+}
+__device__ __forceinline__ long long fix_coord(float p, double centre, double fix_scale) {
+  return __double2ll_rn(((double)p - centre) * fix_scale);
+}
+
+// a3: exact sums -> Welford form (n, mean, M2) -> Sigma = M2/(n-1) -> eigenvalue clamp ->
+// Sigma^-1 record.  float64 scalar code in the order of oracle/ndt2d.py finalise_cell().
+// Returns false (record zeroed) when the cell is not usable.
+__device__ __forceinline__ bool finalise_sums(int n, long long sx, long long sy, long long sxx, long long sxy,
+                                              long long syy, double cx, double cy, double fix_scale,
+                                              int min_points, double eig_ratio, float4& ra, float2& rb) {
+  ra = make_float4(0.f, 0.f, 0.f, 0.f);
+  rb = make_float2(0.f, 0.f);
+  if (n < min_points || n < 2) return false;
+  const double inv_s = 1.0 / fix_scale;
+  const double dn = (double)n;
+  const double mx = fma((double)sx / dn, inv_s, cx);
+  const double my = fma((double)sy / dn, inv_s, cy);
+  // M2 = (n*Suu - Su*Su) / (n * S^2), numerator exact in 128-bit
+  const double den = 1.0 / (dn * fix_scale * fix_scale);
+  const double m2xx = to_double(sub128(mul_s64(n, sxx), mul_s64(sx, sx))) * den;
+  const double m2xy = to_double(sub128(mul_s64(n, sxy), mul_s64(sx, sy))) * den;
+  const double m2yy = to_double(sub128(mul_s64(n, syy), mul_s64(sy, sy))) * den;
+  const double vxx = m2xx / (dn - 1.0), vxy = m2xy / (dn - 1.0), vyy = m2yy / (dn - 1.0);
+  const double half_tr = 0.5 * (vxx + vyy);
+  const double half_df = 0.5 * (vxx - vyy);
+  const double disc = sqrt(fma(half_df, half_df, vxy * vxy));
+  const double l1 = half_tr + disc;
+  const double l2 = half_tr - disc;
+  if (!(l1 > 0.0)) return false;
+  const double l2c = fmax(l2, eig_ratio * l1);
+  double ex, ey;
+  if (half_df >= 0.0) { ex = half_df + disc; ey = vxy; }
+  else                { ex = vxy; ey = disc - half_df; }
+  const double nrm = sqrt(fma(ex, ex, ey * ey));
+  if (nrm > 0.0) { ex /= nrm; ey /= nrm; } else { ex = 1.0; ey = 0.0; }
+  const double i1 = 1.0 / l1, i2 = 1.0 / l2c, d = i1 - i2;
+  ra = make_float4((float)mx, (float)my, (float)fma(d * ex, ex, i2), (float)(d * ex * ey));
+  rb = make_float2((float)fma(d * ey, ey, i2), (float)n);
+  return true;
+}
+
 // ------------------------------------------------------------------ a1+a2 accumulate
 // Exact, order-independent per-cell sufficient statistics: cell-centred coordinates
 // quantised to c*2^-22 and summed with 64-bit integer atomics.  Integer addition is
@@ -131,10 +178,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float* __restrict__
     const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H);
     if (in) {
       const int ix = (int)fx, iy = (int)fy;
-      const double cx = (double)g.ox + ((double)ix + 0.5) * g.cell;
-      const double cy = (double)g.oy + ((double)iy + 0.5) * g.cell;
-      const long long ux = __double2ll_rn(((double)px - cx) * g.fix_scale);
-      const long long uy = __double2ll_rn(((double)py - cy) * g.fix_scale);
+      const long long ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
+      const long long uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
       CellAcc* c = g.acc + ((size_t)iy * g.W + ix);
       atomicAdd(&c->n, 1u);
       atomicAdd((unsigned long long*)&c->sx, (unsigned long long)ux);
@@ -150,49 +195,26 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------- a3 finalise
-// One thread per cell.  float64 scalar code in the order of oracle/ndt2d.py finalise_cell().
+// One thread per cell.
 __global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, double eig_ratio,
                                                       int* __restrict__ counters /*[2]: valid, overflow*/) {
   const size_t ncell = (size_t)g.W * g.H;
   const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= ncell) return;
   const CellAcc c = g.acc[k];
-  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
-  float2 rb = make_float2(0.f, 0.f);
-  const int n = (int)c.n;
-  if (c.n > kMaxCellCount) atomicAdd(&counters[1], 1);
-  if (n >= min_points && n >= 2 && c.n <= kMaxCellCount) {
+  float4 ra;
+  float2 rb;
+  bool ok = false;
+  if (c.n > kMaxCellCount) {
+    atomicAdd(&counters[1], 1);
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb = make_float2(0.f, 0.f);
+  } else {
     const int ix = (int)(k % g.W), iy = (int)(k / g.W);
-    const double cx = (double)g.ox + ((double)ix + 0.5) * g.cell;
-    const double cy = (double)g.oy + ((double)iy + 0.5) * g.cell;
-    const double inv_s = 1.0 / g.fix_scale;
-    const double dn = (double)n;
-    const double mx = cx + ((double)c.sx / dn) * inv_s;
-    const double my = cy + ((double)c.sy / dn) * inv_s;
-    // M2 = (n*Suu - Su*Su) / (n * S^2), numerator exact in 128-bit
-    const double den = 1.0 / (dn * g.fix_scale * g.fix_scale);
-    const double m2xx = to_double(sub128(mul_s64(n, c.sxx), mul_s64(c.sx, c.sx))) * den;
-    const double m2xy = to_double(sub128(mul_s64(n, c.sxy), mul_s64(c.sx, c.sy))) * den;
-    const double m2yy = to_double(sub128(mul_s64(n, c.syy), mul_s64(c.sy, c.sy))) * den;
-    const double sxx = m2xx / (dn - 1.0), sxy = m2xy / (dn - 1.0), syy = m2yy / (dn - 1.0);
-    const double half_tr = 0.5 * (sxx + syy);
-    const double half_df = 0.5 * (sxx - syy);
-    const double disc = sqrt(half_df * half_df + sxy * sxy);
-    const double l1 = half_tr + disc;
-    const double l2 = half_tr - disc;
-    if (l1 > 0.0) {
-      const double l2c = fmax(l2, eig_ratio * l1);
-      double ex, ey;
-      if (half_df >= 0.0) { ex = half_df + disc; ey = sxy; }
-      else                { ex = sxy; ey = disc - half_df; }
-      const double nrm = sqrt(ex * ex + ey * ey);
-      if (nrm > 0.0) { ex /= nrm; ey /= nrm; } else { ex = 1.0; ey = 0.0; }
-      const double i1 = 1.0 / l1, i2 = 1.0 / l2c, d = i1 - i2;
-      ra = make_float4((float)mx, (float)my, (float)(i2 + d * ex * ex), (float)(d * ex * ey));
-      rb = make_float2((float)(i2 + d * ey * ey), (float)n);
-      atomicAdd(&counters[0], 1);
-    }
+    ok = finalise_sums((int)c.n, c.sx, c.sy, c.sxx, c.sxy, c.syy, cell_centre(g.ox, ix, g.cell),
+                       cell_centre(g.oy, iy, g.cell), g.fix_scale, min_points, eig_ratio, ra, rb);
   }
+  if (ok) atomicAdd(&counters[0], 1);
   g.recA[k] = ra;
   g.recB[k] = rb;
 }

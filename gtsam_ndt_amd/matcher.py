@@ -179,3 +179,92 @@ class NdtMatcher2D:
     @property
     def stream(self) -> int:
         return int(self._lib.ndt2d_stream(self._h) or 0)
+
+
+RESULT_DOUBLES = C.sizeof(L.Result2D) // 8     # 16 doubles + 4 int32
+
+
+def _results_from_bytes(buf: np.ndarray, n: int):
+    arr = (L.Result2D * n).from_buffer_copy(buf.tobytes())
+    return [_to_result(r) for r in arr]
+
+
+class NdtBatch2D:
+    """Loop-closure candidate batch: independent scan pairs aligned concurrently on one GPU
+    (one persistent workgroup per CU, target grid resident in LDS).  Mirrors
+    ndt2d_batch_* of include/ndt_hip.h."""
+
+    def __init__(self, device: int = 0, params: L.Params2D | None = None, **overrides):
+        self._lib = L.load()
+        self.params = params if params is not None else default_params(**overrides)
+        if params is not None:
+            for k, v in overrides.items():
+                setattr(self.params, k, v)
+        h = C.c_void_p()
+        L.check(self._lib.ndt2d_batch_create(C.byref(self.params), int(device), C.byref(h)), "ndt2d_batch_create")
+        self._h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndt2d_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.ndt2d_batch_stream(self._h) or 0)
+
+    def align(self, targets, sources, inits):
+        """targets / sources: lists of (x, y) numpy pairs; inits: [n][3].  Returns a list of
+        AlignResult.  Pairs over the on-chip capacity are re-run through the general path."""
+        n = len(targets)
+        toff = np.zeros(n + 1, dtype=np.uint64)
+        soff = np.zeros(n + 1, dtype=np.uint64)
+        toff[1:] = np.cumsum([len(t[0]) for t in targets])
+        soff[1:] = np.cumsum([len(s[0]) for s in sources])
+        tx = np.concatenate([_host_f32(t[0]) for t in targets]); ty = np.concatenate([_host_f32(t[1]) for t in targets])
+        sx = np.concatenate([_host_f32(s[0]) for s in sources]); sy = np.concatenate([_host_f32(s[1]) for s in sources])
+        init = np.ascontiguousarray(inits, dtype=np.float64).reshape(n, 3)
+        out = np.zeros(n * RESULT_DOUBLES, dtype=np.float64)
+        L.check(self._lib.ndt2d_batch_align(self._h, tx.ctypes.data, ty.ctypes.data, toff.ctypes.data,
+                                            sx.ctypes.data, sy.ctypes.data, soff.ctypes.data, init.ctypes.data,
+                                            n, out.ctypes.data), "ndt2d_batch_align")
+        return _results_from_bytes(out, n)
+
+    def align_dev(self, tx, ty, toff, sx, sy, soff, init, out=None, stream=None):
+        """Everything already on the device (torch CUDA tensors: float32 clouds, int64
+        offsets [n+1], float64 init [n,3]).  Asynchronous; returns the float64 [n,18] result
+        tensor (decode with ``decode``) - valid once the stream is synchronised."""
+        import torch
+        n = int(toff.numel()) - 1
+        if out is None:
+            out = torch.empty((n, RESULT_DOUBLES), dtype=torch.float64, device=tx.device)
+        for t, dt in ((tx, torch.float32), (ty, torch.float32), (sx, torch.float32), (sy, torch.float32),
+                      (toff, torch.int64), (soff, torch.int64), (init, torch.float64), (out, torch.float64)):
+            if not (t.is_cuda and t.dtype == dt and t.is_contiguous()):
+                raise ValueError("batch tensors must be contiguous CUDA tensors of the documented dtypes")
+        self._keep = (tx, ty, toff, sx, sy, soff, init, out)
+        L.check(self._lib.ndt2d_batch_align_dev(
+            self._h, C.c_void_p(tx.data_ptr()), C.c_void_p(ty.data_ptr()), C.c_void_p(toff.data_ptr()),
+            C.c_void_p(sx.data_ptr()), C.c_void_p(sy.data_ptr()), C.c_void_p(soff.data_ptr()),
+            C.c_void_p(init.data_ptr()), n, C.c_void_p(out.data_ptr()),
+            C.c_void_p(stream if stream is not None else 0)), "ndt2d_batch_align_dev")
+        return out
+
+    @staticmethod
+    def decode(out_tensor):
+        """float64 [n,18] device/host tensor -> list of AlignResult (synchronises)."""
+        a = out_tensor.detach().cpu().numpy()
+        return _results_from_bytes(np.ascontiguousarray(a).reshape(-1), a.shape[0])

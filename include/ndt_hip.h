@@ -148,6 +148,27 @@ int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out);
 /* hipStream_t the handle enqueues on (as void*), for event timing by the caller */
 void* ndt2d_stream(ndt2d_handle* h);
 
+/* ---- loop-closure candidate batch (BASELINE config 4) -------------- */
+/* Independent scan pairs, aligned concurrently: one persistent workgroup per CU pulls pairs
+ * from a queue, builds the pair's target grid in LDS and runs its whole Gauss-Newton loop on
+ * chip.  Clouds are concatenated SoA arrays; pair k owns target points [toff[k], toff[k+1])
+ * and source points [soff[k], soff[k+1]); init is [n_pairs][3]; results is [n_pairs].
+ * A pair whose grid exceeds the on-chip capacity (more than 16384 cells or 2304 occupied
+ * cells) gets status NDT_ERR_CAPACITY from the _dev entry point; the host-pointer entry
+ * point re-runs such pairs through the general path transparently. */
+typedef struct ndt2d_batch ndt2d_batch;
+int32_t ndt2d_batch_create(const ndt2d_params* p, int32_t device_id, ndt2d_batch** out);
+int32_t ndt2d_batch_destroy(ndt2d_batch* b);
+int32_t ndt2d_batch_align(ndt2d_batch* b, const float* tx, const float* ty, const uint64_t* toff,
+                          const float* sx, const float* sy, const uint64_t* soff, const double* init,
+                          size_t n_pairs, ndt2d_result* results);
+/* All pointers are device pointers (results too).  Asynchronous on `stream` (NULL = the
+ * context's own stream): the results are valid once that stream is synchronised. */
+int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_ty, const uint64_t* d_toff,
+                              const float* d_sx, const float* d_sy, const uint64_t* d_soff,
+                              const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream);
+void* ndt2d_batch_stream(ndt2d_batch* b);
+
 #ifdef __cplusplus
 }
 #endif

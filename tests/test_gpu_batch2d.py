@@ -1,0 +1,88 @@
+"""Loop-closure batch path (BASELINE config 4): every pair's result must equal the single-pair
+path's and the CPU oracle's, independent of batching and of the queue order."""
+import numpy as np
+import pytest
+
+from gtsam_ndt_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pairs():
+    return [synth.make_pair(4, pair_index=k, n_tgt=20000, n_src=20000) for k in range(12)]
+
+
+def _run_batch(gpu_lib, pairs, **kw):
+    from gtsam_ndt_amd.matcher import NdtBatch2D
+    with NdtBatch2D(**kw) as b:
+        return b.align([(p["tx"], p["ty"]) for p in pairs], [(p["sx"], p["sy"]) for p in pairs],
+                       [p["init"] for p in pairs])
+
+
+def test_batch_matches_oracle_and_single_pair_path(gpu_lib, pairs):
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    from oracle import ndt2d as o
+    res = _run_batch(gpu_lib, pairs)
+    prm = o.NdtParams()
+    with NdtMatcher2D() as m:
+        for p, r in zip(pairs, res):
+            ref = o.align(o.build_grid(p["tx"], p["ty"], prm), p["sx"], p["sy"], p["init"], prm)
+            m.set_target(p["tx"], p["ty"])
+            s = m.align(p["sx"], p["sy"], p["init"])
+            assert r.status == 0 == ref["status"] == s.status
+            e = np.abs(np.array(r.pose) - np.array(ref["pose"]))
+            assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 1e-4          # BASELINE.json tolerance
+            assert np.abs(np.array(r.pose) - np.array(s.pose)).max() < 2e-5
+            assert abs(r.iterations - ref["iterations"]) <= 3
+            assert abs(r.n_hit - ref["n_hit"]) <= 3
+            assert abs(r.score - ref["score"]) / ref["score"] < 1e-3
+            assert np.abs(r.H - ref["H"]).max() / np.abs(ref["H"]).max() < 2e-3
+
+
+def test_batch_fixed_iterations_and_determinism(gpu_lib, pairs):
+    a = _run_batch(gpu_lib, pairs, fixed_iterations=7)
+    b = _run_batch(gpu_lib, pairs[::-1], fixed_iterations=7)[::-1]     # other queue order
+    for x, y in zip(a, b):
+        assert x.iterations == 7 == y.iterations
+        assert x.pose == y.pose                                         # bitwise: fixed trees, integer atomics
+        np.testing.assert_array_equal(x.H, y.H)
+
+
+def test_batch_ragged_and_edge_pairs(gpu_lib, pairs):
+    """Pairs of different sizes in one batch; empty-ish, sparse and far-away pairs get their
+    status without disturbing their neighbours."""
+    from gtsam_ndt_amd import _lib as L
+    p0, p1 = pairs[0], pairs[1]
+    sparse_t = (np.array([0.0, 10.0], np.float32), np.array([0.0, 10.0], np.float32))
+    targets = [(p0["tx"], p0["ty"]), sparse_t, (p1["tx"][:5000], p1["ty"][:5000]), (p0["tx"], p0["ty"])]
+    sources = [(p0["sx"][:777], p0["sy"][:777]), (p0["sx"], p0["sy"]), (p1["sx"], p1["sy"]),
+               (p0["sx"] + 1000.0, p0["sy"])]
+    inits = [p0["init"], p0["init"], p1["init"], p0["init"]]
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMatcher2D
+    with NdtBatch2D() as b:
+        res = b.align(targets, sources, inits)
+    assert res[1].status == L.NDT_TOO_FEW_CELLS
+    assert res[3].status == L.NDT_TOO_FEW_HITS and res[3].iterations == 0
+    with NdtMatcher2D() as m:
+        for k in (0, 2):
+            m.set_target(*targets[k])
+            s = m.align(*sources[k], inits[k])
+            assert res[k].status == s.status
+            assert np.abs(np.array(res[k].pose) - np.array(s.pose)).max() < 5e-5
+
+
+def test_batch_capacity_fallback(gpu_lib):
+    """A target wider than the on-chip index table (here 100 m at 0.5 m cells) is re-run
+    through the global-memory path by the host-pointer entry point."""
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMatcher2D
+    d = synth.make_pair(3, n_tgt=200000, n_src=20000)       # 200 m submap: 404 x 404 cells
+    small = synth.make_pair(4, pair_index=3, n_tgt=20000, n_src=20000)
+    with NdtBatch2D() as b:
+        res = b.align([(d["tx"], d["ty"]), (small["tx"], small["ty"])],
+                      [(d["sx"], d["sy"]), (small["sx"], small["sy"])], [d["init"], small["init"]])
+    with NdtMatcher2D() as m:
+        m.set_target(d["tx"], d["ty"])
+        s = m.align(d["sx"], d["sy"], d["init"])
+    assert res[0].status == s.status == 0 and res[0].pose == s.pose
+    assert res[1].status == 0
