@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="N=1: skip the extra loop-closure batch figure")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the N>1 code path (process group + all_gather) even with one rank")
     return ap.parse_args()
 
 
@@ -111,6 +113,93 @@ def cpu_baseline(d, seconds: float):
     return best
 
 
+def run_batch(a, dev, dev_index, rank, world, dist, barrier):
+    """BASELINE config 4, this rank's shard: pairs_per_rank candidate pairs x batch_points,
+    all resident in HBM; a step aligns every pair (LDS grid build + 30 GN iterations each) and
+    gathers the per-pair results of all ranks (RCCL all_gather; the path's only collective)."""
+    from gtsam_ndt_amd import dist as nd, synth
+    from gtsam_ndt_amd.matcher import NdtBatch2D
+    ppr, npts = a.pairs_per_rank, a.batch_points
+    total = ppr * world
+    mine = nd.shard_range(total, rank, world)
+    pairs = [synth.make_pair(4, pair_index=k, n_tgt=npts, n_src=npts) for k in mine]
+    h = nd.pack_pairs(pairs)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
+    truth = np.array([p["pose"] for p in pairs])
+    del pairs, h
+    b = NdtBatch2D(device=dev_index, fixed_iterations=K_GN)
+    # one explicit (non-default) stream carries the kernel, the HIP events and - through
+    # torch.distributed's stream ordering - the RCCL all_gather that consumes the results
+    side = torch.cuda.Stream(device=dev)
+    res = torch.empty((ppr, 18), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        cur = side.cuda_stream
+        assert cur != 0
+
+        def step():
+            b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"], out=res, stream=cur)
+            return nd.gather_results(res, total) if dist is not None else res
+
+        for _ in range(max(1, a.warmup)):
+            allr = step()
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        t0 = time.perf_counter()
+        for e0, e1 in ev:
+            e0.record(side)
+            b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"], out=res, stream=cur)
+            e1.record(side)
+            allr = nd.gather_results(res, total) if dist is not None else res
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev)
+    if dist is not None:
+        elapsed = nd.max_over_ranks(elapsed, device=dev)
+    rows = NdtBatch2D.decode(allr)
+    assert len(rows) == total and all(r.iterations == K_GN and r.status == 0 for r in rows)
+    local = rows[mine.start: mine.stop]
+    err = np.abs(np.array([r.pose for r in local]) - truth)      # vs the generating pose (sampling noise)
+    iters = total * K_GN * a.steps
+    launch_ms = kern_ms / a.steps
+    # Algorithmic HBM bytes of one pair for THIS kernel (DESIGN.md section 7): the target once
+    # (8 B/pt) + the source once per iteration (8 B/pt; 0.8 MB per pair does not fit on chip)
+    # + one result row.  SURVEY.md section 8d's figure of record, 32 B per point-iteration,
+    # also counts the 24 B cell-record gather, which this kernel serves from LDS - it is
+    # reported beside it, not as the roofline numerator.
+    alg_pair = 8 * npts + K_GN * 8 * npts + 144
+    streamed_pair = 3 * 8 * npts + K_GN * 8 * npts + 144          # what the kernel reads: 3 target passes
+    survey_pair = 8 * npts + 24 * 10816 + K_GN * BYTES_PER_POINT_ITER * npts
+    achieved = ppr * alg_pair / (launch_ms * 1e-3) / 1e9
+    out = {
+        "metric": METRIC, "value": round(iters / elapsed, 1), "unit": "iters/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"config4: loop-closure batch, {ppr} candidate pairs x {npts} pts per GPU "
+                               f"({total} pairs total), 0.5 m cells, grid build + fixed 30 GN iterations per pair",
+                   "pairs_per_gpu": ppr, "pairs_total": total, "n_target": npts, "n_source": npts,
+                   "cell_size": 0.5, "gn_iterations_per_pair": K_GN, "collective": "all_gather of 144 B/pair"
+                   if world > 1 else "none (1 GPU)"},
+        "pairs_per_s": round(total * a.steps / elapsed, 1),
+        "roofline": {"bound": "hbm", "kernel": "k_batch<GN>", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": (load_traffic() or {}).get("batch_bytes_per_launch"),
+                     "algorithmic_bytes_per_launch": ppr * alg_pair, "avg_launch_us": round(1e3 * launch_ms, 1),
+                     "streamed_bytes_per_launch": ppr * streamed_pair,
+                     "survey_8d_bytes_per_launch": ppr * survey_pair,
+                     "survey_8d_GBps": round(ppr * survey_pair / (launch_ms * 1e-3) / 1e9, 1),
+                     "timing": "HIP events on the launch stream around each k_batch launch (rank 0)",
+                     "note": "numerator = 8 B/pt target once + 8 B/pt source per iteration; SURVEY.md 8d's "
+                             "32 B per point-iteration also counts the 24 B cell record, LDS-served here "
+                             "(survey_8d_* fields)"},
+        "pose_err_vs_truth_max": {"dx_m": float(err[:, 0].max()), "dy_m": float(err[:, 1].max()),
+                                  "dtheta_rad": float(err[:, 2].max()),
+                                  "note": "fixed 30 iterations vs the generating pose (sampling noise included)"},
+    }
+    b.close()
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -120,11 +209,13 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist_
         dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev_index = local_rank if world > 1 else 0
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
@@ -140,7 +231,7 @@ def main():
         torch.cuda.synchronize()
 
     out = {}
-    if world == 1:
+    if dist is None:
         # ------------------------------------------------------------- config 3, single pair
         d = synth.make_pair(3)
         tx, ty, sx, sy = (torch.from_numpy(d[k]).to(dev) for k in ("tx", "ty", "sx", "sy"))
@@ -206,8 +297,10 @@ def main():
         m.close()
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, a.cpu_seconds)
+        if not a.no_batch:
+            out["batch"] = run_batch(a, dev, dev_index, 0, 1, None, barrier)
     else:
-        raise SystemExit("multi-GPU batch path: see bench_batch section (not yet wired)")
+        out = run_batch(a, dev, dev_index, rank, world, dist, barrier)
 
     if rank == 0:
         print(json.dumps(out))

@@ -1,0 +1,67 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes exercise the pair sharding and the one
+result gather exactly as bench.py does on GPUs with RCCL (no compute: there is no GPU here)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gtsam_ndt_amd import dist as nd
+
+
+def test_shards_partition_the_batch():
+    for total, world in ((4096, 8), (4096, 1), (1000, 3), (7, 8), (0, 2)):
+        got = [i for r in range(world) for i in nd.shard_range(total, r, world)]
+        assert got == list(range(total))
+        sizes = nd.shard_sizes(total, world)
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        nd.shard_range(10, 2, 2)
+
+
+def _fake_rows(idx):
+    """Deterministic stand-in for ndt2d_result rows keyed by global pair index."""
+    i = np.asarray(list(idx), dtype=np.float64)[:, None]
+    return torch.from_numpy(i * 1000.0 + np.arange(18, dtype=np.float64)[None, :])
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = nd.shard_range(total, rank, world)
+        allr = nd.gather_results(_fake_rows(mine), total)
+        ok = bool(torch.equal(allr, _fake_rows(range(total))))
+        t = nd.max_over_ranks(1.0 + rank)
+        q.put((rank, ok, t))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [1024, 11])
+def test_gather_restores_global_pair_order_world2(total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + total % 7
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == [0, 1]
+    assert all(ok for _, ok, _ in res)
+    assert all(t == 2.0 for _, _, t in res)          # max over ranks of (1 + rank)
+
+
+def test_pack_pairs_layout():
+    from gtsam_ndt_amd import synth
+    ps = [synth.make_pair(4, pair_index=k, n_tgt=100 + k, n_src=50 + 2 * k) for k in range(3)]
+    b = nd.pack_pairs(ps)
+    assert list(b["toff"]) == [0, 100, 201, 303] and list(b["soff"]) == [0, 50, 102, 156]
+    assert np.array_equal(b["tx"][100:201], ps[1]["tx"]) and np.array_equal(b["sy"][102:156], ps[2]["sy"])
+    assert b["init"].shape == (3, 3)
