@@ -1,0 +1,163 @@
+// ndt_matcher_hip.hpp - header-only C++ adapter over the C ABI (ndt_hip.h).
+//
+// This is the host-side mirror of the scan-matcher interface named by BASELINE.json's
+// north_star ("the repo's existing scan-matcher -> GTSAM-factor interface").  The reference
+// checkout shows no such interface (/root/reference/README.md:1 is its only line), so the
+// class below is this repo's proposal of the smallest one a SLAM front end needs:
+//   setTarget(scan or submap)  ->  align(scan, initial guess)  ->  pose + information.
+// INTEGRATION.md shows how a maintainer maps it onto the real interface.
+//
+// No GPU code here: everything goes through extern "C" entry points of libndt_hip.so.
+#ifndef NDT_MATCHER_HIP_HPP_
+#define NDT_MATCHER_HIP_HPP_
+
+#include <array>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ndt_hip.h"
+
+namespace ndt {
+
+struct Pose2 {           // tx, ty, theta: maps source-frame points into the target frame
+  double x = 0.0, y = 0.0, theta = 0.0;
+};
+
+struct MatchResult {
+  Pose2 pose;
+  std::array<double, 9> information{};   // row-major 3x3 Hessian of -score at the last evaluation
+  std::array<double, 9> covariance{};    // its inverse (zero if the Hessian is singular)
+  double score = 0.0;
+  int iterations = 0;
+  int n_hit = 0;
+  int status = NDT_OK;                   // NDT_OK / NDT_NOT_CONVERGED / ...
+  bool converged() const { return status == NDT_OK; }
+};
+
+class NdtError : public std::runtime_error {
+ public:
+  NdtError(int32_t code, const std::string& where)
+      : std::runtime_error(where + ": " + ndt_status_string(code) + " (" + std::to_string(code) + ") " +
+                           ndt_last_error()),
+        code_(code) {}
+  int32_t code() const { return code_; }
+
+ private:
+  int32_t code_;
+};
+
+inline bool invert3(const double* H, double* C) {
+  const double a = H[0], b = H[1], c = H[2], d = H[4], e = H[5], f = H[8];   // symmetric
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  if (!(det > 0.0) && !(det < 0.0)) { for (int i = 0; i < 9; ++i) C[i] = 0.0; return false; }
+  const double id = 1.0 / det;
+  C[0] = c00 * id; C[1] = c01 * id; C[2] = c02 * id;
+  C[3] = C[1];     C[4] = (a * f - c * c) * id; C[5] = (b * c - a * e) * id;
+  C[6] = C[2];     C[7] = C[5];                 C[8] = (a * d - b * b) * id;
+  return true;
+}
+
+inline MatchResult to_match_result(const ndt2d_result& r) {
+  MatchResult m;
+  m.pose = {r.pose[0], r.pose[1], r.pose[2]};
+  for (int i = 0; i < 9; ++i) m.information[i] = r.H[i];
+  invert3(r.H, m.covariance.data());
+  m.score = r.score; m.iterations = r.iterations; m.n_hit = r.n_hit; m.status = r.status;
+  return m;
+}
+
+// One matcher = one device stream + one cached target grid.  Not thread-safe; use one
+// instance per thread (distinct instances are independent).
+class NdtMatcherHip {
+ public:
+  static ndt2d_params defaultParams() { ndt2d_params p; ndt2d_default_params(&p); return p; }
+
+  explicit NdtMatcherHip(const ndt2d_params& params = defaultParams(), int device = 0) {
+    const int32_t st = ndt2d_create(&params, device, &h_);
+    if (st != NDT_OK) throw NdtError(st, "ndt2d_create");
+  }
+  ~NdtMatcherHip() { ndt2d_destroy(h_); }
+  NdtMatcherHip(const NdtMatcherHip&) = delete;
+  NdtMatcherHip& operator=(const NdtMatcherHip&) = delete;
+
+  // (i) target grid from SoA float arrays
+  void setTarget(const float* x, const float* y, size_t n) { check(ndt2d_set_target(h_, x, y, n), "ndt2d_set_target"); }
+  void setTarget(const std::vector<float>& x, const std::vector<float>& y) { setTarget(x.data(), y.data(), x.size()); }
+  // incremental submap update: returns the number of points outside the cached extent
+  size_t addTargetPoints(const float* x, const float* y, size_t n) {
+    size_t outside = 0;
+    check(ndt2d_add_target_points(h_, x, y, n, &outside), "ndt2d_add_target_points");
+    return outside;
+  }
+  ndt2d_grid_info gridInfo() const { ndt2d_grid_info g; check(ndt2d_get_grid_info(h_, &g), "ndt2d_get_grid_info"); return g; }
+
+  // (ii)+(iii)+solve: full alignment from an initial guess
+  MatchResult align(const float* sx, const float* sy, size_t n, const Pose2& guess = Pose2()) {
+    const double init[3] = {guess.x, guess.y, guess.theta};
+    ndt2d_result r;
+    check(ndt2d_align(h_, sx, sy, n, init, &r), "ndt2d_align");
+    return to_match_result(r);
+  }
+  MatchResult align(const std::vector<float>& sx, const std::vector<float>& sy, const Pose2& guess = Pose2()) {
+    return align(sx.data(), sy.data(), sx.size(), guess);
+  }
+  // one evaluation at a fixed pose, for callers with their own optimiser
+  ndt2d_eval evaluate(const float* sx, const float* sy, size_t n, const Pose2& at) {
+    const double p[3] = {at.x, at.y, at.theta};
+    ndt2d_eval e;
+    check(ndt2d_evaluate(h_, sx, sy, n, p, &e), "ndt2d_evaluate");
+    return e;
+  }
+  ndt2d_handle* raw() { return h_; }
+
+ private:
+  static void check(int32_t st, const char* where) { if (st < 0) throw NdtError(st, where); }
+  ndt2d_handle* h_ = nullptr;
+};
+
+// Loop-closure candidates: many independent pairs in one call.
+class NdtBatchHip {
+ public:
+  struct Cloud { const float* x; const float* y; size_t n; };
+
+  explicit NdtBatchHip(const ndt2d_params& params = NdtMatcherHip::defaultParams(), int device = 0) {
+    const int32_t st = ndt2d_batch_create(&params, device, &b_);
+    if (st != NDT_OK) throw NdtError(st, "ndt2d_batch_create");
+  }
+  ~NdtBatchHip() { ndt2d_batch_destroy(b_); }
+  NdtBatchHip(const NdtBatchHip&) = delete;
+  NdtBatchHip& operator=(const NdtBatchHip&) = delete;
+
+  std::vector<MatchResult> align(const std::vector<Cloud>& targets, const std::vector<Cloud>& sources,
+                                 const std::vector<Pose2>& guesses) {
+    const size_t n = targets.size();
+    if (sources.size() != n || guesses.size() != n || n == 0) throw NdtError(NDT_ERR_INVALID_ARG, "NdtBatchHip::align");
+    std::vector<uint64_t> toff(n + 1, 0), soff(n + 1, 0);
+    for (size_t k = 0; k < n; ++k) { toff[k + 1] = toff[k] + targets[k].n; soff[k + 1] = soff[k] + sources[k].n; }
+    std::vector<float> tx(toff[n]), ty(toff[n]), sx(soff[n]), sy(soff[n]);
+    std::vector<double> init(3 * n);
+    for (size_t k = 0; k < n; ++k) {
+      std::copy(targets[k].x, targets[k].x + targets[k].n, tx.begin() + toff[k]);
+      std::copy(targets[k].y, targets[k].y + targets[k].n, ty.begin() + toff[k]);
+      std::copy(sources[k].x, sources[k].x + sources[k].n, sx.begin() + soff[k]);
+      std::copy(sources[k].y, sources[k].y + sources[k].n, sy.begin() + soff[k]);
+      init[3 * k] = guesses[k].x; init[3 * k + 1] = guesses[k].y; init[3 * k + 2] = guesses[k].theta;
+    }
+    std::vector<ndt2d_result> res(n);
+    const int32_t st = ndt2d_batch_align(b_, tx.data(), ty.data(), toff.data(), sx.data(), sy.data(), soff.data(),
+                                         init.data(), n, res.data());
+    if (st < 0) throw NdtError(st, "ndt2d_batch_align");
+    std::vector<MatchResult> out;
+    out.reserve(n);
+    for (const auto& r : res) out.push_back(to_match_result(r));
+    return out;
+  }
+
+ private:
+  ndt2d_batch* b_ = nullptr;
+};
+
+}  // namespace ndt
+#endif  // NDT_MATCHER_HIP_HPP_
