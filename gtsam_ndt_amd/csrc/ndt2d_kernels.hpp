@@ -209,10 +209,14 @@ __global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, 
     atomicAdd(&counters[1], 1);
     ra = make_float4(0.f, 0.f, 0.f, 0.f);
     rb = make_float2(0.f, 0.f);
-  } else {
-    const int ix = (int)(k % g.W), iy = (int)(k / g.W);
+  } else if ((int)c.n >= min_points) {             // empty cells (the vast majority) skip everything
+    const unsigned int k32 = (unsigned int)k, w32 = (unsigned int)g.W;   // ncell <= 2^27: 32-bit div
+    const int ix = (int)(k32 % w32), iy = (int)(k32 / w32);
     ok = finalise_sums((int)c.n, c.sx, c.sy, c.sxx, c.sxy, c.syy, cell_centre(g.ox, ix, g.cell),
                        cell_centre(g.oy, iy, g.cell), g.fix_scale, min_points, eig_ratio, ra, rb);
+  } else {
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb = make_float2(0.f, 0.f);
   }
   if (ok) atomicAdd(&counters[0], 1);
   g.recA[k] = ra;
