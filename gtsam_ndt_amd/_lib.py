@@ -77,6 +77,21 @@ class GridInfo2D(C.Structure):
     ]
 
 
+class Result3D(C.Structure):
+    _fields_ = [("pose", C.c_double * 6), ("H", C.c_double * 36), ("g", C.c_double * 6), ("score", C.c_double),
+                ("iterations", C.c_int32), ("n_hit", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Eval3D(C.Structure):
+    _fields_ = [("H", C.c_double * 36), ("g", C.c_double * 6), ("score", C.c_double), ("n_hit", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class GridInfo3D(C.Structure):
+    _fields_ = [("ox", C.c_float), ("oy", C.c_float), ("oz", C.c_float), ("inv_cell", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_int32), ("n_valid", C.c_int32)]
+
+
 _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
@@ -107,6 +122,15 @@ SIGNATURES = {
     "ndt2d_batch_align": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ndt2d_batch_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "ndt2d_batch_stream": (_vp, [_vp]),
+    "ndt3d_default_params": (None, [C.POINTER(Params2D)]),
+    "ndt3d_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),
+    "ndt3d_destroy": (C.c_int32, [_vp]),
+    "ndt3d_set_target": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t]),
+    "ndt3d_get_grid_info": (C.c_int32, [_vp, C.POINTER(GridInfo3D)]),
+    "ndt3d_get_grid": (C.c_int32, [_vp, _vp, _vp, _vp]),
+    "ndt3d_evaluate": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval3D)]),
+    "ndt3d_align": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result3D)]),
+    "ndt3d_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result3D)]),
 }
 
 _lib = None

@@ -1,0 +1,336 @@
+// C-ABI of the 3D SE(3) variant (included at the end of ndt2d_api.hip: one translation unit).
+#pragma once
+#include "ndt3d_kernels.hpp"
+
+struct ndt3d_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  ndt3d_params prm{};
+  ndt::Grid3Dev grid{};
+  size_t cell_capacity = 0;
+  bool has_target = false;
+  int n_valid = 0;
+  unsigned int* d_bounds = nullptr;   // [6]
+  int* d_counters = nullptr;          // [2]
+  void* h_small = nullptr;            // pinned 64 B
+  float *d_t[3] = {nullptr, nullptr, nullptr}; size_t tcap = 0;
+  float *d_s[3] = {nullptr, nullptr, nullptr}; size_t scap = 0;
+  ndt::AlignStatic3* d_static = nullptr;
+  ndt::AlignCall3* d_call = nullptr;
+  ndt::AlignDyn3* d_dyn = nullptr;
+  ndt::AlignStatic3* h_static = nullptr;
+  ndt::IterState3* h_state = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph = nullptr;
+  int graph_launches = 0;
+  bool host_result = false;           // result already in h_state (no device work was enqueued)
+};
+
+namespace {
+
+int32_t ensure3(float** d, size_t* cap, size_t n) {
+  if (n <= *cap) return NDT_OK;
+  for (int a = 0; a < 3; ++a) { if (d[a]) (void)hipFree(d[a]); d[a] = nullptr; }
+  *cap = 0;
+  const size_t want = n + n / 4 + 1024;
+  for (int a = 0; a < 3; ++a) HIP_TRY(hipMalloc((void**)&d[a], want * sizeof(float)));
+  *cap = want;
+  return NDT_OK;
+}
+
+int32_t upload_static3(ndt3d_handle* h) {
+  ndt::AlignStatic3* c = h->h_static;
+  c->grid = h->grid;
+  ndt::SolveParams& p = c->prm;
+  p.d1 = (float)h->prm.d1; p.d2 = (float)h->prm.d2;
+  p.hessian_mode = 0; p.max_iterations = h->prm.max_iterations; p.min_hits = h->prm.min_hits; p.pad = 0;
+  p.eps_trans = h->prm.eps_trans; p.eps_rot = h->prm.eps_rot;
+  p.step_max_trans = h->prm.step_max_trans; p.step_max_rot = h->prm.step_max_rot;
+  HIP_TRY(hipMemcpyAsync(h->d_static, c, sizeof(ndt::AlignStatic3), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NDT_OK;
+}
+
+int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
+  using namespace ndt;
+  h->has_target = false;
+  unsigned int* hb = (unsigned int*)h->h_small;
+  for (int a = 0; a < 3; ++a) { hb[2 * a] = 0xFFFFFFFFu; hb[2 * a + 1] = 0u; }
+  HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, 24, hipMemcpyHostToDevice, h->stream));
+  const int sb = stream_blocks(n) > 512 ? 512 : stream_blocks(n);
+  hipLaunchKernelGGL(k_bounds3, dim3(sb), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_bounds);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, 24, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (hb[0] == 0xFFFFFFFFu || hb[1] == 0u) { set_error("target has no finite point"); return NDT_ERR_INVALID_ARG; }
+  const double c = h->prm.cell_size;
+  Grid3Dev& g = h->grid;
+  g.cell = c;
+  g.inv_c = (float)(1.0 / c);
+  float o[3];
+  int dims[3];
+  double ncell_d = 1.0;
+  for (int a = 0; a < 3; ++a) {
+    const float mn = ordered_to_float(hb[2 * a]), mx = ordered_to_float(hb[2 * a + 1]);
+    o[a] = (float)((std::floor((double)mn / c) - 1.0) * c);
+    const volatile float f = (mx - o[a]) * g.inv_c;
+    const double k = std::floor((double)f);
+    if (!(k >= 0.0) || k > 1e7) { set_error("target extent too large for the cell size"); return NDT_ERR_CAPACITY; }
+    dims[a] = (int)k + 2;
+    ncell_d *= dims[a];
+  }
+  if (ncell_d > (double)kMaxCells) { set_error("3D target needs more than 2^27 cells"); return NDT_ERR_CAPACITY; }
+  g.ox = o[0]; g.oy = o[1]; g.oz = o[2];
+  g.W = dims[0]; g.H = dims[1]; g.D = dims[2]; g.pad = 0;
+  g.fix_scale = std::ldexp(1.0, kFixShift) / c;
+  const size_t ncell = (size_t)g.W * g.H * g.D;
+  if (ncell > h->cell_capacity) {
+    void* old[] = {g.recA, g.recB, g.recC, g.acc};
+    for (void* p : old) if (p) (void)hipFree(p);
+    g.recA = nullptr; g.recB = nullptr; g.recC = nullptr; g.acc = nullptr; h->cell_capacity = 0;
+    const size_t want = ncell + ncell / 8;
+    HIP_TRY(hipMalloc((void**)&g.recA, want * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&g.recB, want * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&g.recC, want * sizeof(float2)));
+    HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc3)));
+    h->cell_capacity = want;
+  }
+  HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));
+  hipLaunchKernelGGL(k_accumulate3, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, g);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_finalise3, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, g,
+                     h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+  HIP_TRY(hipGetLastError());
+  int* hc = (int*)h->h_small;
+  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->n_valid = hc[0];
+  if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+  h->has_target = true;
+  return upload_static3(h);
+}
+
+int32_t ensure_graph3(ndt3d_handle* h, int launches) {
+  using namespace ndt;
+  if (h->graph_exec && h->graph_launches == launches) return NDT_OK;
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
+  h->graph_exec = nullptr; h->graph = nullptr; h->graph_launches = 0;
+  HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+  for (int k = 0; k < launches; ++k)
+    hipLaunchKernelGGL(k_iterate3, dim3(kMaxBlocks), dim3(kBlock), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(h->stream, &g);
+  if (e != hipSuccess || !g) { set_error("hipStreamEndCapture failed"); (void)hipGetLastError(); return NDT_ERR_HIP; }
+  h->graph = g;
+  HIP_TRY(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+  h->graph_launches = launches;
+  return NDT_OK;
+}
+
+// runs the loop and leaves the final state in h->h_state
+int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n, const double* pose,
+                   int fixed_override) {
+  using namespace ndt;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  if (n == 0 || n > 0x7fffffffull) return NDT_ERR_INVALID_ARG;
+  if (h->n_valid < 1) {
+    std::memset(h->h_state, 0, sizeof(IterState3));
+    for (int j = 0; j < 6; ++j) h->h_state->pose[j] = pose[j];
+    h->h_state->status = NDT_TOO_FEW_CELLS;
+    return NDT_OK;
+  }
+  const int fixed = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
+  hipLaunchKernelGGL(k_begin3, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, dx, dy, dz, (int)n, pose[0], pose[1],
+                     pose[2], pose[3], pose[4], pose[5], fixed);
+  const int K = fixed > 0 ? fixed : h->prm.max_iterations;
+  int last_parity;
+  if (fixed > 0) {
+    const int32_t gs = ensure_graph3(h, K + 1);
+    if (gs != NDT_OK) return gs;
+    HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+    last_parity = K & 1;
+  } else {
+    const int chunk = 8;
+    const int32_t gs = ensure_graph3(h, chunk);
+    if (gs != NDT_OK) return gs;
+    for (int k = 0; k <= K;) {
+      HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+      k += chunk;
+      if (k > K) break;
+      HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[1], sizeof(IterState3), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->h_state->done) break;
+    }
+    last_parity = 1;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[last_parity], sizeof(IterState3), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NDT_OK;
+}
+
+void unpack_h21(const double* s, double* H) {
+  H[0] = s[0]; H[1] = s[1]; H[2] = s[2]; H[7] = s[3]; H[8] = s[4]; H[14] = s[5];
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) H[6 * r + 3 + k] = s[6 + 3 * r + k];
+  H[21] = s[15]; H[22] = s[16]; H[23] = s[17]; H[28] = s[18]; H[29] = s[19]; H[35] = s[20];
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < r; ++c) H[6 * r + c] = H[6 * c + r];
+}
+
+}  // namespace
+
+extern "C" {
+
+void ndt3d_default_params(ndt3d_params* p) {
+  if (!p) return;
+  ndt2d_default_params(p);
+  p->cell_size = 1.0;
+  p->min_points = 5;
+  p->step_max_trans = 1.0;
+  p->min_hits = 6;
+}
+
+int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** out) {
+  if (!out) return NDT_ERR_INVALID_ARG;
+  *out = nullptr;
+  const int32_t st = check_params(p);
+  if (st != NDT_OK) return st;
+  if (p->hessian_mode != NDT_HESSIAN_GAUSS_NEWTON) { set_error("3D path implements the Gauss-Newton Hessian only"); return NDT_ERR_INVALID_ARG; }
+  const int ndev = ndt_device_count();
+  if (ndev <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }
+  if (device_id < 0 || device_id >= ndev) return NDT_ERR_INVALID_ARG;
+  ndt3d_handle* h = new (std::nothrow) ndt3d_handle();
+  if (!h) return NDT_ERR_ALLOC;
+  h->device = device_id;
+  h->prm = *p;
+  auto fail = [&](int32_t code) { ndt3d_destroy(h); return code; };
+  if (hipSetDevice(device_id) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipMalloc((void**)&h->d_bounds, 32) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_counters, 2 * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_static, sizeof(ndt::AlignStatic3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_call, sizeof(ndt::AlignCall3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_dyn, sizeof(ndt::AlignDyn3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc((void**)&h->h_static, sizeof(ndt::AlignStatic3), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc((void**)&h->h_state, sizeof(ndt::IterState3), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMemset(h->d_dyn, 0, sizeof(ndt::AlignDyn3)) != hipSuccess) return fail(NDT_ERR_HIP);
+  *out = h;
+  return NDT_OK;
+}
+
+int32_t ndt3d_destroy(ndt3d_handle* h) {
+  if (!h) return NDT_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
+  void* dev[] = {h->d_bounds, h->d_counters, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
+                 h->d_s[0], h->d_s[1], h->d_s[2], h->grid.recA, h->grid.recB, h->grid.recC, h->grid.acc};
+  for (void* p : dev) if (p) (void)hipFree(p);
+  void* host[] = {h->h_static, h->h_state, h->h_small};
+  for (void* p : host) if (p) (void)hipHostFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return NDT_OK;
+}
+
+int32_t ndt3d_set_target(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n) {
+  if (!h || !x || !y || !z || n == 0) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = ensure3(h->d_t, &h->tcap, n);
+  if (st != NDT_OK) return st;
+  const float* src[3] = {x, y, z};
+  for (int a = 0; a < 3; ++a) HIP_TRY(hipMemcpyAsync(h->d_t[a], src[a], n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  return set_target3_impl(h, h->d_t[0], h->d_t[1], h->d_t[2], n);
+}
+
+int32_t ndt3d_get_grid_info(ndt3d_handle* h, ndt3d_grid_info* info) {
+  if (!h || !info) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  info->ox = h->grid.ox; info->oy = h->grid.oy; info->oz = h->grid.oz; info->inv_cell = h->grid.inv_c;
+  info->width = h->grid.W; info->height = h->grid.H; info->depth = h->grid.D; info->n_valid = h->n_valid;
+  return NDT_OK;
+}
+
+int32_t ndt3d_get_grid(ndt3d_handle* h, int32_t* count, float* mean_xyz, float* icov6) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nc = (size_t)h->grid.W * h->grid.H * h->grid.D;
+  float4* a = new (std::nothrow) float4[nc];
+  float4* b = new (std::nothrow) float4[nc];
+  float2* c = new (std::nothrow) float2[nc];
+  ndt::CellAcc3* acc = count ? new (std::nothrow) ndt::CellAcc3[nc] : nullptr;
+  int32_t rc = (!a || !b || !c || (count && !acc)) ? NDT_ERR_ALLOC : NDT_OK;
+  if (rc == NDT_OK && hipMemcpyAsync(a, h->grid.recA, nc * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK && hipMemcpyAsync(b, h->grid.recB, nc * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK && hipMemcpyAsync(c, h->grid.recC, nc * sizeof(float2), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK && acc && hipMemcpyAsync(acc, h->grid.acc, nc * sizeof(ndt::CellAcc3), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK) {
+    for (size_t k = 0; k < nc; ++k) {
+      const bool valid = a[k].w > 0.f;
+      if (count) count[k] = (int32_t)acc[k].n;
+      if (mean_xyz) { mean_xyz[3 * k] = valid ? a[k].x : 0.f; mean_xyz[3 * k + 1] = valid ? a[k].y : 0.f; mean_xyz[3 * k + 2] = valid ? a[k].z : 0.f; }
+      if (icov6) {
+        icov6[6 * k] = b[k].x; icov6[6 * k + 1] = b[k].y; icov6[6 * k + 2] = b[k].z; icov6[6 * k + 3] = b[k].w;
+        icov6[6 * k + 4] = c[k].x; icov6[6 * k + 5] = c[k].y;
+      }
+    }
+  }
+  delete[] a; delete[] b; delete[] c; delete[] acc;
+  return rc;
+}
+
+static int32_t upload_source3(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n) {
+  const int32_t st = ensure3(h->d_s, &h->scap, n);
+  if (st != NDT_OK) return st;
+  const float* src[3] = {sx, sy, sz};
+  for (int a = 0; a < 3; ++a) HIP_TRY(hipMemcpyAsync(h->d_s[a], src[a], n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  return NDT_OK;
+}
+
+int32_t ndt3d_evaluate(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n,
+                       const double pose[6], ndt3d_eval* out) {
+  if (!h || !sx || !sy || !sz || !pose || !out || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  int32_t st = upload_source3(h, sx, sy, sz, n);
+  if (st != NDT_OK) return st;
+  st = run_align3(h, h->d_s[0], h->d_s[1], h->d_s[2], n, pose, 1);
+  if (st != NDT_OK) return st;
+  std::memset(out, 0, sizeof(*out));
+  unpack_h21(h->h_state->H, out->H);
+  for (int j = 0; j < 6; ++j) out->g[j] = h->h_state->g[j];
+  out->score = h->h_state->score;
+  out->n_hit = h->h_state->n_hit;
+  return NDT_OK;
+}
+
+int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                        const double init_pose[6], ndt3d_result* out) {
+  if (!h || !d_sx || !d_sy || !d_sz || !init_pose || !out) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = run_align3(h, d_sx, d_sy, d_sz, n, init_pose, -1);
+  if (st != NDT_OK) return st;
+  const ndt::IterState3& s = *h->h_state;
+  std::memset(out, 0, sizeof(*out));
+  for (int j = 0; j < 6; ++j) { out->pose[j] = s.pose[j]; out->g[j] = s.g[j]; }
+  unpack_h21(s.H, out->H);
+  out->score = s.score; out->iterations = s.iter; out->n_hit = s.n_hit; out->status = s.status;
+  return NDT_OK;
+}
+
+int32_t ndt3d_align(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n,
+                    const double init_pose[6], ndt3d_result* out) {
+  if (!h || !sx || !sy || !sz || !init_pose || !out || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = upload_source3(h, sx, sy, sz, n);
+  if (st != NDT_OK) return st;
+  return ndt3d_align_dev(h, h->d_s[0], h->d_s[1], h->d_s[2], n, init_pose, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,467 @@
+// 3D NDT SE(3) variant (BASELINE config 5).  Same structure as the
+// 2D path: exact fixed-point per-cell sums, one launch per Gauss-Newton iteration with the
+// reduction of the previous launch's block partials and the 6x6 solve in every workgroup's
+// prologue, kernel boundary as the only inter-workgroup synchronisation.
+// Pose = (tx, ty, tz, roll, pitch, yaw), R = Rz(yaw) Ry(pitch) Rx(roll); 21 + 6 + 2 = 29 sums.
+#pragma once
+#include "ndt2d_kernels.hpp"
+
+namespace ndt {
+
+constexpr int kNumAcc3 = 32;   // 29 used: Htt(6) Htr(9) Hrr(6) g(6) score nhit
+
+struct CellAcc3 {   // 88 B
+  long long s[3];
+  long long ss[6];   // xx xy xz yy yz zz
+  unsigned int n;
+  unsigned int pad;
+};
+
+struct Grid3Dev {
+  float ox, oy, oz, inv_c;
+  int W, H, D, pad;
+  double cell, fix_scale;
+  float4* recA;   // mean_x, mean_y, mean_z, n (0 = invalid)
+  float4* recB;   // Sigma^-1: xx xy xz yy
+  float2* recC;   //           yz zz
+  CellAcc3* acc;
+};
+
+struct IterState3 {
+  double pose[6];
+  double H[21];
+  double g[6];
+  double score;
+  int n_hit, iter, status, done, have_partials, pad;
+};   // 34 doubles + 6 ints = 296 B -> padded to 304 by alignment of the arrays below
+static_assert(sizeof(IterState3) % 8 == 0, "IterState3 is copied as 8-byte words");
+
+struct AlignStatic3 {
+  Grid3Dev grid;
+  SolveParams prm;
+};
+struct AlignCall3 {
+  const float* sx; const float* sy; const float* sz;
+  int n;
+  int fixed_iterations;
+};
+struct AlignDyn3 {
+  IterState3 state[2];
+  float partials[2][kNumAcc3][kMaxBlocks];
+};
+
+// ---------------------------------------------------------------------------- bounds
+__global__ __launch_bounds__(kBlock) void k_bounds3(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ z, size_t n,
+                                                     unsigned int* __restrict__ out /*[6]*/) {
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float p[3] = {x[i], y[i], z[i]};
+    if (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], p[a]); mx[a] = fmaxf(mx[a], p[a]); }
+    }
+  }
+  __shared__ float s_b[kBlock / 64][6];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]);
+    if ((threadIdx.x & 63) == 0) { s_b[wave][2 * a] = mn[a]; s_b[wave][2 * a + 1] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < 3; ++a) {
+      for (int w = 1; w < kBlock / 64; ++w) { mn[a] = fminf(mn[a], s_b[w][2 * a]); mx[a] = fmaxf(mx[a], s_b[w][2 * a + 1]); }
+      atomicMin(&out[2 * a], float_to_ordered(mn[a]));
+      atomicMax(&out[2 * a + 1], float_to_ordered(mx[a]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- accumulate
+__global__ __launch_bounds__(kBlock) void k_accumulate3(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, size_t n, Grid3Dev g) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float px = x[i], py = y[i], pz = z[i];
+    const float fx = (px - g.ox) * g.inv_c, fy = (py - g.oy) * g.inv_c, fz = (pz - g.oz) * g.inv_c;
+    const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H) & (fz >= 0.f) & (fz < (float)g.D);
+    if (in) {
+      const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+      const long long ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
+      const long long uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
+      const long long uz = fix_coord(pz, cell_centre(g.oz, iz, g.cell), g.fix_scale);
+      CellAcc3* c = g.acc + (((size_t)iz * g.H + iy) * g.W + ix);
+      atomicAdd(&c->n, 1u);
+      atomicAdd((unsigned long long*)&c->s[0], (unsigned long long)ux);
+      atomicAdd((unsigned long long*)&c->s[1], (unsigned long long)uy);
+      atomicAdd((unsigned long long*)&c->s[2], (unsigned long long)uz);
+      atomicAdd((unsigned long long*)&c->ss[0], (unsigned long long)(ux * ux));
+      atomicAdd((unsigned long long*)&c->ss[1], (unsigned long long)(ux * uy));
+      atomicAdd((unsigned long long*)&c->ss[2], (unsigned long long)(ux * uz));
+      atomicAdd((unsigned long long*)&c->ss[3], (unsigned long long)(uy * uy));
+      atomicAdd((unsigned long long*)&c->ss[4], (unsigned long long)(uy * uz));
+      atomicAdd((unsigned long long*)&c->ss[5], (unsigned long long)(uz * uz));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- finalise
+// Cyclic Jacobi, 6 sweeps over (0,1),(0,2),(1,2): oracle/ndt3d.py jacobi_eig3().
+__device__ __forceinline__ void jacobi_rot(double& app, double& aqq, double& apq, double& arp, double& arq,
+                                           double* vp, double* vq) {
+  if (fabs(apq) > 1e-300) {
+    const double tau = (aqq - app) / (2.0 * apq);
+    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+    app = app - t * apq;
+    aqq = aqq + t * apq;
+    apq = 0.0;
+    const double rp = arp, rq = arq;
+    arp = c * rp - s * rq;
+    arq = s * rp + c * rq;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double a = vp[i], b = vq[i];
+      vp[i] = c * a - s * b;
+      vq[i] = s * a + c * b;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_finalise3(Grid3Dev g, int min_points, double eig_ratio,
+                                                       int* __restrict__ counters) {
+  const size_t ncell = (size_t)g.W * g.H * g.D;
+  const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= ncell) return;
+  const CellAcc3 c = g.acc[k];
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 rc = make_float2(0.f, 0.f);
+  const int n = (int)c.n;
+  if (c.n > kMaxCellCount) atomicAdd(&counters[1], 1);
+  if (n >= min_points && n >= 2 && c.n <= kMaxCellCount) {
+    const unsigned int k32 = (unsigned int)k, w32 = (unsigned int)g.W, h32 = (unsigned int)g.H;
+    const int ix = (int)(k32 % w32), iy = (int)((k32 / w32) % h32), iz = (int)(k32 / (w32 * h32));
+    const double inv_s = 1.0 / g.fix_scale, dn = (double)n;
+    const double mx = fma((double)c.s[0] / dn, inv_s, cell_centre(g.ox, ix, g.cell));
+    const double my = fma((double)c.s[1] / dn, inv_s, cell_centre(g.oy, iy, g.cell));
+    const double mz = fma((double)c.s[2] / dn, inv_s, cell_centre(g.oz, iz, g.cell));
+    const double den = 1.0 / (dn * g.fix_scale * g.fix_scale * (dn - 1.0));
+    double axx = to_double(sub128(mul_s64(n, c.ss[0]), mul_s64(c.s[0], c.s[0]))) * den;
+    double axy = to_double(sub128(mul_s64(n, c.ss[1]), mul_s64(c.s[0], c.s[1]))) * den;
+    double axz = to_double(sub128(mul_s64(n, c.ss[2]), mul_s64(c.s[0], c.s[2]))) * den;
+    double ayy = to_double(sub128(mul_s64(n, c.ss[3]), mul_s64(c.s[1], c.s[1]))) * den;
+    double ayz = to_double(sub128(mul_s64(n, c.ss[4]), mul_s64(c.s[1], c.s[2]))) * den;
+    double azz = to_double(sub128(mul_s64(n, c.ss[5]), mul_s64(c.s[2], c.s[2]))) * den;
+    double v0[3] = {1, 0, 0}, v1[3] = {0, 1, 0}, v2[3] = {0, 0, 1};   // eigenvector columns
+    for (int sweep = 0; sweep < 6; ++sweep) {
+      jacobi_rot(axx, ayy, axy, axz, ayz, v0, v1);   // (p,q) = (0,1), r = 2
+      jacobi_rot(axx, azz, axz, axy, ayz, v0, v2);   // (0,2), r = 1
+      jacobi_rot(ayy, azz, ayz, axy, axz, v1, v2);   // (1,2), r = 0
+    }
+    const double lmax = fmax(axx, fmax(ayy, azz));
+    if (lmax > 0.0) {
+      const double lim = eig_ratio * lmax;
+      const double i0 = 1.0 / fmax(axx, lim), i1 = 1.0 / fmax(ayy, lim), i2 = 1.0 / fmax(azz, lim);
+      const double cxx = i0 * v0[0] * v0[0] + i1 * v1[0] * v1[0] + i2 * v2[0] * v2[0];
+      const double cxy = i0 * v0[0] * v0[1] + i1 * v1[0] * v1[1] + i2 * v2[0] * v2[1];
+      const double cxz = i0 * v0[0] * v0[2] + i1 * v1[0] * v1[2] + i2 * v2[0] * v2[2];
+      const double cyy = i0 * v0[1] * v0[1] + i1 * v1[1] * v1[1] + i2 * v2[1] * v2[1];
+      const double cyz = i0 * v0[1] * v0[2] + i1 * v1[1] * v1[2] + i2 * v2[1] * v2[2];
+      const double czz = i0 * v0[2] * v0[2] + i1 * v1[2] * v1[2] + i2 * v2[2] * v2[2];
+      ra = make_float4((float)mx, (float)my, (float)mz, (float)n);
+      rb = make_float4((float)cxx, (float)cxy, (float)cxz, (float)cyy);
+      rc = make_float2((float)cyz, (float)czz);
+      atomicAdd(&counters[0], 1);
+    }
+  }
+  g.recA[k] = ra;
+  g.recB[k] = rb;
+  g.recC[k] = rc;
+}
+
+// ---------------------------------------------------------------------------- solve (6x6)
+__device__ __forceinline__ bool solve6(const double* A /*6x6 row-major, symmetric*/, const double* g, double* x) {
+  double dg[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dg[i] = fmax(fabs(A[7 * i]), 1e-12);
+  double lam = 0.0;
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    double L[6][6], D[6], rD[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double p = A[7 * j] + lam * dg[j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) p -= L[j][k] * L[j][k] * D[k];
+      ok = ok && (p > 1e-12 * dg[j]);
+      D[j] = p;
+      rD[j] = fast_rcp(ok ? p : 1.0);
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        double a = A[6 * i + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) a -= L[i][k] * L[j][k] * D[k];
+        L[i][j] = a * rD[j];
+      }
+    }
+    if (ok) {
+      double z[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double a = -g[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) a -= L[i][k] * z[k];
+        z[i] = a;
+      }
+      bool fin = true;
+#pragma unroll
+      for (int i = 5; i >= 0; --i) {
+        double a = z[i] * rD[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) a -= L[k][i] * x[k];
+        x[i] = a;
+        fin = fin && isfinite(a);
+      }
+      if (fin) return true;
+    }
+    lam = (lam == 0.0) ? 1e-6 : lam * 10.0;
+  }
+  return false;
+}
+
+__device__ __forceinline__ bool gn_update3(double* pose, const double* A, const double* g, int n_hit, int& iter,
+                                           int& status, const SolveParams& p, int fixed_iterations) {
+  if (n_hit < p.min_hits) { status = 3; return true; }
+  double d[6];
+  if (!solve6(A, g, d)) { status = 2; return true; }
+  const double nt2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const double nr2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+  double alpha = 1.0;
+  if (nt2 > p.step_max_trans * p.step_max_trans) alpha = p.step_max_trans / sqrt(nt2);
+  if (nr2 * alpha * alpha > p.step_max_rot * p.step_max_rot) alpha = p.step_max_rot / sqrt(nr2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pose[i] += d[i] * alpha;
+#pragma unroll
+  for (int i = 3; i < 6; ++i) pose[i] = wrap_angle(pose[i] + d[i] * alpha);
+  iter += 1;
+  status = 0;
+  if (fixed_iterations > 0) return iter >= fixed_iterations;
+  if (nt2 * alpha * alpha < p.eps_trans * p.eps_trans && nr2 * alpha * alpha < p.eps_rot * p.eps_rot) return true;
+  if (iter >= p.max_iterations) { status = 1; return true; }
+  return false;
+}
+
+__global__ void k_begin3(AlignCall3* __restrict__ call, AlignDyn3* __restrict__ dyn, const float* sx,
+                         const float* sy, const float* sz, int n, double p0, double p1, double p2, double p3,
+                         double p4, double p5, int fixed_iterations) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  call->sx = sx; call->sy = sy; call->sz = sz;
+  call->n = n;
+  call->fixed_iterations = fixed_iterations;
+  IterState3 s = {};
+  s.pose[0] = p0; s.pose[1] = p1; s.pose[2] = p2;
+  s.pose[3] = wrap_angle(p3); s.pose[4] = wrap_angle(p4); s.pose[5] = wrap_angle(p5);
+  dyn->state[1] = s;
+  dyn->state[0] = IterState3{};
+}
+
+__device__ __forceinline__ void copy_state3(IterState3* dst, const IterState3* src, int have_partials) {
+  const unsigned long long* s8 = reinterpret_cast<const unsigned long long*>(src);
+  unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
+#pragma unroll
+  for (int j = 0; j < (int)(sizeof(IterState3) / 8); ++j) d8[j] = s8[j];
+  if (have_partials >= 0) dst->have_partials = have_partials;
+}
+
+// ---------------------------------------------------------------------------- iterate
+__global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restrict__ st,
+                                                      const AlignCall3* __restrict__ call,
+                                                      AlignDyn3* __restrict__ dyn, int parity) {
+  __shared__ double s_red[kNumAcc3];
+  __shared__ float s_wave[kBlock / 64][kNumAcc3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const IterState3* prev = &dyn->state[parity ^ 1];
+  IterState3* cur = &dyn->state[parity];
+  const bool writer = (blockIdx.x == 0) && (tid == 0);
+
+  double pose[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) pose[j] = prev->pose[j];
+  const int ps_iter = prev->iter, ps_done = prev->done, ps_have = prev->have_partials;
+  const SolveParams prm = st->prm;
+  const Grid3Dev G = st->grid;
+  const int n = call->n;
+  const int fixed_iterations = call->fixed_iterations;
+  const float* __restrict__ sx = call->sx;
+  const float* __restrict__ sy = call->sy;
+  const float* __restrict__ sz = call->sz;
+  float4 pv[8];
+  {
+    const float* part = &dyn->partials[parity ^ 1][0][0];
+#pragma unroll
+    for (int v = 0; v < 8; ++v)
+      pv[v] = *reinterpret_cast<const float4*>(part + (wave * 8 + v) * kMaxBlocks + lane * 4);
+  }
+  asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.oz), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.D), "s"(G.recA),
+               "s"(G.recB), "s"(G.recC), "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations),
+               "s"(prm.eps_trans), "s"(prm.eps_rot), "s"(prm.step_max_trans), "s"(prm.step_max_rot), "s"(ps_iter),
+               "s"(ps_done), "s"(ps_have), "s"(fixed_iterations));
+  const int stride = kMaxBlocks * kBlock;
+  int i = blockIdx.x * kBlock + tid;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
+
+  if (ps_done) {
+    if (writer) copy_state3(cur, prev, -1);
+    return;
+  }
+  int iter = ps_iter;
+  if (ps_have) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      double a = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
+      a = wave_sum_lane63(a);
+      if (lane == 63) s_red[wave * 8 + v] = a;
+    }
+    __syncthreads();
+    // 6x6 from the 21 packed sums: Htt(6) Htr(9) Hrr(6)
+    double A[36], g[6];
+    A[0] = s_red[0]; A[1] = s_red[1]; A[2] = s_red[2]; A[7] = s_red[3]; A[8] = s_red[4]; A[14] = s_red[5];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) A[6 * r + 3 + k] = s_red[6 + 3 * r + k];
+    A[21] = s_red[15]; A[22] = s_red[16]; A[23] = s_red[17]; A[28] = s_red[18]; A[29] = s_red[19]; A[35] = s_red[20];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < r; ++c) A[6 * r + c] = A[6 * c + r];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) g[j] = s_red[21 + j];
+    const double score = s_red[27];
+    const int n_hit = (int)(s_red[28] + 0.5);
+    int status = 0;
+    const bool done = gn_update3(pose, A, g, n_hit, iter, status, prm, fixed_iterations);
+    if (writer) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { cur->pose[j] = pose[j]; cur->g[j] = g[j]; }
+#pragma unroll
+      for (int j = 0; j < 21; ++j) cur->H[j] = s_red[j];
+      cur->score = score;
+      cur->n_hit = n_hit; cur->iter = iter; cur->status = status;
+      cur->done = done ? 1 : 0; cur->have_partials = 1; cur->pad = 0;
+    }
+    if (done) return;
+  } else if (writer) {
+    copy_state3(cur, prev, 1);
+  }
+
+  // rotation and its three derivative matrices, float64 -> float32
+  float R[9], Ra[9], Rb[9], Rg[9];
+  {
+    double sa, ca, sb, cb, sg, cg;
+    sincos_wrapped(pose[3], &sa, &ca);
+    sincos_wrapped(pose[4], &sb, &cb);
+    sincos_wrapped(pose[5], &sg, &cg);
+    // R = Rz Ry Rx
+    const double r00 = cg * cb, r01 = cg * sb * sa - sg * ca, r02 = cg * sb * ca + sg * sa;
+    const double r10 = sg * cb, r11 = sg * sb * sa + cg * ca, r12 = sg * sb * ca - cg * sa;
+    const double r20 = -sb, r21 = cb * sa, r22 = cb * ca;
+    R[0] = (float)r00; R[1] = (float)r01; R[2] = (float)r02; R[3] = (float)r10; R[4] = (float)r11; R[5] = (float)r12;
+    R[6] = (float)r20; R[7] = (float)r21; R[8] = (float)r22;
+    // d/droll: columns 1,2 rotate: dR[:,1] = R[:,2], dR[:,2] = -R[:,1], dR[:,0] = 0
+    Ra[0] = 0.f; Ra[1] = (float)r02; Ra[2] = (float)(-r01);
+    Ra[3] = 0.f; Ra[4] = (float)r12; Ra[5] = (float)(-r11);
+    Ra[6] = 0.f; Ra[7] = (float)r22; Ra[8] = (float)(-r21);
+    // d/dpitch = Rz dRy Rx
+    Rb[0] = (float)(-cg * sb); Rb[1] = (float)(cg * cb * sa); Rb[2] = (float)(cg * cb * ca);
+    Rb[3] = (float)(-sg * sb); Rb[4] = (float)(sg * cb * sa); Rb[5] = (float)(sg * cb * ca);
+    Rb[6] = (float)(-cb);      Rb[7] = (float)(-sb * sa);     Rb[8] = (float)(-sb * ca);
+    // d/dyaw: rows rotate: dR[0,:] = -R[1,:], dR[1,:] = R[0,:], dR[2,:] = 0
+    Rg[0] = (float)(-r10); Rg[1] = (float)(-r11); Rg[2] = (float)(-r12);
+    Rg[3] = (float)r00;    Rg[4] = (float)r01;    Rg[5] = (float)r02;
+    Rg[6] = 0.f; Rg[7] = 0.f; Rg[8] = 0.f;
+  }
+  const float tx = (float)pose[0], ty = (float)pose[1], tz = (float)pose[2];
+  const float fW = (float)G.W, fH = (float)G.H, fD = (float)G.D;
+  const float d1 = prm.d1, d2 = prm.d2;
+  const float nhd2 = -0.5f * d2 * 1.44269504088896340736f;
+
+  float acc[kNumAcc3];
+#pragma unroll
+  for (int j = 0; j < kNumAcc3; ++j) acc[j] = 0.f;
+
+  while (i < n) {
+    const int inext = i + stride;
+    float xn = 0.f, yn = 0.f, zn = 0.f;
+    if (inext < n) { xn = sx[inext]; yn = sy[inext]; zn = sz[inext]; }
+    float px = fmaf(R[0], x, fmaf(R[1], y, fmaf(R[2], z, tx)));
+    float py = fmaf(R[3], x, fmaf(R[4], y, fmaf(R[5], z, ty)));
+    float pz = fmaf(R[6], x, fmaf(R[7], y, fmaf(R[8], z, tz)));
+    const float fx = (px - G.ox) * G.inv_c, fy = (py - G.oy) * G.inv_c, fz = (pz - G.oz) * G.inv_c;
+    const bool in = (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
+    const int key = in ? (((int)fz * G.H + (int)fy) * G.W + (int)fx) : 0;
+    if (!in) { px = py = pz = 0.f; x = y = z = 0.f; }
+    const float4 A4 = G.recA[key];
+    const float4 B4 = G.recB[key];
+    const float2 C2 = G.recC[key];
+    const bool hit = in & (A4.w > 0.f);
+    const float qx = px - A4.x, qy = py - A4.y, qz = pz - A4.z;
+    const float cxx = B4.x, cxy = B4.y, cxz = B4.z, cyy = B4.w, cyz = C2.x, czz = C2.y;
+    const float vx = fmaf(cxx, qx, fmaf(cxy, qy, cxz * qz));
+    const float vy = fmaf(cxy, qx, fmaf(cyy, qy, cyz * qz));
+    const float vz = fmaf(cxz, qx, fmaf(cyz, qy, czz * qz));
+    const float m = fmaf(qx, vx, fmaf(qy, vy, qz * vz));
+    const float s = hit ? d1 * __builtin_amdgcn_exp2f(nhd2 * m) : 0.f;
+    const float w = s * d2;
+    float J[3][3], U[3][3];   // J[k] = dR_k p ; U[k] = Sigma^-1 J[k]
+    const float* Rd[3] = {Ra, Rb, Rg};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      J[k][0] = fmaf(Rd[k][0], x, fmaf(Rd[k][1], y, Rd[k][2] * z));
+      J[k][1] = fmaf(Rd[k][3], x, fmaf(Rd[k][4], y, Rd[k][5] * z));
+      J[k][2] = fmaf(Rd[k][6], x, fmaf(Rd[k][7], y, Rd[k][8] * z));
+      U[k][0] = fmaf(cxx, J[k][0], fmaf(cxy, J[k][1], cxz * J[k][2]));
+      U[k][1] = fmaf(cxy, J[k][0], fmaf(cyy, J[k][1], cyz * J[k][2]));
+      U[k][2] = fmaf(cxz, J[k][0], fmaf(cyz, J[k][1], czz * J[k][2]));
+    }
+    acc[0] = fmaf(w, cxx, acc[0]); acc[1] = fmaf(w, cxy, acc[1]); acc[2] = fmaf(w, cxz, acc[2]);
+    acc[3] = fmaf(w, cyy, acc[3]); acc[4] = fmaf(w, cyz, acc[4]); acc[5] = fmaf(w, czz, acc[5]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[6 + 3 * r + k] = fmaf(w, U[k][r], acc[6 + 3 * r + k]);
+    {
+      int q = 15;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = k; l < 3; ++l) {
+          const float h = fmaf(J[k][0], U[l][0], fmaf(J[k][1], U[l][1], J[k][2] * U[l][2]));
+          acc[q] = fmaf(w, h, acc[q]);
+          ++q;
+        }
+    }
+    acc[21] = fmaf(w, vx, acc[21]); acc[22] = fmaf(w, vy, acc[22]); acc[23] = fmaf(w, vz, acc[23]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      acc[24 + k] = fmaf(w, fmaf(vx, J[k][0], fmaf(vy, J[k][1], vz * J[k][2])), acc[24 + k]);
+    acc[27] += s;
+    acc[28] += hit ? 1.f : 0.f;
+    x = xn; y = yn; z = zn; i = inext;
+  }
+
+#pragma unroll
+  for (int j = 0; j < 29; ++j) {
+    const float r = wave_sum_lane63(acc[j]);
+    if (lane == 63) s_wave[wave][j] = r;
+  }
+  __syncthreads();
+  if (tid < kNumAcc3) {
+    const float r = tid < 29 ? ((s_wave[0][tid] + s_wave[1][tid]) + s_wave[2][tid]) + s_wave[3][tid] : 0.f;
+    dyn->partials[parity][tid][blockIdx.x] = r;
+  }
+}
+
+}  // namespace ndt

@@ -268,3 +268,96 @@ class NdtBatch2D:
         """float64 [n,18] device/host tensor -> list of AlignResult (synchronises)."""
         a = out_tensor.detach().cpu().numpy()
         return _results_from_bytes(np.ascontiguousarray(a).reshape(-1), a.shape[0])
+
+
+@dataclass
+class AlignResult3D:
+    pose: tuple            # (tx, ty, tz, roll, pitch, yaw), R = Rz(yaw) Ry(pitch) Rx(roll)
+    H: np.ndarray          # 6x6 Gauss-Newton Hessian of -score
+    g: np.ndarray
+    score: float
+    iterations: int
+    n_hit: int
+    status: int
+
+
+def default_params3d(**overrides) -> L.Params2D:
+    p = L.Params2D()
+    L.load().ndt3d_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(f"ndt3d_params has no field {k!r}")
+        setattr(p, k, v)
+    return p
+
+
+class NdtMatcher3D:
+    """3D SE(3) variant (BASELINE config 5); mirrors ndt3d_* of include/ndt_hip.h."""
+
+    def __init__(self, device: int = 0, **overrides):
+        self._lib = L.load()
+        self.params = default_params3d(**overrides)
+        h = C.c_void_p()
+        L.check(self._lib.ndt3d_create(C.byref(self.params), int(device), C.byref(h)), "ndt3d_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndt3d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_target(self, x, y, z):
+        x, y, z = _host_f32(x), _host_f32(y), _host_f32(z)
+        L.check(self._lib.ndt3d_set_target(self._h, x.ctypes.data, y.ctypes.data, z.ctypes.data, x.size),
+                "ndt3d_set_target")
+        return self.grid_info()
+
+    def grid_info(self) -> L.GridInfo3D:
+        info = L.GridInfo3D()
+        L.check(self._lib.ndt3d_get_grid_info(self._h, C.byref(info)), "ndt3d_get_grid_info")
+        return info
+
+    def grid(self):
+        info = self.grid_info()
+        nc = info.width * info.height * info.depth
+        count = np.zeros(nc, dtype=np.int32)
+        mean = np.zeros((nc, 3), dtype=np.float32)
+        icov = np.zeros((nc, 6), dtype=np.float32)
+        L.check(self._lib.ndt3d_get_grid(self._h, count.ctypes.data, mean.ctypes.data, icov.ctypes.data),
+                "ndt3d_get_grid")
+        return count, mean, icov
+
+    def evaluate(self, sx, sy, sz, pose):
+        sx, sy, sz = _host_f32(sx), _host_f32(sy), _host_f32(sz)
+        p = (C.c_double * 6)(*[float(v) for v in pose])
+        out = L.Eval3D()
+        L.check(self._lib.ndt3d_evaluate(self._h, sx.ctypes.data, sy.ctypes.data, sz.ctypes.data, sx.size, p,
+                                         C.byref(out)), "ndt3d_evaluate")
+        return (np.array(out.H, dtype=np.float64).reshape(6, 6), np.array(out.g, dtype=np.float64),
+                float(out.score), int(out.n_hit))
+
+    def align(self, sx, sy, sz, init_pose=(0.0,) * 6) -> AlignResult3D:
+        p = (C.c_double * 6)(*[float(v) for v in init_pose])
+        r = L.Result3D()
+        if _is_dev(sx):
+            n = sx.numel()
+            st = self._lib.ndt3d_align_dev(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), _dev_ptr(sz, n), n, p, C.byref(r))
+        else:
+            sx, sy, sz = _host_f32(sx), _host_f32(sy), _host_f32(sz)
+            st = self._lib.ndt3d_align(self._h, sx.ctypes.data, sy.ctypes.data, sz.ctypes.data, sx.size, p, C.byref(r))
+        L.check(st, "ndt3d_align")
+        return AlignResult3D(tuple(r.pose), np.array(r.H, dtype=np.float64).reshape(6, 6),
+                             np.array(r.g, dtype=np.float64), float(r.score), int(r.iterations), int(r.n_hit),
+                             int(r.status))

@@ -169,6 +169,49 @@ int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_
                               const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream);
 void* ndt2d_batch_stream(ndt2d_batch* b);
 
+/* ---- 3D NDT, SE(3) (BASELINE config 5) ----------------------- */
+/* Same pipeline in 3D: dense voxel grid with per-cell mean / 3x3 covariance (eigenvalue clamp
+ * by a fixed-sweep Jacobi), pose = (tx, ty, tz, roll, pitch, yaw) with R = Rz(yaw) Ry(pitch)
+ * Rx(roll), 6x6 Gauss-Newton Hessian, 6-vector gradient.  ndt3d_params has the layout and
+ * meaning of ndt2d_params; hessian_mode must be NDT_HESSIAN_GAUSS_NEWTON. */
+typedef ndt2d_params ndt3d_params;
+
+typedef struct ndt3d_result {
+  double pose[6];     /* tx ty tz roll pitch yaw                                  */
+  double H[36];       /* row-major 6x6 Gauss-Newton Hessian at the last evaluation */
+  double g[6];
+  double score;
+  int32_t iterations, n_hit, status, reserved;
+} ndt3d_result;
+
+typedef struct ndt3d_eval {
+  double H[36];
+  double g[6];
+  double score;
+  int32_t n_hit, reserved;
+} ndt3d_eval;
+
+typedef struct ndt3d_grid_info {
+  float ox, oy, oz, inv_cell;
+  int32_t width, height, depth;
+  int32_t n_valid;
+} ndt3d_grid_info;
+
+typedef struct ndt3d_handle ndt3d_handle;
+void ndt3d_default_params(ndt3d_params* p);   /* cell 1.0 m, min_points 5, step_max_trans 1.0, min_hits 6 */
+int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** out);
+int32_t ndt3d_destroy(ndt3d_handle* h);
+int32_t ndt3d_set_target(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n);
+int32_t ndt3d_get_grid_info(ndt3d_handle* h, ndt3d_grid_info* info);
+/* count [cells], mean [cells][3], icov [cells][6] (xx xy xz yy yz zz); any pointer may be NULL */
+int32_t ndt3d_get_grid(ndt3d_handle* h, int32_t* count, float* mean_xyz, float* icov6);
+int32_t ndt3d_evaluate(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n,
+                       const double pose[6], ndt3d_eval* out);
+int32_t ndt3d_align(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n,
+                    const double init_pose[6], ndt3d_result* out);
+int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                        const double init_pose[6], ndt3d_result* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,87 @@
+"""3D SE(3) variant on the GPU vs the CPU oracle (BASELINE config 5; parity unpinned: the
+oracle is this repo's own, the reference holds no code)."""
+import numpy as np
+import pytest
+
+from gtsam_ndt_amd import synth3d
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small():
+    from oracle import ndt3d as o
+    d = synth3d.make_pair3d(n_elev=32, n_azim=512)
+    prm = o.Ndt3Params()
+    return d, prm, o.build_grid3(d["tx"], d["ty"], d["tz"], prm)
+
+
+def test_grid3d_parity(gpu_lib, small):
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    d, prm, g = small
+    with NdtMatcher3D() as m:
+        info = m.set_target(d["tx"], d["ty"], d["tz"])
+        assert (info.width, info.height, info.depth) == g.dims and info.n_valid == g.n_valid
+        assert (info.ox, info.oy, info.oz) == tuple(g.o)
+        count, mean, icov = m.grid()
+    np.testing.assert_array_equal(count.astype(np.int64), g.count)          # bit-exact integer work
+    v = g.valid
+    np.testing.assert_array_equal(icov[:, 0] != 0, v)
+    np.testing.assert_allclose(mean[v], g.mean[v], rtol=0, atol=4e-6)
+    nrm = np.linalg.norm(g.icov[v], axis=1, keepdims=True)
+    assert np.max(np.abs(icov[v] - g.icov[v]) / nrm) < 2e-5
+
+
+def test_evaluate3d_parity(gpu_lib, small):
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    from oracle import ndt3d as o
+    d, prm, g = small
+    with NdtMatcher3D() as m:
+        m.set_target(d["tx"], d["ty"], d["tz"])
+        for pose in (d["init"], d["pose"]):
+            H, gr, s, nh = m.evaluate(d["sx"], d["sy"], d["sz"], pose)
+            Hm, gm, sm, nm = o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose, prm, mirror32=True)
+            Ht, gt, st, nt = o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose, prm)
+            assert abs(nh - nm) <= 3 and abs(nh - nt) <= 5
+            sc = np.sqrt(np.outer(np.diag(Hm), np.diag(Hm)))
+            assert np.max(np.abs(H - Hm) / sc) < 2e-4
+            assert abs(s - sm) / sm < 2e-4 and abs(s - st) / st < 5e-3
+            gs = np.sqrt(np.diag(Hm) * sm)
+            assert np.max(np.abs(gr - gm) / gs) < 1e-3
+
+
+def test_align3d_converged_pose_parity(gpu_lib, small):
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    from oracle import ndt3d as o
+    d, prm, g = small
+    ref = o.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm)
+    with NdtMatcher3D() as m:
+        m.set_target(d["tx"], d["ty"], d["tz"])
+        r = m.align(d["sx"], d["sy"], d["sz"], d["init"])
+        r2 = m.align(d["sx"], d["sy"], d["sz"], d["init"])
+    assert r.status == 0 == ref["status"]
+    e = np.abs(np.array(r.pose) - np.array(ref["pose"]))
+    assert e[:3].max() < 1e-4 and e[3:].max() < 1e-4             # BASELINE.json: 1e-4 m / 1e-4 rad
+    assert abs(r.iterations - ref["iterations"]) <= 3
+    assert r.pose == r2.pose and np.array_equal(r.H, r2.H)        # deterministic
+
+
+def test_align3d_full_config5(gpu_lib):
+    """The full 64 x 2048 = 131072-point pair of BASELINE config 5."""
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    from oracle import ndt3d as o
+    d = synth3d.make_pair3d()
+    prm = o.Ndt3Params(fixed_iterations=10)
+    ref = o.align3(o.build_grid3(d["tx"], d["ty"], d["tz"], prm), d["sx"], d["sy"], d["sz"], d["init"], prm)
+    with NdtMatcher3D(fixed_iterations=10) as m:
+        m.set_target(d["tx"], d["ty"], d["tz"])
+        r = m.align(d["sx"], d["sy"], d["sz"], d["init"])
+    assert r.iterations == 10
+    e = np.abs(np.array(r.pose) - np.array(ref["pose"]))
+    assert e[:3].max() < 1e-4 and e[3:].max() < 1e-4
+    with NdtMatcher3D() as m:
+        m.set_target(d["tx"], d["ty"], d["tz"])
+        r = m.align(d["sx"], d["sy"], d["sz"], d["init"])
+    assert r.status == 0
+    e = np.abs(np.array(r.pose) - np.array(d["pose"]))
+    assert e[:3].max() < 5e-3 and e[3:].max() < 1e-3             # recovers the generating pose

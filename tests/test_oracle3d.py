@@ -1,0 +1,70 @@
+"""Self-validation of the 3D oracle (parity unpinned: no reference code exists)."""
+import numpy as np
+import pytest
+
+from gtsam_ndt_amd import synth3d
+from oracle import ndt3d as o
+
+
+@pytest.fixture(scope="module")
+def small():
+    d = synth3d.make_pair3d(n_elev=32, n_azim=512)
+    prm = o.Ndt3Params()
+    return d, prm, o.build_grid3(d["tx"], d["ty"], d["tz"], prm)
+
+
+def test_jacobi_matches_lapack():
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(200, 3, 3))
+    S = A @ A.transpose(0, 2, 1) * rng.uniform(1e-4, 10.0, size=(200, 1, 1))
+    S[:20] = np.einsum("ni,nj->nij", A[:20, 0], A[:20, 0])         # rank one
+    lam, V = o.jacobi_eig3(S)
+    rec = np.einsum("nik,nk,njk->nij", V, lam, V)
+    assert np.abs(rec - S).max() < 1e-12 * np.abs(S).max()
+    assert np.abs(np.sort(lam, axis=1) - np.linalg.eigvalsh(S)).max() < 1e-11 * np.abs(S).max()
+    assert np.abs(np.einsum("nki,nkj->nij", V, V) - np.eye(3)).max() < 1e-12
+
+
+def test_rotation_derivatives():
+    ang = np.array([0.3, -0.2, 0.7])
+    R, Ra, Rb, Rg = o.rot_and_derivs(*ang)
+    assert np.allclose(R, synth3d.rotation(*ang)) and np.allclose(R @ R.T, np.eye(3))
+    h = 1e-6
+    for k, D in enumerate((Ra, Rb, Rg)):
+        e = np.zeros(3); e[k] = h
+        fd = (o.rot_and_derivs(*(ang + e))[0] - o.rot_and_derivs(*(ang - e))[0]) / (2 * h)
+        assert np.allclose(D, fd, atol=1e-9)
+
+
+def test_gradient_matches_finite_differences(small):
+    d, prm, g = small
+    pose = np.array(d["pose"]) + np.array([0.01, -0.01, 0.005, 0.001, -0.001, 0.002])
+    H, gr, s, n = o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose, prm)
+    h = 1e-7
+    fd = np.zeros(6)
+    for k in range(6):
+        e = np.zeros(6); e[k] = h
+        sp = o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose + e, prm)
+        sm = o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose - e, prm)
+        fd[k] = -(sp[2] - sm[2]) / (2 * h)
+    assert np.allclose(gr, fd, rtol=1e-4, atol=1e-5 * np.abs(gr).max())
+    assert np.allclose(H, H.T) and np.all(np.linalg.eigvalsh(H) > 0)
+
+
+def test_solve_ldl_matches_numpy():
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        A = rng.normal(size=(6, 6)); H = A @ A.T + 1e-3 * np.eye(6); g = rng.normal(size=6)
+        d, ok = o.solve_ldl(H, g)
+        assert ok and np.allclose(d, np.linalg.solve(H, -g), rtol=1e-8, atol=1e-11)
+    assert not o.solve_ldl(np.full((6, 6), np.nan), np.ones(6))[1]
+
+
+def test_known_transform_recovery(small):
+    d, prm, g = small
+    r = o.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm)
+    assert r["status"] == 0
+    e = np.abs(np.array(r["pose"]) - np.array(d["pose"]))
+    assert e[:3].max() < 2e-2 and e[3:].max() < 3e-3
+    m = o.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm, mirror32=True)
+    assert np.abs(np.array(m["pose"]) - np.array(r["pose"])).max() < 1e-4
