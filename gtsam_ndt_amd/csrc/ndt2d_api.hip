@@ -140,7 +140,7 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
     g.recA = nullptr; g.recB = nullptr; g.acc = nullptr; h->cell_capacity = 0;
     const size_t want = ncell + ncell / 8;
     HIP_TRY(hipMalloc((void**)&g.recA, want * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&g.recB, want * sizeof(float2)));
+    HIP_TRY(hipMalloc((void**)&g.recB, want * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc)));
     h->cell_capacity = want;
   }
@@ -438,12 +438,12 @@ int32_t ndt2d_get_grid(ndt2d_handle* h, int32_t* count, float* mean_xy, float* i
   HIP_TRY(hipSetDevice(h->device));
   const size_t ncell = (size_t)h->grid.W * h->grid.H;
   float4* a = new (std::nothrow) float4[ncell];
-  float2* b = new (std::nothrow) float2[ncell];
+  float4* b = new (std::nothrow) float4[ncell];
   CellAcc* acc = count ? new (std::nothrow) CellAcc[ncell] : nullptr;
   int32_t rc = NDT_OK;
   if (!a || !b || (count && !acc)) rc = NDT_ERR_ALLOC;
   if (rc == NDT_OK && hipMemcpyAsync(a, h->grid.recA, ncell * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
-  if (rc == NDT_OK && hipMemcpyAsync(b, h->grid.recB, ncell * sizeof(float2), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (rc == NDT_OK && hipMemcpyAsync(b, h->grid.recB, ncell * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
   if (rc == NDT_OK && acc && hipMemcpyAsync(acc, h->grid.acc, ncell * sizeof(CellAcc), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
   if (rc == NDT_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = NDT_ERR_HIP;
   if (rc == NDT_OK) {
@@ -451,10 +451,10 @@ int32_t ndt2d_get_grid(ndt2d_handle* h, int32_t* count, float* mean_xy, float* i
       if (count) count[k] = (int32_t)acc[k].n;
       if (mean_xy) { mean_xy[2 * k] = a[k].x; mean_xy[2 * k + 1] = a[k].y; }
       if (icov_abc) {
-        const bool valid = b[k].y > 0.f;
+        const bool valid = b[k].z > 0.f;
         icov_abc[3 * k] = valid ? a[k].z : 0.f;
         icov_abc[3 * k + 1] = valid ? a[k].w : 0.f;
-        icov_abc[3 * k + 2] = valid ? b[k].x : 0.f;
+        icov_abc[3 * k + 2] = valid ? b[k].y : 0.f;
       }
     }
   } else if (rc == NDT_ERR_HIP) {

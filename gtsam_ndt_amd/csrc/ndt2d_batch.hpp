@@ -14,11 +14,18 @@
 
 namespace ndt {
 
-constexpr int kBatchThreads = 1024;
+#ifndef NDT_BATCH_THREADS
+#define NDT_BATCH_THREADS 1024
+#endif
+#ifndef NDT_BATCH_UNROLL
+#define NDT_BATCH_UNROLL 2
+#endif
+constexpr int kBatchThreads = NDT_BATCH_THREADS;
 constexpr int kBatchWaves = kBatchThreads / 64;
 constexpr int kBatchMaxCells = 16384;   // dense index table: e.g. 128 x 128 cells
 constexpr int kBatchMaxSlots = 2304;    // cells with n >= min_points (<= 3 per thread at finalise)
-constexpr int kBatchUnroll = 4;         // source points in flight per thread
+constexpr int kBatchUnroll = NDT_BATCH_UNROLL;   // source points per thread and register set
+constexpr int kBatchSlotsPerThread = (kBatchMaxSlots + kBatchThreads - 1) / kBatchThreads;
 
 struct ResultDev {   // layout of ndt2d_result (include/ndt_hip.h); static_assert in the API file
   double pose[3];
@@ -49,15 +56,14 @@ constexpr int kLdsSlotN = kLdsIdx + kBatchMaxCells * 2;               // u32 [Ma
 constexpr int kLdsSlotKey = kLdsSlotN + kBatchMaxSlots * 4;           // u16 [MaxSlots]
 constexpr int kLdsSums = kLdsSlotKey + kBatchMaxSlots * 2;            // u64 [5][MaxSlots]; aliases:
                                                                       //   u32 cnt[MaxCells] (build)
-                                                                      //   float4 recA[MaxSlots], float2 recB[MaxSlots]
+                                                                      //   float4 recA[MaxSlots], float4 recB[MaxSlots]
 constexpr int kLdsRed = kLdsSums + 5 * kBatchMaxSlots * 8;            // float [Waves][kNumAcc]
 constexpr int kLdsBc = kLdsRed + kBatchWaves * kNumAcc * 4;           // double [16] broadcast
 constexpr int kLdsMisc = kLdsBc + 16 * 8;                             // int [16]
 constexpr int kLdsScan = kLdsMisc + 16 * 4;                           // int [Waves]
 constexpr int kBatchLdsBytes = kLdsScan + kBatchWaves * 4;
 static_assert(kBatchMaxCells * 4 <= 5 * kBatchMaxSlots * 8, "cnt must fit in the sums region");
-static_assert(kBatchMaxSlots * 24 <= 5 * kBatchMaxSlots * 8, "records must fit in the sums region");
-static_assert(kBatchMaxSlots <= 3 * kBatchThreads, "finalise keeps at most 3 slots per thread in registers");
+static_assert(kBatchMaxSlots * 32 <= 5 * kBatchMaxSlots * 8, "records must fit in the sums region");
 static_assert(kBatchLdsBytes <= 160 * 1024, "CDNA4 LDS is 160 KiB per CU");
 static_assert((kLdsSlotN % 16) == 0 && (kLdsSlotKey % 16) == 0 && (kLdsSums % 16) == 0 && (kLdsRed % 16) == 0 &&
               (kLdsBc % 16) == 0 && (kLdsMisc % 16) == 0, "16-byte aligned carve");
@@ -96,24 +102,32 @@ __device__ __forceinline__ void write_result(ResultDev* o, const double* pose, c
   o->iterations = iter; o->n_hit = n_hit; o->status = status; o->reserved = 0;
 }
 
-// a4 with the record served from LDS: dense index table -> slot -> (recA, recB)
+// a4 with the record served from LDS: dense index table -> slot -> 32-byte record
 __device__ __forceinline__ void lookup_point_lds(const PoseF& P, const unsigned short* __restrict__ idx,
                                                  const float4* __restrict__ recA,
-                                                 const float2* __restrict__ recB, float x, float y, bool live,
+                                                 const float4* __restrict__ recB, float x, float y, bool live,
                                                  PointRec& r) {
-  float px = fmaf(P.cs, x, fmaf(-P.sn, y, P.tx));
-  float py = fmaf(P.sn, x, fmaf(P.cs, y, P.ty));
-  const float fx = (px - P.ox) * P.inv_c;
-  const float fy = (py - P.oy) * P.inv_c;
-  const bool in = live & (fx >= 0.f) & (fx < P.fW) & (fy >= 0.f) & (fy < P.fH);
-  const int key = in ? ((int)fy * P.W + (int)fx) : 0;
-  const int slot = idx[key];                       // unconditional read: no exec-mask branch
-  const bool hit = in & (slot > 0);
-  if (!in) { px = 0.f; py = 0.f; x = 0.f; y = 0.f; }
-  r.x = x; r.y = y; r.px = px; r.py = py; r.in = hit;
-  const int s = hit ? slot - 1 : 0;
+  const int key = point_key(P, x, y, live, r);
+#if defined(NDT_BATCH_ABLATE) && (NDT_BATCH_ABLATE & 1)      // tools/exp_batch.hip only: no LDS traffic
+  r.hit = key > 0;
+  r.A = make_float4(r.p.x - 0.01f, r.p.y + 0.01f, 900.f, 30.f);
+  r.B = make_float4(30.f, 800.f, 9.f, 0.f);
+#else
+  const int slot = idx[key];                       // guard cells and empty cells hold 0
+  r.hit = slot > 0;
+  const int s = max(slot - 1, 0);
   r.A = recA[s];
   r.B = recB[s];
+#endif
+}
+
+__device__ __forceinline__ float uniformf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffull));
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 constexpr int kStatusCapacity = -5;   // NDT_ERR_CAPACITY: pair needs the global-memory path
@@ -129,7 +143,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
   unsigned long long* sums = reinterpret_cast<unsigned long long*>(smem + kLdsSums);
   unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + kLdsSums);
   float4* recA = reinterpret_cast<float4*>(smem + kLdsSums);
-  float2* recB = reinterpret_cast<float2*>(smem + kLdsSums + kBatchMaxSlots * 16);
+  float4* recB = reinterpret_cast<float4*>(smem + kLdsSums + kBatchMaxSlots * 16);
   float* red = reinterpret_cast<float*>(smem + kLdsRed);
   double* bc = reinterpret_cast<double*>(smem + kLdsBc);
   int* misc = reinterpret_cast<int*>(smem + kLdsMisc);
@@ -138,8 +152,11 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
   const int minpts = a.min_points < 2 ? 2 : a.min_points;
   const double zero6[6] = {0, 0, 0, 0, 0, 0};
   {
-    const unsigned long long t0 = a.toff[pair], s0 = a.soff[pair];
-    const int nt = (int)(a.toff[pair + 1] - t0), ns = (int)(a.soff[pair + 1] - s0);
+    // offsets and sizes are wave-uniform: keep them (and the cloud base pointers) in SGPRs so
+    // that every point load is `saddr + 32-bit voffset` instead of a 64-bit VGPR address
+    const unsigned long long t0 = uniform64(a.toff[pair]), s0 = uniform64(a.soff[pair]);
+    const int nt = __builtin_amdgcn_readfirstlane((int)(a.toff[pair + 1] - t0));
+    const int ns = __builtin_amdgcn_readfirstlane((int)(a.soff[pair + 1] - s0));
     const float* __restrict__ tx = a.tx + t0;
     const float* __restrict__ ty = a.ty + t0;
     const float* __restrict__ sx = a.sx + s0;
@@ -189,7 +206,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     }
     const int W = __builtin_amdgcn_readfirstlane(misc[1]), Hh = __builtin_amdgcn_readfirstlane(misc[2]);
     int status = __builtin_amdgcn_readfirstlane(misc[3]);
-    const float ox = reinterpret_cast<float*>(misc)[4], oy = reinterpret_cast<float*>(misc)[5];
+    const float ox = uniformf(reinterpret_cast<float*>(misc)[4]), oy = uniformf(reinterpret_cast<float*>(misc)[5]);
     const float inv_c = (float)(1.0 / a.cell);
     const float fW = (float)W, fH = (float)Hh;
     const int ncell = W * Hh;
@@ -263,14 +280,13 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
 
     // ---- a3: finalise (<= 3 slots per thread held in registers, then overwrite the sums)
     {
-      float4 ra[3];
-      float2 rb[3];
+      float4 ra[kBatchSlotsPerThread], rb[kBatchSlotsPerThread];
       int nvalid = 0;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < kBatchSlotsPerThread; ++j) {
         const int sl = tid + j * kBatchThreads;
         ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rb[j] = make_float2(0.f, 0.f);
+        rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (sl < nslot) {
           const int key = slot_key[sl];
           const int n = (int)slot_n[sl];
@@ -286,7 +302,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       }
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < kBatchSlotsPerThread; ++j) {
         const int sl = tid + j * kBatchThreads;
         if (sl < nslot) { recA[sl] = ra[j]; recB[sl] = rb[j]; }
       }
@@ -307,32 +323,52 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     __syncthreads();
     for (;;) {
       float acc[kNumAcc];
-#pragma unroll
-      for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.f;
       {
         double sn_d, cs_d;
         sincos_wrapped(pose[2], &sn_d, &cs_d);
-        const float d1 = a.prm.d1, d2 = a.prm.d2;
-        const PoseF P = {(float)cs_d, (float)sn_d, (float)pose[0], (float)pose[1], ox, oy, inv_c, fW, fH, W,
-                         d1, d2, -0.5f * d2 * 1.44269504088896340736f};
-        // kBatchUnroll points in flight per thread; every load of a wave is 256 contiguous bytes
-        for (int i = tid; i < ns; i += kBatchUnroll * kBatchThreads) {
-          float x[kBatchUnroll], y[kBatchUnroll];
-          bool live[kBatchUnroll];
+        // the pose is the same in every lane: SGPRs, not 13 VGPRs held across the point loop
+        const PoseF P = make_pose(uniformf((float)cs_d), uniformf((float)sn_d), uniformf((float)pose[0]),
+                                  uniformf((float)pose[1]), ox, oy, inv_c, W, Hh, a.prm.d1, a.prm.d2);
+        Acc2D A;
+        acc_zero(A);
+        // Software-pipelined source stream: two register sets (a, b) of kBatchUnroll points each;
+        // while one set is consumed the other set's loads are in flight.  No register copies
+        // between trips (a copy is a use and would put the wait right behind the loads).
+        // Every load of a wave is 256 contiguous bytes; lanes past the end re-read the last
+        // point and are masked by `live`.
+        constexpr int kTrip = kBatchUnroll * kBatchThreads;
+        float xa[kBatchUnroll], ya[kBatchUnroll], xb[kBatchUnroll], yb[kBatchUnroll];
+        auto load_set = [&](int base, float* xs, float* ys) {
 #pragma unroll
           for (int u = 0; u < kBatchUnroll; ++u) {
-            const int ii = i + u * kBatchThreads;
-            live[u] = ii < ns;
-            const int ic = live[u] ? ii : ns - 1;     // clamped, always a valid address: no branch
-            x[u] = sx[ic];
-            y[u] = sy[ic];
+            const int ii = base + u * kBatchThreads;
+            const int ic = ii < ns ? ii : ns - 1;
+#if defined(NDT_BATCH_ABLATE) && (NDT_BATCH_ABLATE & 2)      // tools only: no global point loads
+            xs[u] = (float)(ic & 1023) * 0.04f - 20.f;
+            ys[u] = (float)(ic >> 10) * 0.4f - 20.f;
+#else
+            xs[u] = sx[ic];
+            ys[u] = sy[ic];
+#endif
           }
+        };
+        auto consume_set = [&](int base, const float* xs, const float* ys) {
           PointRec r[kBatchUnroll];
 #pragma unroll
-          for (int u = 0; u < kBatchUnroll; ++u) lookup_point_lds(P, idx, recA, recB, x[u], y[u], live[u], r[u]);
+          for (int u = 0; u < kBatchUnroll; ++u)
+            lookup_point_lds(P, idx, recA, recB, xs[u], ys[u], (base + u * kBatchThreads) < ns, r[u]);
 #pragma unroll
-          for (int u = 0; u < kBatchUnroll; ++u) accumulate_point<MODE>(P, r[u], acc);
+          for (int u = 0; u < kBatchUnroll; ++u) accumulate_point<MODE>(P, r[u], A);
+        };
+        load_set(tid, xa, ya);
+        for (int i = tid; i < ns; i += 2 * kTrip) {
+          load_set(i + kTrip, xb, yb);
+          consume_set(i, xa, ya);
+          load_set(i + 2 * kTrip, xa, ya);
+          if (i + kTrip < ns) consume_set(i + kTrip, xb, yb);     // wave-uniform except at the tail
         }
+        acc_store(A, acc);
+        acc[11] = 0.f;
       }
 #pragma unroll
       for (int j = 0; j < kNumAcc - 1; ++j) {

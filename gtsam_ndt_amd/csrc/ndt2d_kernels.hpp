@@ -34,8 +34,8 @@ struct GridDev {
   int W, H;
   double cell;       // params.cell_size
   double fix_scale;  // 2^kFixShift / cell
-  float4* recA;      // (mean_x, mean_y, a, b)
-  float2* recB;      // (c, n as float; 0 = invalid)
+  float4* recA;      // (mean_x, mean_y, a, b)      one 32-byte record per cell, laid out so that
+  float4* recB;      // (b, c, n as float, 0)       (a,b) and (b,c) are both register pairs
   CellAcc* acc;
 };
 
@@ -128,9 +128,9 @@ __device__ __forceinline__ long long fix_coord(float p, double centre, double fi
 // Returns false (record zeroed) when the cell is not usable.
 __device__ __forceinline__ bool finalise_sums(int n, long long sx, long long sy, long long sxx, long long sxy,
                                               long long syy, double cx, double cy, double fix_scale,
-                                              int min_points, double eig_ratio, float4& ra, float2& rb) {
+                                              int min_points, double eig_ratio, float4& ra, float4& rb) {
   ra = make_float4(0.f, 0.f, 0.f, 0.f);
-  rb = make_float2(0.f, 0.f);
+  rb = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n < min_points || n < 2) return false;
   const double inv_s = 1.0 / fix_scale;
   const double dn = (double)n;
@@ -155,8 +155,9 @@ __device__ __forceinline__ bool finalise_sums(int n, long long sx, long long sy,
   const double nrm = sqrt(fma(ex, ex, ey * ey));
   if (nrm > 0.0) { ex /= nrm; ey /= nrm; } else { ex = 1.0; ey = 0.0; }
   const double i1 = 1.0 / l1, i2 = 1.0 / l2c, d = i1 - i2;
-  ra = make_float4((float)mx, (float)my, (float)fma(d * ex, ex, i2), (float)(d * ex * ey));
-  rb = make_float2((float)fma(d * ey, ey, i2), (float)n);
+  const float b32 = (float)(d * ex * ey);
+  ra = make_float4((float)mx, (float)my, (float)fma(d * ex, ex, i2), b32);
+  rb = make_float4(b32, (float)fma(d * ey, ey, i2), (float)n, 0.f);
   return true;
 }
 
@@ -202,13 +203,12 @@ __global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, 
   const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= ncell) return;
   const CellAcc c = g.acc[k];
-  float4 ra;
-  float2 rb;
+  float4 ra, rb;
   bool ok = false;
   if (c.n > kMaxCellCount) {
     atomicAdd(&counters[1], 1);
     ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    rb = make_float2(0.f, 0.f);
+    rb = make_float4(0.f, 0.f, 0.f, 0.f);
   } else if ((int)c.n >= min_points) {             // empty cells (the vast majority) skip everything
     const unsigned int k32 = (unsigned int)k, w32 = (unsigned int)g.W;   // ncell <= 2^27: 32-bit div
     const int ix = (int)(k32 % w32), iy = (int)(k32 / w32);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, 
                        cell_centre(g.oy, iy, g.cell), g.fix_scale, min_points, eig_ratio, ra, rb);
   } else {
     ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    rb = make_float2(0.f, 0.f);
+    rb = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (ok) atomicAdd(&counters[0], 1);
   g.recA[k] = ra;
@@ -340,70 +340,153 @@ __global__ void k_begin(AlignCall* __restrict__ call, AlignDyn* __restrict__ dyn
 }
 
 // ---- per-point pieces of the body (rows a4-a6) ------------------------------------------
+// The 2D math is written on (x, y) register pairs so that it issues as packed-f32 VALU
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes-worth of f32 per instruction); the
+// loop-closure kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 90 % of SIMD cycles), so
+// instructions per point are its cost.  Per-element arithmetic is unchanged: every packed
+// fma is the same fmaf(a, b, c) the contract names.
+#ifndef NDT_POINT_PACKED
+#define NDT_POINT_PACKED 0     // 1: issue the (x,y) math as v_pk_*_f32 on register pairs.  Measured
+#endif                         //    slower on gfx950 (packed f32 runs at half rate there), so off.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float a) { return (v2f){a, a}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 struct PoseF {
-  float cs, sn, tx, ty, ox, oy, inv_c, fW, fH;
-  int W;
+  v2f c0;      // (cos, sin)        p' = c0*x + (c1*y + t)
+  v2f c1;      // (-sin, cos)
+  v2f t;       // (tx, ty)
+  v2f o;       // grid origin
+  v2f j1;      // (-cos, -sin)      dR/dtheta p = c1*x + j1*y
+  float inv_c;
+  int W, wm1, hm1;
   float d1, d2, nhd2;
 };
+__device__ __forceinline__ PoseF make_pose(float cs, float sn, float tx, float ty, float ox, float oy, float inv_c,
+                                           int W, int H, float d1, float d2) {
+  PoseF P;
+  P.c0 = (v2f){cs, sn}; P.c1 = (v2f){-sn, cs}; P.t = (v2f){tx, ty}; P.o = (v2f){ox, oy}; P.j1 = (v2f){-cs, -sn};
+  P.inv_c = inv_c; P.W = W; P.wm1 = W - 1; P.hm1 = H - 1;
+  P.d1 = d1; P.d2 = d2; P.nhd2 = -0.5f * d2 * 1.44269504088896340736f;   // exp(-d2/2 m) = exp2(nhd2*m)
+  return P;
+}
+
 struct PointRec {
-  float x, y, px, py;   // source point (zeroed when it misses the grid) and its image
-  float4 A;             // mean_x, mean_y, a, b
-  float2 B;             // c, n
-  bool in;
+  v2f xy;      // source point (non-finite coordinates clamped to +-1e15)
+  v2f p;       // its image R p + t
+  float4 A;    // mean_x, mean_y, a, b
+  float4 B;    // b, c, n, 0
+  bool hit;    // set by the LDS lookup; the global lookup leaves validity to B.z
 };
 
-// a4: transform + cell key + record gather (loads only; nothing is consumed here)
+// a4 (1/2): transform and cell key.  No in-grid compare chain: the key is clamped onto the grid,
+// whose outermost ring of cells is empty by construction (one guard cell below the minimum,
+// one above the maximum), so every out-of-range, infinite or NaN point lands on an invalid
+// cell.  NaN/inf never reach the sums: coordinates are clamped to +-1e15 first (v_med3_f32
+// returns the finite bound for a NaN), which keeps every later product finite.
+__device__ __forceinline__ int point_key(const PoseF& P, float x, float y, bool live, PointRec& r) {
+  x = __builtin_amdgcn_fmed3f(x, -1e15f, 1e15f);
+  y = __builtin_amdgcn_fmed3f(y, -1e15f, 1e15f);
+  r.xy = (v2f){x, y};
+#if NDT_POINT_PACKED
+  r.p = fma2(P.c0, splat2(x), fma2(P.c1, splat2(y), P.t));
+  const v2f f = (r.p - P.o) * splat2(P.inv_c);
+#else
+  r.p.x = fmaf(P.c0.x, x, fmaf(P.c1.x, y, P.t.x));
+  r.p.y = fmaf(P.c0.y, x, fmaf(P.c1.y, y, P.t.y));
+  const v2f f = (v2f){(r.p.x - P.o.x) * P.inv_c, (r.p.y - P.o.y) * P.inv_c};
+#endif
+  int ix = __float2int_rd(f.x), iy = __float2int_rd(f.y);       // floor; saturating
+  ix = min(max(ix, 0), P.wm1);
+  iy = min(max(iy, 0), P.hm1);
+  return live ? iy * P.W + ix : 0;                                // cell 0 is a guard cell
+}
+
+// a4 (2/2), global-memory grid: one 32-byte record per cell
 __device__ __forceinline__ void lookup_point(const PoseF& P, const float4* __restrict__ recA,
-                                             const float2* __restrict__ recB, float x, float y, bool live,
+                                             const float4* __restrict__ recB, float x, float y, bool live,
                                              PointRec& r) {
-  float px = fmaf(P.cs, x, fmaf(-P.sn, y, P.tx));
-  float py = fmaf(P.sn, x, fmaf(P.cs, y, P.ty));
-  const float fx = (px - P.ox) * P.inv_c;
-  const float fy = (py - P.oy) * P.inv_c;
-  const bool in = live & (fx >= 0.f) & (fx < P.fW) & (fy >= 0.f) & (fy < P.fH);   // false for NaN/inf
-  const int key = in ? ((int)fy * P.W + (int)fx) : 0;
-  if (!in) { px = 0.f; py = 0.f; x = 0.f; y = 0.f; }   // keep 0*NaN out of the sums
-  r.x = x; r.y = y; r.px = px; r.py = py; r.in = in;
+  const int key = point_key(P, x, y, live, r);
   r.A = recA[key];
   r.B = recB[key];
+  r.hit = true;
+}
+
+struct Acc2D {   // the 11 running sums of one thread
+  v2f h01;       // Hxx Hxy
+  v2f h34;       // Hxt Hyt
+  v2f g01;       // gx gy
+  float h2, h5, g2, s, n;   // Hyy Htt gt score hits
+};
+__device__ __forceinline__ void acc_zero(Acc2D& a) {
+  a.h01 = a.h34 = a.g01 = splat2(0.f);
+  a.h2 = a.h5 = a.g2 = a.s = a.n = 0.f;
+}
+__device__ __forceinline__ void acc_store(const Acc2D& a, float* out /*[11]*/) {
+  out[0] = a.h01.x; out[1] = a.h01.y; out[2] = a.h2; out[3] = a.h34.x; out[4] = a.h34.y; out[5] = a.h5;
+  out[6] = a.g01.x; out[7] = a.g01.y; out[8] = a.g2; out[9] = a.s; out[10] = a.n;
 }
 
 // a5+a6: Mahalanobis score, SE(2) Jacobian, gradient / Hessian terms into the thread's sums
 template <int MODE>
-__device__ __forceinline__ void accumulate_point(const PoseF& P, const PointRec& r, float* acc) {
-  const bool hit = r.in & (r.B.y > 0.f);
-  const float qx = r.px - r.A.x, qy = r.py - r.A.y;
-  const float a = r.A.z, b = r.A.w, c = r.B.x;
-  const float vx = fmaf(a, qx, b * qy);
-  const float vy = fmaf(b, qx, c * qy);
+__device__ __forceinline__ void accumulate_point(const PoseF& P, const PointRec& r, Acc2D& acc) {
+  const bool hit = r.hit & (r.B.z > 0.f);
+#if NDT_POINT_PACKED
+  const v2f mu = (v2f){r.A.x, r.A.y}, ab = (v2f){r.A.z, r.A.w}, bc = (v2f){r.B.x, r.B.y};
+  const v2f q = r.p - mu;
+  const v2f v = fma2(ab, splat2(q.x), bc * splat2(q.y));          // Sigma^-1 q
+  const v2f qv = q * v;
+  const float m = qv.x + qv.y;
+#else
+  const float a = r.A.z, b = r.A.w, c = r.B.y;
+  const float qx = r.p.x - r.A.x, qy = r.p.y - r.A.y;
+  const float vx = fmaf(a, qx, b * qy), vy = fmaf(b, qx, c * qy);
   const float m = fmaf(qx, vx, qy * vy);
+  const v2f v = (v2f){vx, vy};
+#endif
+#if defined(NDT_BATCH_ABLATE) && (NDT_BATCH_ABLATE & 4)      // tools only: no transcendental
+  const float s = hit ? P.d1 * (1.f + P.nhd2 * m) : 0.f;
+#else
   const float s = hit ? P.d1 * __builtin_amdgcn_exp2f(P.nhd2 * m) : 0.f;
+#endif
   const float w = s * P.d2;
-  const float jx = fmaf(-P.sn, r.x, -P.cs * r.y);
-  const float jy = fmaf(P.cs, r.x, -P.sn * r.y);
+#if NDT_POINT_PACKED
+  const v2f j = fma2(P.c1, splat2(r.xy.x), P.j1 * splat2(r.xy.y));   // dR/dtheta p
+  const v2f vj = v * j;
+  const float vt = vj.x + vj.y;
+  const v2f u = fma2(ab, splat2(j.x), bc * splat2(j.y));          // Sigma^-1 j
+  const v2f ju = j * u;
+  v2f h01 = ab, h34 = u;
+  float hyy = bc.y, htt = ju.x + ju.y;
+#else
+  const float jx = fmaf(P.c1.x, r.xy.x, P.j1.x * r.xy.y), jy = fmaf(P.c1.y, r.xy.x, P.j1.y * r.xy.y);
   const float vt = fmaf(vx, jx, vy * jy);
-  const float ux = fmaf(a, jx, b * jy);
-  const float uy = fmaf(b, jx, c * jy);
-  float hxx = a, hxy = b, hyy = c, hxt = ux, hyt = uy, htt = fmaf(jx, ux, jy * uy);
+  const float ux = fmaf(a, jx, b * jy), uy = fmaf(b, jx, c * jy);
+  const v2f j = (v2f){jx, jy};
+  v2f h01 = (v2f){a, b}, h34 = (v2f){ux, uy};
+  float hyy = c, htt = fmaf(jx, ux, jy * uy);
+#endif
   if (MODE == 1) {   // full Newton Hessian (Biber / Magnusson)
-    hxx = fmaf(-P.d2 * vx, vx, hxx);
-    hxy = fmaf(-P.d2 * vx, vy, hxy);
-    hyy = fmaf(-P.d2 * vy, vy, hyy);
-    hxt = fmaf(-P.d2 * vx, vt, hxt);
-    hyt = fmaf(-P.d2 * vy, vt, hyt);
-    htt = fmaf(-P.d2 * vt, vt, htt) + fmaf(vy, jx, -vx * jy);
+    h01 = fma2(splat2(-P.d2 * v.x), v, h01);
+    hyy = fmaf(-P.d2 * v.y, v.y, hyy);
+    h34 = fma2(splat2(-P.d2 * vt), v, h34);
+    htt = fmaf(-P.d2 * vt, vt, htt) + fmaf(v.y, j.x, -v.x * j.y);
   }
-  acc[0] = fmaf(w, hxx, acc[0]);
-  acc[1] = fmaf(w, hxy, acc[1]);
-  acc[2] = fmaf(w, hyy, acc[2]);
-  acc[3] = fmaf(w, hxt, acc[3]);
-  acc[4] = fmaf(w, hyt, acc[4]);
-  acc[5] = fmaf(w, htt, acc[5]);
-  acc[6] = fmaf(w, vx, acc[6]);
-  acc[7] = fmaf(w, vy, acc[7]);
-  acc[8] = fmaf(w, vt, acc[8]);
-  acc[9] += s;
-  acc[10] += hit ? 1.f : 0.f;
+#if NDT_POINT_PACKED
+  const v2f w2 = splat2(w);
+  acc.h01 = fma2(w2, h01, acc.h01);
+  acc.h34 = fma2(w2, h34, acc.h34);
+  acc.g01 = fma2(w2, v, acc.g01);
+#else
+  acc.h01.x = fmaf(w, h01.x, acc.h01.x); acc.h01.y = fmaf(w, h01.y, acc.h01.y);
+  acc.h34.x = fmaf(w, h34.x, acc.h34.x); acc.h34.y = fmaf(w, h34.y, acc.h34.y);
+  acc.g01.x = fmaf(w, v.x, acc.g01.x);   acc.g01.y = fmaf(w, v.y, acc.g01.y);
+#endif
+  acc.h2 = fmaf(w, hyy, acc.h2);
+  acc.h5 = fmaf(w, htt, acc.h5);
+  acc.g2 = fmaf(w, vt, acc.g2);
+  acc.s += s;
+  acc.n += hit ? 1.f : 0.f;
 }
 
 // 128-byte state copy without a struct temporary (a by-value IterState lands in scratch)
@@ -524,20 +607,12 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restric
   // ---- body: per-point terms at `pose`
   double sn_d, cs_d;
   sincos_wrapped(pose[2], &sn_d, &cs_d);
-  const float cs = (float)cs_d, sn = (float)sn_d;
-  const float tx = (float)pose[0], ty = (float)pose[1];
-  const float ox = G.ox, oy = G.oy, inv_c = G.inv_c;
-  const int W = G.W, Hh = G.H;
-  const float fW = (float)W, fH = (float)Hh;
   const float4* __restrict__ recA = G.recA;
-  const float2* __restrict__ recB = G.recB;
-  const float d1 = prm.d1, d2 = prm.d2;
-  const float nhd2 = -0.5f * d2 * 1.44269504088896340736f;   // exp(-d2/2 m) = exp2(nhd2*m)
-
-  float acc[kNumAcc];
-#pragma unroll
-  for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.f;
-  const PoseF P = {cs, sn, tx, ty, ox, oy, inv_c, fW, fH, W, d1, d2, nhd2};
+  const float4* __restrict__ recB = G.recB;
+  const PoseF P = make_pose((float)cs_d, (float)sn_d, (float)pose[0], (float)pose[1], G.ox, G.oy, G.inv_c, G.W,
+                            G.H, prm.d1, prm.d2);
+  Acc2D A;
+  acc_zero(A);
 
   // two points in flight per thread: both gathers are issued before either is consumed
   while (!(EXP & 2) && i < n) {
@@ -549,10 +624,13 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restric
     const bool two = (i + stride) < n;
     lookup_point(P, recA, recB, x, y, true, r0);
     lookup_point(P, recA, recB, x1, y1, two, r1);
-    accumulate_point<MODE>(P, r0, acc);
-    accumulate_point<MODE>(P, r1, acc);
+    accumulate_point<MODE>(P, r0, A);
+    accumulate_point<MODE>(P, r1, A);
     x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
   }
+  float acc[kNumAcc];
+  acc_store(A, acc);
+  acc[11] = 0.f;
 
   // ---- epilogue: wave tree -> LDS -> one partial row per block
   if (EXP & 4) {

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
   g.cell = 0.5; g.cell32 = 0.5f; g.inv_c = 2.f; g.ox = -101.f; g.oy = -101.f; g.W = 404; g.H = 404;
   g.fix_scale = std::ldexp(1.0, kFixShift) / 0.5;
   const size_t nc = (size_t)g.W * g.H;
-  CK(hipMalloc(&g.recA, nc * sizeof(float4))); CK(hipMalloc(&g.recB, nc * sizeof(float2))); CK(hipMalloc(&g.acc, nc * sizeof(CellAcc)));
+  CK(hipMalloc(&g.recA, nc * sizeof(float4))); CK(hipMalloc(&g.recB, nc * sizeof(float4))); CK(hipMalloc(&g.acc, nc * sizeof(CellAcc)));
   CK(hipMemset(g.acc, 0, nc * sizeof(CellAcc)));
   int* d_cnt; CK(hipMalloc(&d_cnt, 8)); CK(hipMemset(d_cnt, 0, 8));
   hipStream_t st; CK(hipStreamCreate(&st));
