@@ -51,5 +51,29 @@ def main():
     print(path, os.path.getsize(path), "bytes;", r["iterations"], "iterations; pose", r["pose"])
 
 
+def main3d():
+    """tests/golden/ndt3d_small.npz: a 16 x 256-beam (4096-point) pair of the config-5 scene."""
+    from gtsam_ndt_amd import synth3d
+    from oracle import ndt3d as o3
+    d = synth3d.make_pair3d(n_elev=16, n_azim=256)
+    prm = o3.Ndt3Params()
+    g = o3.build_grid3(d["tx"], d["ty"], d["tz"], prm)
+    r = o3.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm)
+    k5 = o3.align3(g, d["sx"], d["sy"], d["sz"], d["init"], o3.Ndt3Params(fixed_iterations=5))
+    ev = o3.evaluate3(g, d["sx"], d["sy"], d["sz"], d["pose"], prm)
+    out = {k: d[k] for k in ("tx", "ty", "tz", "sx", "sy", "sz")}
+    out.update({"init": np.array(d["init"]), "true_pose": np.array(d["pose"]),
+                "grid_geom": np.array([*map(float, g.o), float(g.inv_c), *g.dims, g.n_valid], dtype=np.float64),
+                "grid_count": g.count.astype(np.int32), "grid_mean": g.mean, "grid_icov": g.icov,
+                "grid_valid": g.valid, "final_pose": np.array(r["pose"]),
+                "final_iterations": np.int32(r["iterations"]), "final_status": np.int32(r["status"]),
+                "fixed5_pose": np.array(k5["pose"]), "eval_H": ev[0], "eval_g": ev[1],
+                "eval_score": np.float64(ev[2]), "eval_n_hit": np.int32(ev[3])})
+    path = os.path.join(ROOT, "tests", "golden", "ndt3d_small.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes;", r["iterations"], "iterations; pose", r["pose"])
+
+
 if __name__ == "__main__":
     main()
+    main3d()

@@ -74,3 +74,40 @@ def test_hip_path_matches_golden(gold, gpu_lib):
         m.set_target(gold["tx"], gold["ty"])
         r = m.align(gold["sx"], gold["sy"], tuple(gold["init"]))
         assert r.iterations == 5 and np.abs(np.array(r.pose) - gold["fixed5_pose"]).max() < 1e-4
+
+
+GOLD3 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ndt3d_small.npz")
+
+
+def test_oracle3d_reproduces_golden():
+    from oracle import ndt3d as o3
+    g3 = np.load(GOLD3)
+    prm = o3.Ndt3Params()
+    g = o3.build_grid3(g3["tx"], g3["ty"], g3["tz"], prm)
+    assert [*map(float, g.o), float(g.inv_c), *g.dims, g.n_valid] == list(g3["grid_geom"])
+    np.testing.assert_array_equal(g.count, g3["grid_count"])
+    np.testing.assert_array_equal(g.valid, g3["grid_valid"])
+    np.testing.assert_allclose(g.icov, g3["grid_icov"], rtol=1e-9, atol=1e-9 * np.abs(g3["grid_icov"]).max())
+    r = o3.align3(g, g3["sx"], g3["sy"], g3["sz"], tuple(g3["init"]), prm)
+    assert r["iterations"] == int(g3["final_iterations"]) and r["status"] == int(g3["final_status"])
+    np.testing.assert_allclose(r["pose"], g3["final_pose"], rtol=0, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_hip_3d_matches_golden(gpu_lib):
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    g3 = np.load(GOLD3)
+    with NdtMatcher3D() as m:
+        info = m.set_target(g3["tx"], g3["ty"], g3["tz"])
+        assert [info.ox, info.oy, info.oz, info.inv_cell, info.width, info.height, info.depth, info.n_valid] == list(g3["grid_geom"])
+        count, mean, icov = m.grid()
+        np.testing.assert_array_equal(count, g3["grid_count"])
+        H, g, s, nh = m.evaluate(g3["sx"], g3["sy"], g3["sz"], tuple(g3["true_pose"]))
+        assert abs(nh - int(g3["eval_n_hit"])) <= 3 and abs(s - float(g3["eval_score"])) / float(g3["eval_score"]) < 5e-3
+        r = m.align(g3["sx"], g3["sy"], g3["sz"], tuple(g3["init"]))
+    e = np.abs(np.array(r.pose) - g3["final_pose"])
+    assert r.status == int(g3["final_status"]) and e[:3].max() < 1e-4 and e[3:].max() < 1e-4
+    with NdtMatcher3D(fixed_iterations=5) as m:
+        m.set_target(g3["tx"], g3["ty"], g3["tz"])
+        r = m.align(g3["sx"], g3["sy"], g3["sz"], tuple(g3["init"]))
+    assert r.iterations == 5 and np.abs(np.array(r.pose) - g3["fixed5_pose"]).max() < 1e-4
