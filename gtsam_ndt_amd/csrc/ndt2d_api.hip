@@ -319,6 +319,30 @@ int32_t ndt_device_count(void) {
   return n;
 }
 
+int32_t ndt_magnusson_constants(double outlier_ratio, double cell_size, int32_t dim, double* d1, double* d2) {
+  if (!d1 || !d2 || !(outlier_ratio > 0.0) || !(outlier_ratio < 1.0) || !(cell_size > 0.0) || (dim != 2 && dim != 3))
+    return NDT_ERR_INVALID_ARG;
+  const double c1 = 10.0 * (1.0 - outlier_ratio);
+  const double c2 = outlier_ratio / std::pow(cell_size, (double)dim);
+  const double d3 = -std::log(c2);
+  const double md1 = -std::log(c1 + c2) - d3;                      // Magnusson's d1 (negative)
+  const double md2 = -2.0 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / md1);
+  if (!std::isfinite(md1) || !std::isfinite(md2) || !(md1 < 0.0) || !(md2 > 0.0)) return NDT_ERR_INVALID_ARG;
+  *d1 = -md1;
+  *d2 = md2;
+  return NDT_OK;
+}
+
+int32_t ndt2d_polar_to_points_dev(const float* d_ranges, size_t n, double angle_min, double angle_inc,
+                                  double range_min, double range_max, float* d_x, float* d_y, void* stream) {
+  if (!d_ranges || !d_x || !d_y || n == 0 || !std::isfinite(angle_min) || !std::isfinite(angle_inc))
+    return NDT_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_polar_to_points, dim3(stream_blocks(n)), dim3(kBlock), 0, (hipStream_t)stream, d_ranges, n,
+                     angle_min, angle_inc, (float)range_min, (float)range_max, d_x, d_y);
+  HIP_TRY(hipGetLastError());
+  return NDT_OK;
+}
+
 void ndt2d_default_params(ndt2d_params* p) {
   if (!p) return;
   std::memset(p, 0, sizeof(*p));

@@ -651,4 +651,20 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restric
   }
 }
 
+// ------------------------------------------------------------- scan format (section 8f rank 4)
+// Range/bearing -> Cartesian SoA.  One sincos per beam from the beam index (no accumulated
+// angle error); invalid returns become NaN points, which every kernel above ignores.
+__global__ __launch_bounds__(kBlock) void k_polar_to_points(const float* __restrict__ r, size_t n, double angle_min,
+                                                             double angle_inc, float range_min, float range_max,
+                                                             float* __restrict__ x, float* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float ri = r[i];
+    double s, c;
+    sincos(fma((double)i, angle_inc, angle_min), &s, &c);
+    const bool ok = isfinite(ri) & (ri >= range_min) & (ri <= range_max);
+    x[i] = ok ? (float)((double)ri * c) : NAN;
+    y[i] = ok ? (float)((double)ri * s) : NAN;
+  }
+}
+
 }  // namespace ndt

@@ -361,3 +361,70 @@ class NdtMatcher3D:
         return AlignResult3D(tuple(r.pose), np.array(r.H, dtype=np.float64).reshape(6, 6),
                              np.array(r.g, dtype=np.float64), float(r.score), int(r.iterations), int(r.n_hit),
                              int(r.status))
+
+
+def magnusson_constants(outlier_ratio: float, cell_size: float, dim: int = 2):
+    """(d1, d2) of Magnusson's outlier-mixture score for ndt2d_params / ndt3d_params."""
+    d1, d2 = C.c_double(), C.c_double()
+    L.check(L.load().ndt_magnusson_constants(float(outlier_ratio), float(cell_size), int(dim), C.byref(d1), C.byref(d2)),
+            "ndt_magnusson_constants")
+    return d1.value, d2.value
+
+
+def polar_to_points(ranges, angle_min: float, angle_inc: float, range_min: float = 0.0, range_max: float = 1e30):
+    """Range/bearing scan (torch CUDA float32 tensor) -> (x, y) CUDA tensors, on the device."""
+    import torch
+    n = ranges.numel()
+    x = torch.empty(n, dtype=torch.float32, device=ranges.device)
+    y = torch.empty(n, dtype=torch.float32, device=ranges.device)
+    L.check(L.load().ndt2d_polar_to_points_dev(_dev_ptr(ranges, n), n, float(angle_min), float(angle_inc),
+                                               float(range_min), float(range_max), _dev_ptr(x, n), _dev_ptr(y, n),
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            "ndt2d_polar_to_points_dev")
+    return x, y
+
+
+# Coarse-to-fine schedule relative to the finest cell: (cell multiplier, eig_ratio).  Coarse
+# levels widen the Gaussians (larger cells AND a larger eigenvalue floor) so that alignments
+# started outside the fine grid's ~0.2-cell basin still converge (SURVEY.md section 8f rank 3).
+PYRAMID_LEVELS = ((4.0, 0.1), (2.0, 0.03))
+
+
+class NdtPyramid2D:
+    """Multi-resolution alignment: one NdtMatcher2D per level, each level started from the
+    previous level's pose; the last level runs with the caller's parameters."""
+
+    def __init__(self, device: int = 0, levels=PYRAMID_LEVELS, **overrides):
+        fine = default_params(**overrides)
+        self.levels = []
+        for mult, er in levels:
+            kw = dict(overrides)
+            kw.update(cell_size=fine.cell_size * mult, eig_ratio=er, eps_trans=1e-3, eps_rot=1e-4,
+                      max_iterations=30, fixed_iterations=0, step_max_trans=fine.step_max_trans * mult)
+            self.levels.append(NdtMatcher2D(device, **kw))
+        self.levels.append(NdtMatcher2D(device, **overrides))
+
+    def close(self):
+        for m in self.levels:
+            m.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_target(self, x, y):
+        return [m.set_target(x, y) for m in self.levels][-1]
+
+    def align(self, sx, sy, init_pose=(0.0, 0.0, 0.0)) -> AlignResult:
+        pose, total = tuple(init_pose), 0
+        r = None
+        for m in self.levels:
+            r = m.align(sx, sy, pose)
+            total += r.iterations
+            if r.status not in (L.NDT_OK, L.NDT_NOT_CONVERGED):
+                break
+            pose = r.pose
+        r.iterations = total
+        return r

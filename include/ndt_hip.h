@@ -148,6 +148,20 @@ int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out);
 /* hipStream_t the handle enqueues on (as void*), for event timing by the caller */
 void* ndt2d_stream(ndt2d_handle* h);
 
+/* ---- either side of the path --------------------------- */
+/* Magnusson's outlier-mixture score constants (PhD thesis 2009, eq. 6.8-6.10) expressed as the
+ * d1, d2 of ndt2d_params: with c1 = 10(1 - p_o), c2 = p_o / cell^dim, d3 = -ln c2,
+ * d1 = -ln(c1 + c2) - d3, d2 = -2 ln((-ln(c1 e^-1/2 + c2) - d3) / d1).  The library maximises
+ * sum d1' exp(-d2/2 m) with d1' = -d1 > 0, which is what is returned in *d1.  dim is 2 or 3. */
+int32_t ndt_magnusson_constants(double outlier_ratio, double cell_size, int32_t dim, double* d1, double* d2);
+
+/* Range/bearing scan -> SoA Cartesian points on the device (the driver side of the boundary):
+ * x[i] = r[i] cos(angle_min + i*angle_inc), y likewise; ranges outside [range_min, range_max]
+ * or non-finite become NaN points, which every entry point of this library ignores.
+ * All pointers are device pointers; asynchronous on `stream` (NULL = default stream). */
+int32_t ndt2d_polar_to_points_dev(const float* d_ranges, size_t n, double angle_min, double angle_inc,
+                                  double range_min, double range_max, float* d_x, float* d_y, void* stream);
+
 /* ---- loop-closure candidate batch (BASELINE config 4) -------------- */
 /* Independent scan pairs, aligned concurrently: one persistent workgroup per CU pulls pairs
  * from a queue, builds the pair's target grid in LDS and runs its whole Gauss-Newton loop on

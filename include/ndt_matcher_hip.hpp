@@ -117,6 +117,47 @@ class NdtMatcherHip {
   ndt2d_handle* h_ = nullptr;
 };
 
+// Coarse-to-fine alignment: levels of (cell multiplier, eig_ratio)
+// above the caller's finest grid widen the convergence basin; each level starts from the
+// previous level's pose and the last level runs with the caller's parameters.
+class NdtPyramidHip {
+ public:
+  struct Level { double cell_mult, eig_ratio; };
+  explicit NdtPyramidHip(const ndt2d_params& fine = NdtMatcherHip::defaultParams(), int device = 0,
+                         std::vector<Level> coarse = {{4.0, 0.1}, {2.0, 0.03}}) {
+    for (const Level& l : coarse) {
+      ndt2d_params p = fine;
+      p.cell_size = fine.cell_size * l.cell_mult;
+      p.eig_ratio = l.eig_ratio;
+      p.eps_trans = 1e-3; p.eps_rot = 1e-4; p.max_iterations = 30; p.fixed_iterations = 0;
+      p.step_max_trans = fine.step_max_trans * l.cell_mult;
+      levels_.emplace_back(new NdtMatcherHip(p, device));
+    }
+    levels_.emplace_back(new NdtMatcherHip(fine, device));
+  }
+  ~NdtPyramidHip() { for (NdtMatcherHip* m : levels_) delete m; }
+  NdtPyramidHip(const NdtPyramidHip&) = delete;
+  NdtPyramidHip& operator=(const NdtPyramidHip&) = delete;
+
+  void setTarget(const float* x, const float* y, size_t n) { for (NdtMatcherHip* m : levels_) m->setTarget(x, y, n); }
+  MatchResult align(const float* sx, const float* sy, size_t n, const Pose2& guess = Pose2()) {
+    Pose2 pose = guess;
+    MatchResult r;
+    int total = 0;
+    for (NdtMatcherHip* m : levels_) {
+      r = m->align(sx, sy, n, pose);
+      total += r.iterations;
+      if (r.status != NDT_OK && r.status != NDT_NOT_CONVERGED) break;
+      pose = r.pose;
+    }
+    r.iterations = total;
+    return r;
+  }
+
+ private:
+  std::vector<NdtMatcherHip*> levels_;
+};
+
 // Loop-closure candidates: many independent pairs in one call.
 class NdtBatchHip {
  public:

@@ -1,0 +1,91 @@
+"""Rows either side of the hot path: Magnusson score constants, the
+range/bearing -> Cartesian kernel, and the coarse-to-fine pyramid."""
+import math
+
+import numpy as np
+import pytest
+
+from gtsam_ndt_amd import synth
+
+
+def test_magnusson_constants_formula(ndt_lib):
+    from gtsam_ndt_amd.matcher import magnusson_constants
+    from gtsam_ndt_amd import _lib as L
+    import ctypes as C
+    for p_o, c, dim in ((0.55, 1.0, 3), (0.3, 0.5, 2), (0.1, 2.0, 3)):
+        c1 = 10.0 * (1.0 - p_o); c2 = p_o / c ** dim; d3 = -math.log(c2)
+        md1 = -math.log(c1 + c2) - d3
+        md2 = -2.0 * math.log((-math.log(c1 * math.exp(-0.5) + c2) - d3) / md1)
+        d1, d2 = magnusson_constants(p_o, c, dim)
+        assert abs(d1 + md1) < 1e-12 and abs(d2 - md2) < 1e-12 and d1 > 0 and d2 > 0
+    d1, d2 = C.c_double(), C.c_double()
+    assert ndt_lib.ndt_magnusson_constants(1.5, 1.0, 3, C.byref(d1), C.byref(d2)) == L.NDT_ERR_INVALID_ARG
+    assert ndt_lib.ndt_magnusson_constants(0.5, 1.0, 4, C.byref(d1), C.byref(d2)) == L.NDT_ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_polar_to_points_kernel(gpu_lib):
+    import torch
+    from gtsam_ndt_amd.matcher import polar_to_points
+    n = 100_003
+    rng = np.random.default_rng(0)
+    r = rng.uniform(0.05, 30.0, n).astype(np.float32)
+    r[::97] = np.inf; r[5::101] = np.nan; r[7::103] = 0.01; r[9::107] = 99.0
+    a0, da = -math.pi, 2 * math.pi / n
+    x, y = polar_to_points(torch.from_numpy(r).cuda(), a0, da, 0.05, 30.0)
+    x, y = x.cpu().numpy(), y.cpu().numpy()
+    ang = a0 + np.arange(n) * da
+    ok = np.isfinite(r) & (r >= 0.05) & (r <= 30.0)
+    assert np.array_equal(np.isnan(x), ~ok) and np.array_equal(np.isnan(y), ~ok)
+    np.testing.assert_allclose(x[ok], (r[ok].astype(np.float64) * np.cos(ang[ok])).astype(np.float32), rtol=0, atol=4e-6)
+    np.testing.assert_allclose(y[ok], (r[ok].astype(np.float64) * np.sin(ang[ok])).astype(np.float32), rtol=0, atol=4e-6)
+
+
+@pytest.mark.gpu
+def test_magnusson_score_aligns_like_oracle(gpu_lib):
+    """d1, d2 from the mixture constants flow through kernels and oracle alike."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D, magnusson_constants
+    from oracle import ndt2d as o
+    d = synth.make_pair(2, n_tgt=30000, n_src=30000)
+    d1, d2 = magnusson_constants(0.3, 0.5, 2)
+    prm = o.NdtParams(d1=d1, d2=d2)
+    ref = o.align(o.build_grid(d["tx"], d["ty"], prm), d["sx"], d["sy"], d["init"], prm)
+    with NdtMatcher2D(d1=d1, d2=d2) as m:
+        m.set_target(d["tx"], d["ty"])
+        r = m.align(d["sx"], d["sy"], d["init"])
+    assert r.status == 0 == ref["status"]
+    assert np.abs(np.array(r.pose) - np.array(ref["pose"])).max() < 1e-4
+    assert abs(r.score - ref["score"]) / ref["score"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_pyramid_widens_the_basin(gpu_lib):
+    """From a 0.3 m / 0.05 rad offset the 0.5 m grid alone does not converge; the coarse-to-fine
+    pyramid does, to the pose the oracle's pyramid reaches."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D, NdtPyramid2D, PYRAMID_LEVELS
+    from oracle import ndt2d as o
+    sc = synth.room_scene(2, 50.0, -25.0, -25.0)
+    xt, yt = synth.sample_scene(sc, 60000, 2 * 7919 + 11, 0.03)
+    xs, ys = synth.sample_scene(sc, 60000, 2 * 7919 + 12, 0.03)
+    pose = (0.30, -0.20, 0.05)
+    xs, ys = synth.to_source_frame(xs, ys, pose)
+    f = lambda a: a.astype(np.float32)
+    xt, yt, xs, ys = map(f, (xt, yt, xs, ys))
+    with NdtMatcher2D() as m:
+        m.set_target(xt, yt)
+        single = m.align(xs, ys, (0, 0, 0))
+    assert single.status != 0 or np.abs(np.array(single.pose) - np.array(pose)).max() > 5e-3
+    with NdtPyramid2D() as p:
+        p.set_target(xt, yt)
+        r = p.align(xs, ys, (0, 0, 0))
+    assert r.status == 0 and np.abs(np.array(r.pose) - np.array(pose)).max() < 3e-3
+    # the oracle running the same schedule
+    cur = (0.0, 0.0, 0.0)
+    for mult, er in PYRAMID_LEVELS:
+        prm = o.NdtParams(cell_size=0.5 * mult, eig_ratio=er, eps_trans=1e-3, eps_rot=1e-4, max_iterations=30,
+                          step_max_trans=0.5 * mult)
+        cur = o.align(o.build_grid(xt, yt, prm), xs, ys, cur, prm)["pose"]
+    prm = o.NdtParams()
+    ref = o.align(o.build_grid(xt, yt, prm), xs, ys, cur, prm)
+    assert ref["status"] == 0
+    assert np.abs(np.array(r.pose) - np.array(ref["pose"])).max() < 1e-4
