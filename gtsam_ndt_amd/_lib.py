@@ -147,6 +147,12 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The NDT matcher has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.  If this library
+    # pulled in the system copy first, a later `import torch` would find "No HIP GPUs", so
+    # when torch is installed let it load its runtime before we resolve ours against it.
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -51,6 +51,10 @@ struct ndt2d_handle {
 namespace {
 
 constexpr size_t kMaxCells = (size_t)1 << 27;
+#ifndef NDT_ITER_THREADS
+#define NDT_ITER_THREADS 256
+#endif
+constexpr int kIterThreads = NDT_ITER_THREADS;   // workgroup size of k_iterate (256 workgroups always)
 
 int32_t check_params(const ndt2d_params* p) {
   if (!p) return NDT_ERR_INVALID_ARG;
@@ -134,13 +138,11 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
   g.fix_scale = std::ldexp(1.0, kFixShift) / c;
   const size_t ncell = (size_t)g.W * g.H;
   if (ncell > h->cell_capacity) {
-    if (g.recA) (void)hipFree(g.recA);
-    if (g.recB) (void)hipFree(g.recB);
+    if (g.rec) (void)hipFree(g.rec);
     if (g.acc) (void)hipFree(g.acc);
-    g.recA = nullptr; g.recB = nullptr; g.acc = nullptr; h->cell_capacity = 0;
+    g.rec = nullptr; g.acc = nullptr; h->cell_capacity = 0;
     const size_t want = ncell + ncell / 8;
-    HIP_TRY(hipMalloc((void**)&g.recA, want * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&g.recB, want * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&g.rec, 2 * want * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc)));
     h->cell_capacity = want;
   }
@@ -181,9 +183,9 @@ int32_t upload_static(ndt2d_handle* h) {
 
 void launch_iter(ndt2d_handle* h, int blocks, int k) {
   if (h->prm.hessian_mode == NDT_HESSIAN_NEWTON)
-    hipLaunchKernelGGL((k_iterate<1, 0>), dim3(blocks), dim3(kBlock), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
+    hipLaunchKernelGGL((k_iterate<1, 0, kIterThreads>), dim3(blocks), dim3(kIterThreads), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
   else
-    hipLaunchKernelGGL((k_iterate<0, 0>), dim3(blocks), dim3(kBlock), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
+    hipLaunchKernelGGL((k_iterate<0, 0, kIterThreads>), dim3(blocks), dim3(kIterThreads), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
 }
 
 void drop_graph(ndt2d_handle* h) {
@@ -397,7 +399,7 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
   void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
-                 h->grid.recA, h->grid.recB, h->grid.acc};
+                 h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small};
   for (void* p : host) if (p) (void)hipHostFree(p);
@@ -461,30 +463,29 @@ int32_t ndt2d_get_grid(ndt2d_handle* h, int32_t* count, float* mean_xy, float* i
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   HIP_TRY(hipSetDevice(h->device));
   const size_t ncell = (size_t)h->grid.W * h->grid.H;
-  float4* a = new (std::nothrow) float4[ncell];
-  float4* b = new (std::nothrow) float4[ncell];
+  float4* rec = new (std::nothrow) float4[2 * ncell];
   CellAcc* acc = count ? new (std::nothrow) CellAcc[ncell] : nullptr;
   int32_t rc = NDT_OK;
-  if (!a || !b || (count && !acc)) rc = NDT_ERR_ALLOC;
-  if (rc == NDT_OK && hipMemcpyAsync(a, h->grid.recA, ncell * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
-  if (rc == NDT_OK && hipMemcpyAsync(b, h->grid.recB, ncell * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  if (!rec || (count && !acc)) rc = NDT_ERR_ALLOC;
+  if (rc == NDT_OK && hipMemcpyAsync(rec, h->grid.rec, 2 * ncell * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
   if (rc == NDT_OK && acc && hipMemcpyAsync(acc, h->grid.acc, ncell * sizeof(CellAcc), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
   if (rc == NDT_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = NDT_ERR_HIP;
   if (rc == NDT_OK) {
     for (size_t k = 0; k < ncell; ++k) {
+      const float4 a = rec[2 * k], b = rec[2 * k + 1];
       if (count) count[k] = (int32_t)acc[k].n;
-      if (mean_xy) { mean_xy[2 * k] = a[k].x; mean_xy[2 * k + 1] = a[k].y; }
+      if (mean_xy) { mean_xy[2 * k] = a.x; mean_xy[2 * k + 1] = a.y; }
       if (icov_abc) {
-        const bool valid = b[k].z > 0.f;
-        icov_abc[3 * k] = valid ? a[k].z : 0.f;
-        icov_abc[3 * k + 1] = valid ? a[k].w : 0.f;
-        icov_abc[3 * k + 2] = valid ? b[k].y : 0.f;
+        const bool valid = b.z > 0.f;
+        icov_abc[3 * k] = valid ? a.z : 0.f;
+        icov_abc[3 * k + 1] = valid ? a.w : 0.f;
+        icov_abc[3 * k + 2] = valid ? b.y : 0.f;
       }
     }
   } else if (rc == NDT_ERR_HIP) {
     set_error(hipGetErrorString(hipGetLastError()));
   }
-  delete[] a; delete[] b; delete[] acc;
+  delete[] rec; delete[] acc;
   return rc;
 }
 

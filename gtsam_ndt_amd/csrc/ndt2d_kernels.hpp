@@ -34,8 +34,8 @@ struct GridDev {
   int W, H;
   double cell;       // params.cell_size
   double fix_scale;  // 2^kFixShift / cell
-  float4* recA;      // (mean_x, mean_y, a, b)      one 32-byte record per cell, laid out so that
-  float4* recB;      // (b, c, n as float, 0)       (a,b) and (b,c) are both register pairs
+  float4* rec;       // one 32-byte record per cell = two float4: rec[2k] = (mean_x, mean_y, a, b),
+                     // rec[2k+1] = (b, c, n as float, 0); both halves share one 64-byte line
   CellAcc* acc;
 };
 
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, 
     rb = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (ok) atomicAdd(&counters[0], 1);
-  g.recA[k] = ra;
-  g.recB[k] = rb;
+  g.rec[2 * k] = ra;
+  g.rec[2 * k + 1] = rb;
 }
 
 // ---------------------------------------------------------------------- a8 solve/update
@@ -403,12 +403,11 @@ __device__ __forceinline__ int point_key(const PoseF& P, float x, float y, bool 
 }
 
 // a4 (2/2), global-memory grid: one 32-byte record per cell
-__device__ __forceinline__ void lookup_point(const PoseF& P, const float4* __restrict__ recA,
-                                             const float4* __restrict__ recB, float x, float y, bool live,
-                                             PointRec& r) {
+__device__ __forceinline__ void lookup_point(const PoseF& P, const float4* __restrict__ rec, float x, float y,
+                                             bool live, PointRec& r) {
   const int key = point_key(P, x, y, live, r);
-  r.A = recA[key];
-  r.B = recB[key];
+  r.A = rec[2 * key];
+  r.B = rec[2 * key + 1];
   r.hit = true;
 }
 
@@ -510,12 +509,12 @@ __device__ __forceinline__ void copy_state(IterState* dst, const IterState* src,
 // requested up front in one batch, then the cell-record gather.
 // EXP is an ablation mask for tools/exp_iter.hip only (1: no reduce/solve, 2: no body,
 // 4: no epilogue tree, 8: empty); the library instantiates EXP = 0.
-template <int MODE, int EXP = 0>
-__global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restrict__ st,
+template <int MODE, int EXP = 0, int THREADS = kBlock>
+__global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restrict__ st,
                                                     const AlignCall* __restrict__ call,
                                                     AlignDyn* __restrict__ dyn, int parity) {
   __shared__ double s_red[kNumAcc];
-  __shared__ float s_wave[kBlock / 64][kNumAcc];
+  __shared__ float s_wave[THREADS / 64][kNumAcc];
   if (EXP & 8) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const IterState* prev = &dyn->state[parity ^ 1];
@@ -532,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restric
   const float* __restrict__ sx = call->sx;
   const float* __restrict__ sy = call->sy;
   float4 pv[3];
-  if (!(EXP & 1)) {
+  if (!(EXP & 1) && wave < 4) {          // waves 0..3 own the 12 partial rows
     const float* part = &dyn->partials[parity ^ 1][0][0];
 #pragma unroll
     for (int v = 0; v < 3; ++v)
@@ -540,12 +539,12 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restric
   }
   // Pin the read-only scalars here: without this hipcc sinks their s_loads below the
   // `done` branch and they become a third dependent round trip.
-  asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.recA), "s"(G.recB),
+  asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.rec),
                "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations), "s"(prm.eps_trans),
                "s"(prm.eps_rot), "s"(prm.step_max_trans), "s"(prm.step_max_rot), "s"(ps_pose0), "s"(ps_pose1),
                "s"(ps_pose2), "s"(ps_iter), "s"(ps_done), "s"(ps_have), "s"(fixed_iterations));
-  const int stride = kMaxBlocks * kBlock;
-  int i = blockIdx.x * kBlock + tid;
+  const int stride = kMaxBlocks * THREADS;
+  int i = blockIdx.x * THREADS + tid;
   float x = 0.f, y = 0.f, x1 = 0.f, y1 = 0.f;
   if (i < n) { x = sx[i]; y = sy[i]; }
   if (i + stride < n) { x1 = sx[i + stride]; y1 = sy[i + stride]; }
@@ -562,11 +561,13 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restric
     bool done = false;
     if (!(EXP & 1)) {
       // ---- prologue: fixed-order reduction (wave w owns sums 3w..3w+2), then the solve
+      if (wave < 4) {
 #pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        double a = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
-        a = wave_sum_lane63(a);
-        if (lane == 63) s_red[wave * 3 + v] = a;
+        for (int v = 0; v < 3; ++v) {
+          double a = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
+          a = wave_sum_lane63(a);
+          if (lane == 63) s_red[wave * 3 + v] = a;
+        }
       }
       __syncthreads();
 #pragma unroll
@@ -607,8 +608,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restric
   // ---- body: per-point terms at `pose`
   double sn_d, cs_d;
   sincos_wrapped(pose[2], &sn_d, &cs_d);
-  const float4* __restrict__ recA = G.recA;
-  const float4* __restrict__ recB = G.recB;
+  const float4* __restrict__ rec = G.rec;
   const PoseF P = make_pose((float)cs_d, (float)sn_d, (float)pose[0], (float)pose[1], G.ox, G.oy, G.inv_c, G.W,
                             G.H, prm.d1, prm.d2);
   Acc2D A;
@@ -622,8 +622,8 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restric
     if (i2 + stride < n) { xn1 = sx[i2 + stride]; yn1 = sy[i2 + stride]; }
     PointRec r0, r1;
     const bool two = (i + stride) < n;
-    lookup_point(P, recA, recB, x, y, true, r0);
-    lookup_point(P, recA, recB, x1, y1, two, r1);
+    lookup_point(P, rec, x, y, true, r0);
+    lookup_point(P, rec, x1, y1, two, r1);
     accumulate_point<MODE>(P, r0, A);
     accumulate_point<MODE>(P, r1, A);
     x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
@@ -644,9 +644,11 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const AlignStatic* __restric
   }
   __syncthreads();
   if (tid < kNumAcc) {
-    const float r = tid < kNumAcc - 1
-                        ? ((s_wave[0][tid] + s_wave[1][tid]) + s_wave[2][tid]) + s_wave[3][tid]
-                        : 0.f;
+    float r = 0.f;
+    if (tid < kNumAcc - 1) {
+#pragma unroll
+      for (int w = 0; w < THREADS / 64; ++w) r += s_wave[w][tid];     // fixed order
+    }
     dyn->partials[parity][tid][blockIdx.x] = r;
   }
 }

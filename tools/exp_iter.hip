@@ -13,11 +13,14 @@ using namespace ndt;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
+#ifndef THR
+#define THR 256
+#endif
 template <int EXP>
 float time_chain(hipStream_t st, AlignStatic* d_st, AlignCall* d_call, AlignDyn* d_dyn, const float* sx, const float* sy, int n, int K, int reps) {
   hipGraph_t g; hipGraphExec_t ge;
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-  for (int k = 0; k <= K; ++k) hipLaunchKernelGGL((k_iterate<0, EXP>), dim3(kMaxBlocks), dim3(kBlock), 0, st, d_st, d_call, d_dyn, k & 1);
+  for (int k = 0; k <= K; ++k) hipLaunchKernelGGL((k_iterate<0, EXP, THR>), dim3(kMaxBlocks), dim3(THR), 0, st, d_st, d_call, d_dyn, k & 1);
   CK(hipStreamEndCapture(st, &g));
   CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -62,7 +65,7 @@ int main(int argc, char** argv) {
   g.cell = 0.5; g.cell32 = 0.5f; g.inv_c = 2.f; g.ox = -101.f; g.oy = -101.f; g.W = 404; g.H = 404;
   g.fix_scale = std::ldexp(1.0, kFixShift) / 0.5;
   const size_t nc = (size_t)g.W * g.H;
-  CK(hipMalloc(&g.recA, nc * sizeof(float4))); CK(hipMalloc(&g.recB, nc * sizeof(float4))); CK(hipMalloc(&g.acc, nc * sizeof(CellAcc)));
+  CK(hipMalloc(&g.rec, 2 * nc * sizeof(float4))); CK(hipMalloc(&g.acc, nc * sizeof(CellAcc)));
   CK(hipMemset(g.acc, 0, nc * sizeof(CellAcc)));
   int* d_cnt; CK(hipMalloc(&d_cnt, 8)); CK(hipMemset(d_cnt, 0, 8));
   hipStream_t st; CK(hipStreamCreate(&st));
@@ -80,7 +83,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(d_st, &hs, sizeof(hs), hipMemcpyHostToDevice));
   const int K = 30, reps = 200;
   for (int round = 0; round < 2; ++round) {
-    printf("n_src %d  us/launch: full %.3f | no-solve %.3f | no-body %.3f | no-epilogue %.3f | prologue only %.3f | body only %.3f | empty %.3f\n", n_s,
+    printf("thr %d n_src %d  us/launch: full %.3f | no-solve %.3f | no-body %.3f | no-epilogue %.3f | prologue only %.3f | body only %.3f | empty %.3f\n", THR, n_s,
            time_chain<0>(st, d_st, d_call, d_dyn, dsx, dsy, n_s, K, reps), time_chain<1>(st, d_st, d_call, d_dyn, dsx, dsy, n_s, K, reps),
            time_chain<2>(st, d_st, d_call, d_dyn, dsx, dsy, n_s, K, reps), time_chain<4>(st, d_st, d_call, d_dyn, dsx, dsy, n_s, K, reps),
            time_chain<6>(st, d_st, d_call, d_dyn, dsx, dsy, n_s, K, reps), time_chain<5>(st, d_st, d_call, d_dyn, dsx, dsy, n_s, K, reps),
