@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="N=1: skip the extra loop-closure batch figure")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--with-3d", action="store_true",
+                    help="N=1: also time BASELINE config 5 (3D SE(3), 131072-point pair) and report it in '3d'")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N>1 code path (process group + all_gather) even with one rank")
     return ap.parse_args()
@@ -200,6 +202,37 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
     return out
 
 
+def run_3d(a, dev, dev_index):
+    """BASELINE config 5: 3D SE(3), 64 x 2048 beams, fixed 30 Gauss-Newton iterations per step.
+    Each step ends with the synchronous result fetch of ndt3d_align_dev (no async 3D entry point
+    yet), so the figure includes one host round trip per 30 iterations."""
+    from gtsam_ndt_amd import synth3d
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    d = synth3d.make_pair3d()
+    s = [torch.from_numpy(d[k]).to(dev) for k in ("sx", "sy", "sz")]
+    with NdtMatcher3D(device=dev_index, fixed_iterations=K_GN) as m:
+        t0 = time.perf_counter(); m.set_target(d["tx"], d["ty"], d["tz"]); grid_ms = 1e3 * (time.perf_counter() - t0)
+        for _ in range(max(1, a.warmup)):
+            r = m.align(*s, d["init"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            r = m.align(*s, d["init"])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    n = int(s[0].numel())
+    per_launch_us = 1e6 * el / (a.steps * (K_GN + 1))
+    alg = n * 52                                            # SURVEY.md 8d: 12 B point + 40 B record
+    return {"workload": "config5: 3D NDT SE(3), 131072-pt synthetic 64-beam scans, 1.0 m cells, fixed 30 GN iterations",
+            "value": round(a.steps * K_GN / el, 1), "unit": "iters/s", "ms_per_step": round(1e3 * el / a.steps, 4),
+            "grid_build_ms_incl_upload": round(grid_ms, 3), "iterations": r.iterations,
+            "pose_after_30": list(r.pose), "true_pose": list(d["pose"]),
+            "roofline": {"bound": "hbm", "kernel": "k_iterate3", "algorithmic_bytes_per_launch": alg,
+                         "avg_launch_us_incl_host_sync": round(per_launch_us, 3),
+                         "achieved": round(alg / (per_launch_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (per_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -299,6 +332,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(d, a.cpu_seconds)
         if not a.no_batch:
             out["batch"] = run_batch(a, dev, dev_index, 0, 1, None, barrier)
+        if a.with_3d:
+            out["3d"] = run_3d(a, dev, dev_index)
     else:
         out = run_batch(a, dev, dev_index, rank, world, dist, barrier)
 

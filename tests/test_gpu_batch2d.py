@@ -86,3 +86,26 @@ def test_batch_capacity_fallback(gpu_lib):
         s = m.align(d["sx"], d["sy"], d["init"])
     assert res[0].status == s.status == 0 and res[0].pose == s.pose
     assert res[1].status == 0
+
+
+def test_batch_device_pointer_entry_point(gpu_lib, pairs):
+    """ndt2d_batch_align_dev on torch CUDA tensors (what bench.py and a multi-GPU host use):
+    asynchronous on the caller's stream, results decoded from the device rows."""
+    import torch
+    from gtsam_ndt_amd import dist as nd
+    from gtsam_ndt_amd.matcher import NdtBatch2D
+    h = nd.pack_pairs(pairs)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    with NdtBatch2D() as b:
+        with torch.cuda.stream(side):
+            out = b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"],
+                              stream=side.cuda_stream)
+        side.synchronize()
+        dev_rows = b.decode(out)
+        host_rows = b.align([(p["tx"], p["ty"]) for p in pairs], [(p["sx"], p["sy"]) for p in pairs],
+                            [p["init"] for p in pairs])
+    for a_, b_ in zip(dev_rows, host_rows):
+        assert a_.status == 0 and a_.pose == b_.pose and a_.iterations == b_.iterations
