@@ -183,6 +183,8 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
                    "cell_size": 0.5, "gn_iterations_per_pair": K_GN, "collective": "all_gather of 144 B/pair"
                    if world > 1 else "none (1 GPU)"},
         "pairs_per_s": round(total * a.steps / elapsed, 1),
+        "scaling_note": "weak scaling of the loop-closure batch: compare with the N=1 line's batch.value "
+                        "(the N=1 line's own value is the single-pair config 3)",
         "roofline": {"bound": "hbm", "kernel": "k_batch<GN>", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": (load_traffic() or {}).get("batch_bytes_per_launch"),
@@ -323,6 +325,9 @@ def main():
                        "gn_iterations_per_step": K_GN, "hessian": "gauss-newton"},
             "roofline": roofline,
             "grid_build_ms": round(grid_ms, 4),
+            "scaling_note": "N=1 times the single-pair config 3 named by BASELINE.json's metric; N>1 lines time "
+                            "the sharded loop-closure batch (config 4).  Read multi-GPU scaling against this "
+                            "line's batch.value (same workload, one GPU), not against value.",
             "pose_err_vs_cpu_ref": {"dx_m": float(perr[0]), "dy_m": float(perr[1]), "dtheta_rad": float(perr[2]),
                                     "gpu_iterations": rc.iterations, "cpu_iterations": ref["iterations"],
                                     "cpu_ref": "oracle/ndt2d.py float64 (reference implementation unavailable)"},
