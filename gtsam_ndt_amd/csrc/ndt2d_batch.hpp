@@ -360,12 +360,14 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
 #pragma unroll
           for (int u = 0; u < kBatchUnroll; ++u) accumulate_point<MODE>(P, r[u], A);
         };
-        load_set(tid, xa, ya);
-        for (int i = tid; i < ns; i += 2 * kTrip) {
-          load_set(i + kTrip, xb, yb);
-          consume_set(i, xa, ya);
-          load_set(i + 2 * kTrip, xa, ya);
-          if (i + kTrip < ns) consume_set(i + kTrip, xb, yb);     // wave-uniform except at the tail
+        if (ns > 0) {                                  // uniform; an empty source must not touch sx[-1]
+          load_set(tid, xa, ya);
+          for (int i = tid; i < ns; i += 2 * kTrip) {
+            load_set(i + kTrip, xb, yb);
+            consume_set(i, xa, ya);
+            load_set(i + 2 * kTrip, xa, ya);
+            if (i + kTrip < ns) consume_set(i + kTrip, xb, yb);     // wave-uniform except at the tail
+          }
         }
         acc_store(A, acc);
         acc[11] = 0.f;

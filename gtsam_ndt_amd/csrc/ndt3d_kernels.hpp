@@ -138,6 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_finalise3(Grid3Dev g, int min_points
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
   float2 rc = make_float2(0.f, 0.f);
   const int n = (int)c.n;
+  bool ok = false;
   if (c.n > kMaxCellCount) atomicAdd(&counters[1], 1);
   if (n >= min_points && n >= 2 && c.n <= kMaxCellCount) {
     const unsigned int k32 = (unsigned int)k, w32 = (unsigned int)g.W, h32 = (unsigned int)g.H;
@@ -172,9 +173,12 @@ __global__ __launch_bounds__(kBlock) void k_finalise3(Grid3Dev g, int min_points
       ra = make_float4((float)mx, (float)my, (float)mz, (float)n);
       rb = make_float4((float)cxx, (float)cxy, (float)cxz, (float)cyy);
       rc = make_float2((float)cyz, (float)czz);
-      atomicAdd(&counters[0], 1);
+      ok = true;
     }
   }
+  const unsigned long long valid_mask = __ballot(ok);      // one atomic per wave
+  if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(valid_mask | (1ull << 63)) && valid_mask)
+    atomicAdd(&counters[0], (int)__popcll(valid_mask));
   g.recA[k] = ra;
   g.recB[k] = rb;
   g.recC[k] = rc;

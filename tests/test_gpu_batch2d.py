@@ -109,3 +109,19 @@ def test_batch_device_pointer_entry_point(gpu_lib, pairs):
                             [p["init"] for p in pairs])
     for a_, b_ in zip(dev_rows, host_rows):
         assert a_.status == 0 and a_.pose == b_.pose and a_.iterations == b_.iterations
+
+
+def test_batch_empty_clouds(gpu_lib, pairs):
+    """Pairs with an empty source or an empty target (zero-length slices, first and last in the
+    batch) report a status and touch no memory outside their slice."""
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtBatch2D
+    p = pairs[0]
+    e = np.zeros(0, np.float32)
+    with NdtBatch2D() as b:
+        res = b.align([(p["tx"], p["ty"]), (e, e), (p["tx"], p["ty"]), (p["tx"], p["ty"])],
+                      [(e, e), (p["sx"], p["sy"]), (p["sx"], p["sy"]), (e, e)],
+                      [p["init"]] * 4)
+    assert res[0].status == L.NDT_TOO_FEW_HITS and res[3].status == L.NDT_TOO_FEW_HITS
+    assert res[1].status == L.NDT_TOO_FEW_CELLS
+    assert res[2].status == 0
