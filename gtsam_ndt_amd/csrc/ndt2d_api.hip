@@ -64,6 +64,7 @@ int32_t check_params(const ndt2d_params* p) {
   if (p->hessian_mode != NDT_HESSIAN_GAUSS_NEWTON && p->hessian_mode != NDT_HESSIAN_NEWTON)
     return NDT_ERR_INVALID_ARG;
   if (!(p->step_max_trans > 0.0) || !(p->step_max_rot > 0.0)) return NDT_ERR_INVALID_ARG;
+  if (!(p->d1 > 0.0) || !(p->d2 > 0.0) || !std::isfinite(p->d1) || !std::isfinite(p->d2)) return NDT_ERR_INVALID_ARG;
   return NDT_OK;
 }
 

@@ -23,7 +23,8 @@ namespace ndt {
 constexpr int kBatchThreads = NDT_BATCH_THREADS;
 constexpr int kBatchWaves = kBatchThreads / 64;
 constexpr int kBatchMaxCells = 16384;   // dense index table: e.g. 128 x 128 cells
-constexpr int kBatchMaxSlots = 2304;    // cells with n >= min_points (<= 3 per thread at finalise)
+constexpr int kBatchMaxSlots = 2304;    // records: slot 0 is a dummy invalid record, so 2303 cells
+                                        // with n >= min_points fit
 constexpr int kBatchUnroll = NDT_BATCH_UNROLL;   // source points per thread and register set
 constexpr int kBatchSlotsPerThread = (kBatchMaxSlots + kBatchThreads - 1) / kBatchThreads;
 
@@ -109,15 +110,12 @@ __device__ __forceinline__ void lookup_point_lds(const PoseF& P, const unsigned 
                                                  PointRec& r) {
   const int key = point_key(P, x, y, live, r);
 #if defined(NDT_BATCH_ABLATE) && (NDT_BATCH_ABLATE & 1)      // tools/exp_batch.hip only: no LDS traffic
-  r.hit = key > 0;
-  r.A = make_float4(r.p.x - 0.01f, r.p.y + 0.01f, 900.f, 30.f);
+  r.A = make_float4(r.px - 0.01f, r.py + 0.01f, 900.f, 30.f);
   r.B = make_float4(30.f, 800.f, 9.f, 0.f);
 #else
-  const int slot = idx[key];                       // guard cells and empty cells hold 0
-  r.hit = slot > 0;
-  const int s = max(slot - 1, 0);
-  r.A = recA[s];
-  r.B = recB[s];
+  const int slot = idx[key];                       // guard and empty cells hold 0 = the dummy record,
+  r.A = recA[slot];                                // whose n = 0 marks it invalid
+  r.B = recB[slot];
 #endif
 }
 
@@ -128,6 +126,28 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
   const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffull));
   const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
+}
+
+// Target passes: kTgtUnroll points per thread are requested before any is used (a one-point
+// loop pays the full memory latency per trip: 98 dependent round trips per pass).  Loads go
+// through a buffer descriptor of the pair's slice: lanes past the end read 0 and are skipped.
+constexpr int kTgtUnroll = 8;
+template <typename F>
+__device__ __forceinline__ void for_each_target_point(const float* tx, const float* ty, int nt, F&& body) {
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)tx, 0, nt * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)ty, 0, nt * 4, 0x00020000);
+  for (int i = threadIdx.x; i < nt; i += kTgtUnroll * kBatchThreads) {
+    float x[kTgtUnroll], y[kTgtUnroll];
+#pragma unroll
+    for (int u = 0; u < kTgtUnroll; ++u) {
+      const int off = (i + u * kBatchThreads) * 4;
+      x[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+      y[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < kTgtUnroll; ++u)
+      if (i + u * kBatchThreads < nt) body(x[u], y[u]);
+  }
 }
 
 constexpr int kStatusCapacity = -5;   // NDT_ERR_CAPACITY: pair needs the global-memory path
@@ -167,13 +187,12 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     // ---- a1: bounding box of the target and grid geometry (oracle/ndt2d.py grid_geometry)
     {
       float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-      for (int i = tid; i < nt; i += kBatchThreads) {
-        const float u = tx[i], v = ty[i];
+      for_each_target_point(tx, ty, nt, [&](float u, float v) {
         if (isfinite(u) && isfinite(v)) {
           xmin = fminf(xmin, u); xmax = fmaxf(xmax, u);
           ymin = fminf(ymin, v); ymax = fmaxf(ymax, v);
         }
-      }
+      });
       xmin = wave_min(xmin); xmax = wave_max(xmax);
       ymin = wave_min(ymin); ymax = wave_max(ymax);
       if (lane == 0) { red[wave * 4 + 0] = xmin; red[wave * 4 + 1] = xmax; red[wave * 4 + 2] = ymin; red[wave * 4 + 3] = ymax; }
@@ -221,10 +240,10 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     // ---- a2 (1/2): per-cell counts
     for (int k = tid; k < ncell; k += kBatchThreads) cnt[k] = 0u;
     __syncthreads();
-    for (int i = tid; i < nt; i += kBatchThreads) {
-      const float fx = (tx[i] - ox) * inv_c, fy = (ty[i] - oy) * inv_c;
+    for_each_target_point(tx, ty, nt, [&](float px, float py) {
+      const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
       if ((fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH)) atomicAdd(&cnt[(int)fy * W + (int)fx], 1u);
-    }
+    });
     __syncthreads();
 
     // ---- compaction: cells with n >= min_points get a slot, in cell order (deterministic)
@@ -236,7 +255,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     int nslot = 0;
     int s = block_excl_scan(local, s_scan, &nslot);
     nslot = __builtin_amdgcn_readfirstlane(nslot);
-    if (nslot > kBatchMaxSlots || nslot < 1) {       // uniform
+    if (nslot > kBatchMaxSlots - 1 || nslot < 1) {   // uniform (record 0 is the dummy)
       if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, 0, 0, nslot < 1 ? 4 : kStatusCapacity);
       return;
     }
@@ -257,24 +276,23 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     __syncthreads();
 
     // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics)
-    for (int i = tid; i < nt; i += kBatchThreads) {
-      const float px = tx[i], py = ty[i];
+    for_each_target_point(tx, ty, nt, [&](float px, float py) {
       const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
       if ((fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH)) {
         const int ix = (int)fx, iy = (int)fy;
         const int slot = idx[iy * W + ix];
         if (slot) {
-          const long long ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
-          const long long uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
+          const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
+          const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
           unsigned long long* q = sums + (slot - 1);
-          atomicAdd(q, (unsigned long long)ux);
-          atomicAdd(q + kBatchMaxSlots, (unsigned long long)uy);
-          atomicAdd(q + 2 * kBatchMaxSlots, (unsigned long long)(ux * ux));
-          atomicAdd(q + 3 * kBatchMaxSlots, (unsigned long long)(ux * uy));
-          atomicAdd(q + 4 * kBatchMaxSlots, (unsigned long long)(uy * uy));
+          atomicAdd(q, (unsigned long long)(long long)ux);
+          atomicAdd(q + kBatchMaxSlots, (unsigned long long)(long long)uy);
+          atomicAdd(q + 2 * kBatchMaxSlots, prod64(ux, ux));
+          atomicAdd(q + 3 * kBatchMaxSlots, prod64(ux, uy));
+          atomicAdd(q + 4 * kBatchMaxSlots, prod64(uy, uy));
         }
       }
-    }
+    });
     if (tid == 0) misc[6] = 0;
     __syncthreads();
 
@@ -304,8 +322,9 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
 #pragma unroll
       for (int j = 0; j < kBatchSlotsPerThread; ++j) {
         const int sl = tid + j * kBatchThreads;
-        if (sl < nslot) { recA[sl] = ra[j]; recB[sl] = rb[j]; }
+        if (sl < nslot) { recA[sl + 1] = ra[j]; recB[sl + 1] = rb[j]; }   // record index = idx value
       }
+      if (tid == 0) { recA[0] = make_float4(0.f, 0.f, 0.f, 0.f); recB[0] = make_float4(0.f, 0.f, 0.f, 0.f); }
       if (nvalid) atomicAdd(&misc[6], nvalid);
       __syncthreads();
     }
@@ -338,17 +357,21 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
         // point and are masked by `live`.
         constexpr int kTrip = kBatchUnroll * kBatchThreads;
         float xa[kBatchUnroll], ya[kBatchUnroll], xb[kBatchUnroll], yb[kBatchUnroll];
+        // Source points come through buffer descriptors: 32-bit byte offsets instead of 64-bit
+        // address arithmetic, and the hardware range check returns 0 past the end of the pair's
+        // slice, so no clamp either (those lanes are masked by `live` anyway).
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)sx, 0, ns * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)sy, 0, ns * 4, 0x00020000);
         auto load_set = [&](int base, float* xs, float* ys) {
 #pragma unroll
           for (int u = 0; u < kBatchUnroll; ++u) {
-            const int ii = base + u * kBatchThreads;
-            const int ic = ii < ns ? ii : ns - 1;
+            const int off = (base + u * kBatchThreads) * 4;
 #if defined(NDT_BATCH_ABLATE) && (NDT_BATCH_ABLATE & 2)      // tools only: no global point loads
-            xs[u] = (float)(ic & 1023) * 0.04f - 20.f;
-            ys[u] = (float)(ic >> 10) * 0.4f - 20.f;
+            xs[u] = (float)((off >> 2) & 1023) * 0.04f - 20.f;
+            ys[u] = (float)(off >> 12) * 0.4f - 20.f;
 #else
-            xs[u] = sx[ic];
-            ys[u] = sy[ic];
+            xs[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+            ys[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
 #endif
           }
         };
@@ -369,7 +392,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
             if (i + kTrip < ns) consume_set(i + kTrip, xb, yb);     // wave-uniform except at the tail
           }
         }
-        acc_store(A, acc);
+        acc_store(A, a.prm.d2, acc);
         acc[11] = 0.f;
       }
 #pragma unroll

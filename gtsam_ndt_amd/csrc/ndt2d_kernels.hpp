@@ -119,8 +119,13 @@ __global__ __launch_bounds__(kBlock) void k_bounds(const float* __restrict__ x,
 __device__ __forceinline__ double cell_centre(float o, int i, double cell) {
   return fma((double)i + 0.5, cell, (double)o);
 }
-__device__ __forceinline__ long long fix_coord(float p, double centre, double fix_scale) {
-  return __double2ll_rn(((double)p - centre) * fix_scale);
+// |U| <= 2^21 for a point inside its cell, so the conversion is the single-instruction
+// v_cvt_i32_f64 (an f64 -> i64 conversion is emulated) and products are 32 x 32 -> 64 bit.
+__device__ __forceinline__ int fix_coord(float p, double centre, double fix_scale) {
+  return __double2int_rn(((double)p - centre) * fix_scale);
+}
+__device__ __forceinline__ unsigned long long prod64(int a, int b) {
+  return (unsigned long long)((long long)a * (long long)b);
 }
 
 // a3: exact sums -> Welford form (n, mean, M2) -> Sigma = M2/(n-1) -> eigenvalue clamp ->
@@ -179,15 +184,15 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float* __restrict__
     const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H);
     if (in) {
       const int ix = (int)fx, iy = (int)fy;
-      const long long ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
-      const long long uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
+      const int ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
+      const int uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
       CellAcc* c = g.acc + ((size_t)iy * g.W + ix);
       atomicAdd(&c->n, 1u);
-      atomicAdd((unsigned long long*)&c->sx, (unsigned long long)ux);
-      atomicAdd((unsigned long long*)&c->sy, (unsigned long long)uy);
-      atomicAdd((unsigned long long*)&c->sxx, (unsigned long long)(ux * ux));
-      atomicAdd((unsigned long long*)&c->sxy, (unsigned long long)(ux * uy));
-      atomicAdd((unsigned long long*)&c->syy, (unsigned long long)(uy * uy));
+      atomicAdd((unsigned long long*)&c->sx, (unsigned long long)(long long)ux);
+      atomicAdd((unsigned long long*)&c->sy, (unsigned long long)(long long)uy);
+      atomicAdd((unsigned long long*)&c->sxx, prod64(ux, ux));
+      atomicAdd((unsigned long long*)&c->sxy, prod64(ux, uy));
+      atomicAdd((unsigned long long*)&c->syy, prod64(uy, uy));
     } else {
       outside++;
     }
@@ -343,43 +348,51 @@ __global__ void k_begin(AlignCall* __restrict__ call, AlignDyn* __restrict__ dyn
 }
 
 // ---- per-point pieces of the body (rows a4-a6) ------------------------------------------
-// The 2D math is written on (x, y) register pairs so that it issues as packed-f32 VALU
-// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes-worth of f32 per instruction); the
-// loop-closure kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 90 % of SIMD cycles), so
-// instructions per point are its cost.  Per-element arithmetic is unchanged: every packed
-// fma is the same fmaf(a, b, c) the contract names.
-#ifndef NDT_POINT_PACKED
-#define NDT_POINT_PACKED 0     // 1: issue the (x,y) math as v_pk_*_f32 on register pairs.  Measured
-#endif                         //    slower on gfx950 (packed f32 runs at half rate there), so off.
+// The loop-closure kernel is VALU-issue bound, so this code is written
+// for instructions per point: clamped keys instead of an in-grid compare chain, one-instruction
+// floor, 24-bit multiply, d1 folded into the exponent and d2 applied once to the finished sums,
+// the SE(2) Jacobian read off the image point, hits counted on the scalar unit.  (Writing the
+// (x,y) math on register pairs for v_pk_*_f32 was measured: no gain, gfx950 issues packed f32
+// at half rate.)
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f splat2(float a) { return (v2f){a, a}; }
-__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 struct PoseF {
-  v2f c0;      // (cos, sin)        p' = c0*x + (c1*y + t)
-  v2f c1;      // (-sin, cos)
-  v2f t;       // (tx, ty)
-  v2f o;       // grid origin
-  v2f j1;      // (-cos, -sin)      dR/dtheta p = c1*x + j1*y
-  float inv_c;
+  float cs, sn, tx, ty, ox, oy, inv_c;
   int W, wm1, hm1;
-  float d1, d2, nhd2;
+  float lg_d1;   // log2(d1):  d1*exp(-d2/2 m) = exp2(nhd2*m + lg_d1)
+  float nhd2;    // -d2/2 * log2(e)
+  float d2;
 };
 __device__ __forceinline__ PoseF make_pose(float cs, float sn, float tx, float ty, float ox, float oy, float inv_c,
                                            int W, int H, float d1, float d2) {
   PoseF P;
-  P.c0 = (v2f){cs, sn}; P.c1 = (v2f){-sn, cs}; P.t = (v2f){tx, ty}; P.o = (v2f){ox, oy}; P.j1 = (v2f){-cs, -sn};
-  P.inv_c = inv_c; P.W = W; P.wm1 = W - 1; P.hm1 = H - 1;
-  P.d1 = d1; P.d2 = d2; P.nhd2 = -0.5f * d2 * 1.44269504088896340736f;   // exp(-d2/2 m) = exp2(nhd2*m)
+  P.cs = cs; P.sn = sn; P.tx = tx; P.ty = ty; P.ox = ox; P.oy = oy; P.inv_c = inv_c;
+  P.W = W; P.wm1 = W - 1; P.hm1 = H - 1;
+  P.lg_d1 = __builtin_amdgcn_logf(d1);                 // v_log_f32 = log2
+  P.nhd2 = -0.5f * d2 * 1.44269504088896340736f;
+  P.d2 = d2;
   return P;
 }
 
+// floor(f) as int32 in ONE instruction (v_cvt_flr_i32_f32: saturating, NaN -> 0); the
+// portable spelling costs v_floor_f32 + v_cvt_i32_f32 per coordinate in the hottest loop.
+__device__ __forceinline__ int floor_to_int(float f) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
+}
+
+// clamp(i, 0, hi) in one instruction (v_med3_i32); min(max()) with a runtime bound is two
+__device__ __forceinline__ int clamp_index(int i, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "s"(hi));
+  return r;
+}
+
 struct PointRec {
-  v2f xy;      // source point (non-finite coordinates clamped to +-1e15)
-  v2f p;       // its image R p + t
-  float4 A;    // mean_x, mean_y, a, b
-  float4 B;    // b, c, n, 0
-  bool hit;    // set by the LDS lookup; the global lookup leaves validity to B.z
+  float px, py;   // image R p + t of the source point (non-finite coordinates clamped to +-1e15)
+  float4 A;       // mean_x, mean_y, a, b
+  float4 B;       // b, c, n, 0
 };
 
 // a4 (1/2): transform and cell key.  No in-grid compare chain: the key is clamped onto the grid,
@@ -390,19 +403,12 @@ struct PointRec {
 __device__ __forceinline__ int point_key(const PoseF& P, float x, float y, bool live, PointRec& r) {
   x = __builtin_amdgcn_fmed3f(x, -1e15f, 1e15f);
   y = __builtin_amdgcn_fmed3f(y, -1e15f, 1e15f);
-  r.xy = (v2f){x, y};
-#if NDT_POINT_PACKED
-  r.p = fma2(P.c0, splat2(x), fma2(P.c1, splat2(y), P.t));
-  const v2f f = (r.p - P.o) * splat2(P.inv_c);
-#else
-  r.p.x = fmaf(P.c0.x, x, fmaf(P.c1.x, y, P.t.x));
-  r.p.y = fmaf(P.c0.y, x, fmaf(P.c1.y, y, P.t.y));
-  const v2f f = (v2f){(r.p.x - P.o.x) * P.inv_c, (r.p.y - P.o.y) * P.inv_c};
-#endif
-  int ix = __float2int_rd(f.x), iy = __float2int_rd(f.y);       // floor; saturating
-  ix = min(max(ix, 0), P.wm1);
-  iy = min(max(iy, 0), P.hm1);
-  return live ? iy * P.W + ix : 0;                                // cell 0 is a guard cell
+  r.px = fmaf(P.cs, x, fmaf(-P.sn, y, P.tx));
+  r.py = fmaf(P.sn, x, fmaf(P.cs, y, P.ty));
+  int ix = floor_to_int((r.px - P.ox) * P.inv_c), iy = floor_to_int((r.py - P.oy) * P.inv_c);
+  ix = clamp_index(ix, P.wm1);
+  iy = clamp_index(iy, P.hm1);
+  return live ? __mul24(iy, P.W) + ix : 0;                        // cell 0 is a guard cell; W, iy < 2^24
 }
 
 // a4 (2/2), global-memory grid: one 32-byte record per cell
@@ -411,84 +417,54 @@ __device__ __forceinline__ void lookup_point(const PoseF& P, const float4* __res
   const int key = point_key(P, x, y, live, r);
   r.A = rec[2 * key];
   r.B = rec[2 * key + 1];
-  r.hit = true;
 }
 
-struct Acc2D {   // the 11 running sums of one thread
-  v2f h01;       // Hxx Hxy
-  v2f h34;       // Hxt Hyt
-  v2f g01;       // gx gy
-  float h2, h5, g2, s, n;   // Hyy Htt gt score hits
+struct Acc2D {            // the running sums of one thread (unscaled: d2 is applied in acc_store)
+  float h0, h1, h2, h3, h4, h5;   // Hxx Hxy Hyy Hxt Hyt Htt
+  float g0, g1, g2, s;            // gx gy gt score
+  int n_wave;                     // hits of the whole wave, kept on the scalar unit
 };
 __device__ __forceinline__ void acc_zero(Acc2D& a) {
-  a.h01 = a.h34 = a.g01 = splat2(0.f);
-  a.h2 = a.h5 = a.g2 = a.s = a.n = 0.f;
+  a.h0 = a.h1 = a.h2 = a.h3 = a.h4 = a.h5 = a.g0 = a.g1 = a.g2 = a.s = 0.f;
+  a.n_wave = 0;
 }
-__device__ __forceinline__ void acc_store(const Acc2D& a, float* out /*[11]*/) {
-  out[0] = a.h01.x; out[1] = a.h01.y; out[2] = a.h2; out[3] = a.h34.x; out[4] = a.h34.y; out[5] = a.h5;
-  out[6] = a.g01.x; out[7] = a.g01.y; out[8] = a.g2; out[9] = a.s; out[10] = a.n;
+__device__ __forceinline__ void acc_store(const Acc2D& a, float d2, float* out /*[11]*/) {
+  out[0] = a.h0 * d2; out[1] = a.h1 * d2; out[2] = a.h2 * d2; out[3] = a.h3 * d2; out[4] = a.h4 * d2;
+  out[5] = a.h5 * d2; out[6] = a.g0 * d2; out[7] = a.g1 * d2; out[8] = a.g2 * d2; out[9] = a.s;
+  out[10] = (threadIdx.x & 63) == 0 ? (float)a.n_wave : 0.f;     // the wave's hits, once
 }
 
 // a5+a6: Mahalanobis score, SE(2) Jacobian, gradient / Hessian terms into the thread's sums
 template <int MODE>
 __device__ __forceinline__ void accumulate_point(const PoseF& P, const PointRec& r, Acc2D& acc) {
-  const bool hit = r.hit & (r.B.z > 0.f);
-#if NDT_POINT_PACKED
-  const v2f mu = (v2f){r.A.x, r.A.y}, ab = (v2f){r.A.z, r.A.w}, bc = (v2f){r.B.x, r.B.y};
-  const v2f q = r.p - mu;
-  const v2f v = fma2(ab, splat2(q.x), bc * splat2(q.y));          // Sigma^-1 q
-  const v2f qv = q * v;
-  const float m = qv.x + qv.y;
-#else
+  const bool hit = r.B.z > 0.f;                                   // n > 0: a finalised cell
   const float a = r.A.z, b = r.A.w, c = r.B.y;
-  const float qx = r.p.x - r.A.x, qy = r.p.y - r.A.y;
-  const float vx = fmaf(a, qx, b * qy), vy = fmaf(b, qx, c * qy);
+  const float qx = r.px - r.A.x, qy = r.py - r.A.y;
+  const float vx = fmaf(a, qx, b * qy), vy = fmaf(b, qx, c * qy);   // Sigma^-1 q
   const float m = fmaf(qx, vx, qy * vy);
-  const v2f v = (v2f){vx, vy};
-#endif
 #if defined(NDT_BATCH_ABLATE) && (NDT_BATCH_ABLATE & 4)      // tools only: no transcendental
-  const float s = hit ? P.d1 * (1.f + P.nhd2 * m) : 0.f;
+  const float s = hit ? fmaf(P.nhd2, m, 1.f) : 0.f;
 #else
-  const float s = hit ? P.d1 * __builtin_amdgcn_exp2f(P.nhd2 * m) : 0.f;
+  const float s = hit ? __builtin_amdgcn_exp2f(fmaf(P.nhd2, m, P.lg_d1)) : 0.f;
 #endif
-  const float w = s * P.d2;
-#if NDT_POINT_PACKED
-  const v2f j = fma2(P.c1, splat2(r.xy.x), P.j1 * splat2(r.xy.y));   // dR/dtheta p
-  const v2f vj = v * j;
-  const float vt = vj.x + vj.y;
-  const v2f u = fma2(ab, splat2(j.x), bc * splat2(j.y));          // Sigma^-1 j
-  const v2f ju = j * u;
-  v2f h01 = ab, h34 = u;
-  float hyy = bc.y, htt = ju.x + ju.y;
-#else
-  const float jx = fmaf(P.c1.x, r.xy.x, P.j1.x * r.xy.y), jy = fmaf(P.c1.y, r.xy.x, P.j1.y * r.xy.y);
+  const float jx = P.ty - r.py, jy = r.px - P.tx;                  // dR/dtheta p = perp(p' - t)
   const float vt = fmaf(vx, jx, vy * jy);
-  const float ux = fmaf(a, jx, b * jy), uy = fmaf(b, jx, c * jy);
-  const v2f j = (v2f){jx, jy};
-  v2f h01 = (v2f){a, b}, h34 = (v2f){ux, uy};
-  float hyy = c, htt = fmaf(jx, ux, jy * uy);
-#endif
+  const float ux = fmaf(a, jx, b * jy), uy = fmaf(b, jx, c * jy);   // Sigma^-1 j
+  float hxx = a, hxy = b, hyy = c, hxt = ux, hyt = uy, htt = fmaf(jx, ux, jy * uy);
   if (MODE == 1) {   // full Newton Hessian (Biber / Magnusson)
-    h01 = fma2(splat2(-P.d2 * v.x), v, h01);
-    hyy = fmaf(-P.d2 * v.y, v.y, hyy);
-    h34 = fma2(splat2(-P.d2 * vt), v, h34);
-    htt = fmaf(-P.d2 * vt, vt, htt) + fmaf(v.y, j.x, -v.x * j.y);
+    const float dvx = -P.d2 * vx, dvy = -P.d2 * vy, dvt = -P.d2 * vt;
+    hxx = fmaf(dvx, vx, hxx);
+    hxy = fmaf(dvx, vy, hxy);
+    hyy = fmaf(dvy, vy, hyy);
+    hxt = fmaf(dvt, vx, hxt);
+    hyt = fmaf(dvt, vy, hyt);
+    htt = fmaf(dvt, vt, htt) + fmaf(vy, jx, -vx * jy);
   }
-#if NDT_POINT_PACKED
-  const v2f w2 = splat2(w);
-  acc.h01 = fma2(w2, h01, acc.h01);
-  acc.h34 = fma2(w2, h34, acc.h34);
-  acc.g01 = fma2(w2, v, acc.g01);
-#else
-  acc.h01.x = fmaf(w, h01.x, acc.h01.x); acc.h01.y = fmaf(w, h01.y, acc.h01.y);
-  acc.h34.x = fmaf(w, h34.x, acc.h34.x); acc.h34.y = fmaf(w, h34.y, acc.h34.y);
-  acc.g01.x = fmaf(w, v.x, acc.g01.x);   acc.g01.y = fmaf(w, v.y, acc.g01.y);
-#endif
-  acc.h2 = fmaf(w, hyy, acc.h2);
-  acc.h5 = fmaf(w, htt, acc.h5);
-  acc.g2 = fmaf(w, vt, acc.g2);
+  acc.h0 = fmaf(s, hxx, acc.h0); acc.h1 = fmaf(s, hxy, acc.h1); acc.h2 = fmaf(s, hyy, acc.h2);
+  acc.h3 = fmaf(s, hxt, acc.h3); acc.h4 = fmaf(s, hyt, acc.h4); acc.h5 = fmaf(s, htt, acc.h5);
+  acc.g0 = fmaf(s, vx, acc.g0);  acc.g1 = fmaf(s, vy, acc.g1);  acc.g2 = fmaf(s, vt, acc.g2);
   acc.s += s;
-  acc.n += hit ? 1.f : 0.f;
+  acc.n_wave += (int)__popcll(__ballot(hit));                     // s_bcnt1 on the compare mask: no VALU
 }
 
 // 128-byte state copy without a struct temporary (a by-value IterState lands in scratch)
@@ -632,7 +608,7 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
     x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
   }
   float acc[kNumAcc];
-  acc_store(A, acc);
+  acc_store(A, prm.d2, acc);
   acc[11] = 0.f;
 
   // ---- epilogue: wave tree -> LDS -> one partial row per block

@@ -88,20 +88,20 @@ __global__ __launch_bounds__(kBlock) void k_accumulate3(const float* __restrict_
     const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H) & (fz >= 0.f) & (fz < (float)g.D);
     if (in) {
       const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-      const long long ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
-      const long long uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
-      const long long uz = fix_coord(pz, cell_centre(g.oz, iz, g.cell), g.fix_scale);
+      const int ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
+      const int uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
+      const int uz = fix_coord(pz, cell_centre(g.oz, iz, g.cell), g.fix_scale);
       CellAcc3* c = g.acc + (((size_t)iz * g.H + iy) * g.W + ix);
       atomicAdd(&c->n, 1u);
-      atomicAdd((unsigned long long*)&c->s[0], (unsigned long long)ux);
-      atomicAdd((unsigned long long*)&c->s[1], (unsigned long long)uy);
-      atomicAdd((unsigned long long*)&c->s[2], (unsigned long long)uz);
-      atomicAdd((unsigned long long*)&c->ss[0], (unsigned long long)(ux * ux));
-      atomicAdd((unsigned long long*)&c->ss[1], (unsigned long long)(ux * uy));
-      atomicAdd((unsigned long long*)&c->ss[2], (unsigned long long)(ux * uz));
-      atomicAdd((unsigned long long*)&c->ss[3], (unsigned long long)(uy * uy));
-      atomicAdd((unsigned long long*)&c->ss[4], (unsigned long long)(uy * uz));
-      atomicAdd((unsigned long long*)&c->ss[5], (unsigned long long)(uz * uz));
+      atomicAdd((unsigned long long*)&c->s[0], (unsigned long long)(long long)ux);
+      atomicAdd((unsigned long long*)&c->s[1], (unsigned long long)(long long)uy);
+      atomicAdd((unsigned long long*)&c->s[2], (unsigned long long)(long long)uz);
+      atomicAdd((unsigned long long*)&c->ss[0], prod64(ux, ux));
+      atomicAdd((unsigned long long*)&c->ss[1], prod64(ux, uy));
+      atomicAdd((unsigned long long*)&c->ss[2], prod64(ux, uz));
+      atomicAdd((unsigned long long*)&c->ss[3], prod64(uy, uy));
+      atomicAdd((unsigned long long*)&c->ss[4], prod64(uy, uz));
+      atomicAdd((unsigned long long*)&c->ss[5], prod64(uz, uz));
     }
   }
 }
