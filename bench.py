@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--with-3d", action="store_true",
                     help="N=1: also time BASELINE config 5 (3D SE(3), 131072-point pair) and report it in '3d'")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of the N>1 flow on a 1-GPU box: every rank uses cuda:0 and the result "
+                         "gather runs over gloo on host copies (RCCL refuses two ranks on one device)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N>1 code path (process group + all_gather) even with one rank")
     return ap.parse_args()
@@ -249,9 +252,13 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev_index = local_rank if world > 1 else 0
+        if a.rehearse_on_one_gpu:
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev_index = local_rank if (world > 1 and not a.rehearse_on_one_gpu) else 0
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 

@@ -30,6 +30,8 @@ def gather_results(local, n_pairs_total: int, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()            # rehearsal on a 1-GPU box: gather host copies
     sizes = shard_sizes(n_pairs_total, world)
     assert local.shape[0] == sizes[dist.get_rank(group)], "local rows must match this rank's shard"
     width = local.shape[1]
@@ -44,6 +46,8 @@ def gather_results(local, n_pairs_total: int, group=None):
 def max_over_ranks(value: float, device=None, group=None) -> float:
     import torch
     import torch.distributed as dist
+    if dist.get_backend(group) == "gloo":
+        device = None
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
