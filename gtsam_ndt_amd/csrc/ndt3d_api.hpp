@@ -85,13 +85,11 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
   g.fix_scale = std::ldexp(1.0, kFixShift) / c;
   const size_t ncell = (size_t)g.W * g.H * g.D;
   if (ncell > h->cell_capacity) {
-    void* old[] = {g.recA, g.recB, g.recC, g.acc};
+    void* old[] = {g.rec, g.acc};
     for (void* p : old) if (p) (void)hipFree(p);
-    g.recA = nullptr; g.recB = nullptr; g.recC = nullptr; g.acc = nullptr; h->cell_capacity = 0;
+    g.rec = nullptr; g.acc = nullptr; h->cell_capacity = 0;
     const size_t want = ncell + ncell / 8;
-    HIP_TRY(hipMalloc((void**)&g.recA, want * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&g.recB, want * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&g.recC, want * sizeof(float2)));
+    HIP_TRY(hipMalloc((void**)&g.rec, 4 * want * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc3)));
     h->cell_capacity = want;
   }
@@ -227,7 +225,7 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   void* dev[] = {h->d_bounds, h->d_counters, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
-                 h->d_s[0], h->d_s[1], h->d_s[2], h->grid.recA, h->grid.recB, h->grid.recC, h->grid.acc};
+                 h->d_s[0], h->d_s[1], h->d_s[2], h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small};
   for (void* p : host) if (p) (void)hipHostFree(p);
@@ -259,28 +257,25 @@ int32_t ndt3d_get_grid(ndt3d_handle* h, int32_t* count, float* mean_xyz, float* 
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   HIP_TRY(hipSetDevice(h->device));
   const size_t nc = (size_t)h->grid.W * h->grid.H * h->grid.D;
-  float4* a = new (std::nothrow) float4[nc];
-  float4* b = new (std::nothrow) float4[nc];
-  float2* c = new (std::nothrow) float2[nc];
+  float4* rec = new (std::nothrow) float4[4 * nc];
   ndt::CellAcc3* acc = count ? new (std::nothrow) ndt::CellAcc3[nc] : nullptr;
-  int32_t rc = (!a || !b || !c || (count && !acc)) ? NDT_ERR_ALLOC : NDT_OK;
-  if (rc == NDT_OK && hipMemcpyAsync(a, h->grid.recA, nc * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
-  if (rc == NDT_OK && hipMemcpyAsync(b, h->grid.recB, nc * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
-  if (rc == NDT_OK && hipMemcpyAsync(c, h->grid.recC, nc * sizeof(float2), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
+  int32_t rc = (!rec || (count && !acc)) ? NDT_ERR_ALLOC : NDT_OK;
+  if (rc == NDT_OK && hipMemcpyAsync(rec, h->grid.rec, 4 * nc * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
   if (rc == NDT_OK && acc && hipMemcpyAsync(acc, h->grid.acc, nc * sizeof(ndt::CellAcc3), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = NDT_ERR_HIP;
   if (rc == NDT_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = NDT_ERR_HIP;
   if (rc == NDT_OK) {
     for (size_t k = 0; k < nc; ++k) {
-      const bool valid = a[k].w > 0.f;
+      const float4 a = rec[4 * k], b = rec[4 * k + 1], c = rec[4 * k + 2];
+      const bool valid = a.w > 0.f;
       if (count) count[k] = (int32_t)acc[k].n;
-      if (mean_xyz) { mean_xyz[3 * k] = valid ? a[k].x : 0.f; mean_xyz[3 * k + 1] = valid ? a[k].y : 0.f; mean_xyz[3 * k + 2] = valid ? a[k].z : 0.f; }
+      if (mean_xyz) { mean_xyz[3 * k] = valid ? a.x : 0.f; mean_xyz[3 * k + 1] = valid ? a.y : 0.f; mean_xyz[3 * k + 2] = valid ? a.z : 0.f; }
       if (icov6) {
-        icov6[6 * k] = b[k].x; icov6[6 * k + 1] = b[k].y; icov6[6 * k + 2] = b[k].z; icov6[6 * k + 3] = b[k].w;
-        icov6[6 * k + 4] = c[k].x; icov6[6 * k + 5] = c[k].y;
+        icov6[6 * k] = b.x; icov6[6 * k + 1] = b.y; icov6[6 * k + 2] = b.z; icov6[6 * k + 3] = b.w;
+        icov6[6 * k + 4] = c.x; icov6[6 * k + 5] = c.y;
       }
     }
   }
-  delete[] a; delete[] b; delete[] c; delete[] acc;
+  delete[] rec; delete[] acc;
   return rc;
 }
 

@@ -21,9 +21,8 @@ struct Grid3Dev {
   float ox, oy, oz, inv_c;
   int W, H, D, pad;
   double cell, fix_scale;
-  float4* recA;   // mean_x, mean_y, mean_z, n (0 = invalid)
-  float4* recB;   // Sigma^-1: xx xy xz yy
-  float2* recC;   //           yz zz
+  float4* rec;    // one 64-byte line per cell: rec[4k] = (mean_x, mean_y, mean_z, n; 0 = invalid),
+                  // rec[4k+1] = Sigma^-1 (xx xy xz yy), rec[4k+2] = (yz zz 0 0), rec[4k+3] unused
   CellAcc3* acc;
 };
 
@@ -179,9 +178,9 @@ __global__ __launch_bounds__(kBlock) void k_finalise3(Grid3Dev g, int min_points
   const unsigned long long valid_mask = __ballot(ok);      // one atomic per wave
   if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(valid_mask | (1ull << 63)) && valid_mask)
     atomicAdd(&counters[0], (int)__popcll(valid_mask));
-  g.recA[k] = ra;
-  g.recB[k] = rb;
-  g.recC[k] = rc;
+  g.rec[4 * k] = ra;
+  g.rec[4 * k + 1] = rb;
+  g.rec[4 * k + 2] = make_float4(rc.x, rc.y, 0.f, 0.f);
 }
 
 // ---------------------------------------------------------------------------- solve (6x6)
@@ -307,8 +306,8 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     for (int v = 0; v < 8; ++v)
       pv[v] = *reinterpret_cast<const float4*>(part + (wave * 8 + v) * kMaxBlocks + lane * 4);
   }
-  asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.oz), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.D), "s"(G.recA),
-               "s"(G.recB), "s"(G.recC), "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations),
+  asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.oz), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.D), "s"(G.rec),
+               "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations),
                "s"(prm.eps_trans), "s"(prm.eps_rot), "s"(prm.step_max_trans), "s"(prm.step_max_rot), "s"(ps_iter),
                "s"(ps_done), "s"(ps_have), "s"(fixed_iterations));
   const int stride = kMaxBlocks * kBlock;
@@ -407,9 +406,9 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     const bool in = (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
     const int key = in ? (((int)fz * G.H + (int)fy) * G.W + (int)fx) : 0;
     if (!in) { px = py = pz = 0.f; x = y = z = 0.f; }
-    const float4 A4 = G.recA[key];
-    const float4 B4 = G.recB[key];
-    const float2 C2 = G.recC[key];
+    const float4 A4 = G.rec[4 * key];
+    const float4 B4 = G.rec[4 * key + 1];
+    const float4 C2 = G.rec[4 * key + 2];
     const bool hit = in & (A4.w > 0.f);
     const float qx = px - A4.x, qy = py - A4.y, qz = pz - A4.z;
     const float cxx = B4.x, cxy = B4.y, cxz = B4.z, cyy = B4.w, cyz = C2.x, czz = C2.y;
