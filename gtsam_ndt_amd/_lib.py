@@ -43,7 +43,7 @@ class Params2D(C.Structure):
         ("step_max_trans", C.c_double),
         ("step_max_rot", C.c_double),
         ("min_hits", C.c_int32),
-        ("reserved", C.c_int32),
+        ("overlap_grids", C.c_int32),
     ]
 
 

@@ -65,6 +65,7 @@ int32_t check_params(const ndt2d_params* p) {
     return NDT_ERR_INVALID_ARG;
   if (!(p->step_max_trans > 0.0) || !(p->step_max_rot > 0.0)) return NDT_ERR_INVALID_ARG;
   if (!(p->d1 > 0.0) || !(p->d2 > 0.0) || !std::isfinite(p->d1) || !std::isfinite(p->d2)) return NDT_ERR_INVALID_ARG;
+  if (p->overlap_grids != 0 && p->overlap_grids != 1 && p->overlap_grids != 4) return NDT_ERR_INVALID_ARG;
   return NDT_OK;
 }
 
@@ -92,7 +93,7 @@ int stream_blocks(size_t n) {   // streaming kernels: up to 8 blocks per CU
 int32_t upload_static(ndt2d_handle* h);
 
 int32_t finalise_grid(ndt2d_handle* h) {
-  const size_t ncell = (size_t)h->grid.W * h->grid.H;
+  const size_t ncell = (size_t)h->grid.W * h->grid.H * h->grid.ngrid;
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
   hipLaunchKernelGGL(k_finalise, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      h->stream, h->grid, h->prm.min_points, h->prm.eig_ratio, h->d_counters);
@@ -134,10 +135,20 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
     set_error("target extent / cell_size needs more than 2^27 cells");
     return NDT_ERR_CAPACITY;
   }
-  g.W = (int)kx + 2;
-  g.H = (int)ky + 2;
+  // overlapping grids: origins move down by half a cell, one extra column/row covers the maximum
+  g.ngrid = h->prm.overlap_grids == 4 ? 4 : 1;
+  g.pad = 0;
+  const int extra = g.ngrid > 1 ? 1 : 0;
+  g.W = (int)kx + 2 + extra;
+  g.H = (int)ky + 2 + extra;
+  static const double kShift[4][2] = {{0.0, 0.0}, {0.5, 0.0}, {0.0, 0.5}, {0.5, 0.5}};
+  for (int q = 0; q < kMaxGrids; ++q) {
+    g.gx[q] = (float)((std::floor((double)xmin / c) - 1.0 - kShift[q][0]) * c);
+    g.gy[q] = (float)((std::floor((double)ymin / c) - 1.0 - kShift[q][1]) * c);
+  }
   g.fix_scale = std::ldexp(1.0, kFixShift) / c;
-  const size_t ncell = (size_t)g.W * g.H;
+  const size_t ncell = (size_t)g.W * g.H * g.ngrid;     // all grids, back to back
+  if (ncell > kMaxCells) { set_error("target extent / cell_size needs more than 2^27 cells"); return NDT_ERR_CAPACITY; }
   if (ncell > h->cell_capacity) {
     if (g.rec) (void)hipFree(g.rec);
     if (g.acc) (void)hipFree(g.acc);
@@ -183,10 +194,15 @@ int32_t upload_static(ndt2d_handle* h) {
 }
 
 void launch_iter(ndt2d_handle* h, int blocks, int k) {
-  if (h->prm.hessian_mode == NDT_HESSIAN_NEWTON)
-    hipLaunchKernelGGL((k_iterate<1, 0, kIterThreads>), dim3(blocks), dim3(kIterThreads), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
-  else
-    hipLaunchKernelGGL((k_iterate<0, 0, kIterThreads>), dim3(blocks), dim3(kIterThreads), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
+  const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON, four = h->prm.overlap_grids == 4;
+#define NDT_LAUNCH_ITER(MODE, NG) \
+  hipLaunchKernelGGL((k_iterate<MODE, 0, kIterThreads, NG>), dim3(blocks), dim3(kIterThreads), 0, h->stream, \
+                     h->d_static, h->d_call, h->d_dyn, k & 1)
+  if (newton && four) NDT_LAUNCH_ITER(1, 4);
+  else if (newton) NDT_LAUNCH_ITER(1, 1);
+  else if (four) NDT_LAUNCH_ITER(0, 4);
+  else NDT_LAUNCH_ITER(0, 1);
+#undef NDT_LAUNCH_ITER
 }
 
 void drop_graph(ndt2d_handle* h) {
@@ -463,7 +479,7 @@ int32_t ndt2d_get_grid(ndt2d_handle* h, int32_t* count, float* mean_xy, float* i
   if (!h) return NDT_ERR_INVALID_ARG;
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   HIP_TRY(hipSetDevice(h->device));
-  const size_t ncell = (size_t)h->grid.W * h->grid.H;
+  const size_t ncell = (size_t)h->grid.W * h->grid.H;          // grid 0 (the unshifted one)
   float4* rec = new (std::nothrow) float4[2 * ncell];
   CellAcc* acc = count ? new (std::nothrow) CellAcc[ncell] : nullptr;
   int32_t rc = NDT_OK;

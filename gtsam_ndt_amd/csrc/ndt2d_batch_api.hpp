@@ -74,6 +74,7 @@ int32_t ndt2d_batch_create(const ndt2d_params* p, int32_t device_id, ndt2d_batch
   *out = nullptr;
   const int32_t st = check_params(p);
   if (st != NDT_OK) return st;
+  if (p->overlap_grids == 4) { set_error("overlapping grids are implemented on the single-pair path only"); return NDT_ERR_INVALID_ARG; }
   const int ndev = ndt_device_count();
   if (ndev <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }
   if (device_id < 0 || device_id >= ndev) return NDT_ERR_INVALID_ARG;

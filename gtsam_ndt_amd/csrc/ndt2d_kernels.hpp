@@ -29,9 +29,13 @@ struct CellAcc {
   unsigned int pad;
 };
 
+constexpr int kMaxGrids = 4;       // Biber's four half-cell-shifted grids (params.overlap_grids = 4)
+
 struct GridDev {
-  float ox, oy, inv_c, cell32;
+  float ox, oy, inv_c, cell32;   // origin of grid 0
   int W, H;
+  int ngrid, pad;                // 1 or 4; grid g's cells are [g*W*H, (g+1)*W*H) of rec / acc
+  float gx[kMaxGrids], gy[kMaxGrids];   // origin of grid g (gx[0] = ox, gy[0] = oy)
   double cell;       // params.cell_size
   double fix_scale;  // 2^kFixShift / cell
   float4* rec;       // one 32-byte record per cell = two float4: rec[2k] = (mean_x, mean_y, a, b),
@@ -177,25 +181,30 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float* __restrict__
                                                         GridDev g,
                                                         unsigned long long* __restrict__ n_outside) {
   unsigned int outside = 0;
+  const size_t ncell = (size_t)g.W * g.H;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const float px = x[i], py = y[i];
-    const float fx = (px - g.ox) * g.inv_c;
-    const float fy = (py - g.oy) * g.inv_c;
-    const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H);
-    if (in) {
-      const int ix = (int)fx, iy = (int)fy;
-      const int ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
-      const int uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
-      CellAcc* c = g.acc + ((size_t)iy * g.W + ix);
-      atomicAdd(&c->n, 1u);
-      atomicAdd((unsigned long long*)&c->sx, (unsigned long long)(long long)ux);
-      atomicAdd((unsigned long long*)&c->sy, (unsigned long long)(long long)uy);
-      atomicAdd((unsigned long long*)&c->sxx, prod64(ux, ux));
-      atomicAdd((unsigned long long*)&c->sxy, prod64(ux, uy));
-      atomicAdd((unsigned long long*)&c->syy, prod64(uy, uy));
-    } else {
-      outside++;
+    bool any = false;
+    for (int q = 0; q < g.ngrid; ++q) {
+      const float ox = g.gx[q], oy = g.gy[q];
+      const float fx = (px - ox) * g.inv_c;
+      const float fy = (py - oy) * g.inv_c;
+      const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H);
+      if (in) {
+        any = true;
+        const int ix = (int)fx, iy = (int)fy;
+        const int ux = fix_coord(px, cell_centre(ox, ix, g.cell), g.fix_scale);
+        const int uy = fix_coord(py, cell_centre(oy, iy, g.cell), g.fix_scale);
+        CellAcc* c = g.acc + (q * ncell + (size_t)iy * g.W + ix);
+        atomicAdd(&c->n, 1u);
+        atomicAdd((unsigned long long*)&c->sx, (unsigned long long)(long long)ux);
+        atomicAdd((unsigned long long*)&c->sy, (unsigned long long)(long long)uy);
+        atomicAdd((unsigned long long*)&c->sxx, prod64(ux, ux));
+        atomicAdd((unsigned long long*)&c->sxy, prod64(ux, uy));
+        atomicAdd((unsigned long long*)&c->syy, prod64(uy, uy));
+      }
     }
+    if (!any) outside++;
   }
   if (n_outside && outside) atomicAdd(n_outside, (unsigned long long)outside);
 }
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, 
                                                       int* __restrict__ counters /*[2]: valid, overflow*/) {
   const size_t ncell = (size_t)g.W * g.H;
   const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= ncell) return;
+  if (k >= ncell * g.ngrid) return;
   const CellAcc c = g.acc[k];
   float4 ra, rb;
   bool ok = false;
@@ -215,10 +224,11 @@ __global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, 
     ra = make_float4(0.f, 0.f, 0.f, 0.f);
     rb = make_float4(0.f, 0.f, 0.f, 0.f);
   } else if ((int)c.n >= min_points) {             // empty cells (the vast majority) skip everything
-    const unsigned int k32 = (unsigned int)k, w32 = (unsigned int)g.W;   // ncell <= 2^27: 32-bit div
+    const unsigned int w32 = (unsigned int)g.W, nc32 = (unsigned int)ncell;   // <= 2^27 cells: 32-bit div
+    const unsigned int q = (unsigned int)k / nc32, k32 = (unsigned int)k - q * nc32;
     const int ix = (int)(k32 % w32), iy = (int)(k32 / w32);
-    ok = finalise_sums((int)c.n, c.sx, c.sy, c.sxx, c.sxy, c.syy, cell_centre(g.ox, ix, g.cell),
-                       cell_centre(g.oy, iy, g.cell), g.fix_scale, min_points, eig_ratio, ra, rb);
+    ok = finalise_sums((int)c.n, c.sx, c.sy, c.sxx, c.sxy, c.syy, cell_centre(g.gx[q], ix, g.cell),
+                       cell_centre(g.gy[q], iy, g.cell), g.fix_scale, min_points, eig_ratio, ra, rb);
   } else {
     ra = make_float4(0.f, 0.f, 0.f, 0.f);
     rb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -400,15 +410,21 @@ struct PointRec {
 // one above the maximum), so every out-of-range, infinite or NaN point lands on an invalid
 // cell.  NaN/inf never reach the sums: coordinates are clamped to +-1e15 first (v_med3_f32
 // returns the finite bound for a NaN), which keeps every later product finite.
-__device__ __forceinline__ int point_key(const PoseF& P, float x, float y, bool live, PointRec& r) {
+__device__ __forceinline__ void image_point(const PoseF& P, float x, float y, PointRec& r) {
   x = __builtin_amdgcn_fmed3f(x, -1e15f, 1e15f);
   y = __builtin_amdgcn_fmed3f(y, -1e15f, 1e15f);
   r.px = fmaf(P.cs, x, fmaf(-P.sn, y, P.tx));
   r.py = fmaf(P.sn, x, fmaf(P.cs, y, P.ty));
-  int ix = floor_to_int((r.px - P.ox) * P.inv_c), iy = floor_to_int((r.py - P.oy) * P.inv_c);
+}
+__device__ __forceinline__ int image_key(const PoseF& P, float ox, float oy, const PointRec& r, bool live) {
+  int ix = floor_to_int((r.px - ox) * P.inv_c), iy = floor_to_int((r.py - oy) * P.inv_c);
   ix = clamp_index(ix, P.wm1);
   iy = clamp_index(iy, P.hm1);
   return live ? __mul24(iy, P.W) + ix : 0;                        // cell 0 is a guard cell; W, iy < 2^24
+}
+__device__ __forceinline__ int point_key(const PoseF& P, float x, float y, bool live, PointRec& r) {
+  image_point(P, x, y, r);
+  return image_key(P, P.ox, P.oy, r, live);
 }
 
 // a4 (2/2), global-memory grid: one 32-byte record per cell
@@ -488,7 +504,7 @@ __device__ __forceinline__ void copy_state(IterState* dst, const IterState* src,
 // requested up front in one batch, then the cell-record gather.
 // EXP is an ablation mask for tools/exp_iter.hip only (1: no reduce/solve, 2: no body,
 // 4: no epilogue tree, 8: empty); the library instantiates EXP = 0.
-template <int MODE, int EXP = 0, int THREADS = kBlock>
+template <int MODE, int EXP = 0, int THREADS = kBlock, int NG = 1>
 __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restrict__ st,
                                                     const AlignCall* __restrict__ call,
                                                     AlignDyn* __restrict__ dyn, int parity) {
@@ -601,10 +617,26 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
     if (i2 + stride < n) { xn1 = sx[i2 + stride]; yn1 = sy[i2 + stride]; }
     PointRec r0, r1;
     const bool two = (i + stride) < n;
-    lookup_point(P, rec, x, y, true, r0);
-    lookup_point(P, rec, x1, y1, two, r1);
-    accumulate_point<MODE>(P, r0, A);
-    accumulate_point<MODE>(P, r1, A);
+    if (NG == 1) {
+      lookup_point(P, rec, x, y, true, r0);
+      lookup_point(P, rec, x1, y1, two, r1);
+      accumulate_point<MODE>(P, r0, A);
+      accumulate_point<MODE>(P, r1, A);
+    } else {
+      // overlapping grids (Biber): the same image point scores against every grid
+      image_point(P, x, y, r0);
+      image_point(P, x1, y1, r1);
+      const int ncell = G.W * G.H;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        const int k0 = q * ncell + image_key(P, G.gx[q], G.gy[q], r0, true);
+        const int k1 = q * ncell + image_key(P, G.gx[q], G.gy[q], r1, two);
+        r0.A = rec[2 * k0]; r0.B = rec[2 * k0 + 1];
+        r1.A = rec[2 * k1]; r1.B = rec[2 * k1 + 1];
+        accumulate_point<MODE>(P, r0, A);
+        accumulate_point<MODE>(P, r1, A);
+      }
+    }
     x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
   }
   float acc[kNumAcc];

@@ -194,6 +194,7 @@ int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** ou
   *out = nullptr;
   const int32_t st = check_params(p);
   if (st != NDT_OK) return st;
+  if (p->overlap_grids == 4) { set_error("overlapping grids are a 2D option"); return NDT_ERR_INVALID_ARG; }
   if (p->hessian_mode != NDT_HESSIAN_GAUSS_NEWTON) { set_error("3D path implements the Gauss-Newton Hessian only"); return NDT_ERR_INVALID_ARG; }
   const int ndev = ndt_device_count();
   if (ndev <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }

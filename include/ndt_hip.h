@@ -66,7 +66,8 @@ typedef struct ndt2d_params {
   double step_max_trans;   /* step is scaled so |dt| <= step_max_trans     (row a8) */
   double step_max_rot;     /* ... and |dtheta| <= step_max_rot                     */
   int32_t min_hits;        /* fewer hits than this => NDT_TOO_FEW_HITS             */
-  int32_t reserved;
+  int32_t overlap_grids;   /* 0 or 1: one grid; 4: Biber's four grids shifted by half a cell, every
+                              point scores against all four (single-pair 2D path only)  */
 } ndt2d_params;
 
 /* ---- result (row a9) ------------------------------------------------------------ */

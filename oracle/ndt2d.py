@@ -58,6 +58,7 @@ class NdtParams:
     step_max_trans: float = 0.5
     step_max_rot: float = 0.2
     min_hits: int = 3
+    overlap: int = 1                   # 1: single grid; 4: Biber's four grids shifted by half a cell
 
 
 @dataclass
@@ -82,18 +83,25 @@ class Grid2D:
 
 
 # ----------------------------------------------------------------------------- a1
-def grid_geometry(tx: np.ndarray, ty: np.ndarray, cell: float):
+OVERLAP_SHIFTS = ((0.0, 0.0), (0.5, 0.0), (0.0, 0.5), (0.5, 0.5))   # in cells (Biber & Strasser 2003)
+
+
+def grid_geometry(tx: np.ndarray, ty: np.ndarray, cell: float, shift=(0.0, 0.0), extra: int = 0):
     """Origin/extent rule.  One guard cell below the minimum; the
-    extent is whatever the float32 key formula yields for the maximum, plus one."""
+    extent is whatever the float32 key formula yields for the maximum, plus one.  With
+    overlapping grids the origin moves down by `shift` cells and every grid gets one `extra`
+    column and row so that the shifted grids still cover the maximum with a guard cell."""
     c = float(cell)
     inv_c = np.float32(1.0 / c)
     xmin, xmax = np.float32(tx.min()), np.float32(tx.max())
     ymin, ymax = np.float32(ty.min()), np.float32(ty.max())
-    ox = np.float32((math.floor(float(xmin) / c) - 1.0) * c)
-    oy = np.float32((math.floor(float(ymin) / c) - 1.0) * c)
-    kx = int(np.floor((xmax - ox) * inv_c))      # float32 arithmetic
-    ky = int(np.floor((ymax - oy) * inv_c))
-    return ox, oy, inv_c, kx + 2, ky + 2
+    ox0 = np.float32((math.floor(float(xmin) / c) - 1.0) * c)
+    oy0 = np.float32((math.floor(float(ymin) / c) - 1.0) * c)
+    kx = int(np.floor((xmax - ox0) * inv_c))      # float32 arithmetic, on the unshifted grid
+    ky = int(np.floor((ymax - oy0) * inv_c))
+    ox = np.float32((math.floor(float(xmin) / c) - 1.0 - shift[0]) * c)
+    oy = np.float32((math.floor(float(ymin) / c) - 1.0 - shift[1]) * c)
+    return ox, oy, inv_c, kx + 2 + extra, ky + 2 + extra
 
 
 def cell_keys32(x: np.ndarray, y: np.ndarray, ox, oy, inv_c, W, H):
@@ -147,12 +155,19 @@ def finalise_cell(n: int, mx: float, my: float, m2xx: float, m2xy: float, m2yy: 
     return True, a, b, c
 
 
-def build_grid(tx: np.ndarray, ty: np.ndarray, prm: NdtParams) -> Grid2D:
+def build_grids(tx: np.ndarray, ty: np.ndarray, prm: NdtParams):
+    """The list of grids an alignment uses: one, or Biber's four half-cell-shifted ones."""
+    if prm.overlap <= 1:
+        return [build_grid(tx, ty, prm)]
+    return [build_grid(tx, ty, prm, shift=sh, extra=1) for sh in OVERLAP_SHIFTS]
+
+
+def build_grid(tx: np.ndarray, ty: np.ndarray, prm: NdtParams, shift=(0.0, 0.0), extra: int = 0) -> Grid2D:
     """Rows a1-a3.  Per-cell mean and centred second moment in float64 (two-pass form,
     equal to Welford's result up to float64 rounding), then finalise."""
     tx = np.ascontiguousarray(tx, dtype=np.float32)
     ty = np.ascontiguousarray(ty, dtype=np.float32)
-    ox, oy, inv_c, W, H = grid_geometry(tx, ty, prm.cell_size)
+    ox, oy, inv_c, W, H = grid_geometry(tx, ty, prm.cell_size, shift, extra)
     key, inside = cell_keys32(tx, ty, ox, oy, inv_c, W, H)
     assert inside.all()
     nc = W * H
@@ -230,7 +245,19 @@ def transform(sx, sy, pose, mirror32: bool):
     return px, py, -s * x - c * y, c * x - s * y
 
 
-def evaluate(grid: Grid2D, sx, sy, pose, prm: NdtParams, mirror32: bool = False):
+def evaluate(grid, sx, sy, pose, prm: NdtParams, mirror32: bool = False):
+    """One grid or a list of grids (overlapping grids: the terms of all grids are summed and
+    n_hit counts point-grid hits)."""
+    if isinstance(grid, (list, tuple)):
+        H = np.zeros((3, 3)); g = np.zeros(3); sc = 0.0; nh = 0
+        for gr in grid:
+            Hi, gi, si, ni = evaluate_one(gr, sx, sy, pose, prm, mirror32)
+            H += Hi; g += gi; sc += si; nh += ni
+        return H, g, sc, nh
+    return evaluate_one(grid, sx, sy, pose, prm, mirror32)
+
+
+def evaluate_one(grid: Grid2D, sx, sy, pose, prm: NdtParams, mirror32: bool = False):
     """Score, gradient and Hessian of f(p) = -sum_i d1 exp(-d2/2 q_i' S^-1 q_i) at pose p.
 
     Returns H (3x3), g (3), score (= -f, to be maximised), n_hit.
@@ -368,7 +395,8 @@ def align(grid: Grid2D, sx, sy, init_pose, prm: NdtParams, mirror32: bool = Fals
     of the LAST evaluation, i.e. at the pose before the final update."""
     pose = tuple(float(v) for v in init_pose)
     it = 0
-    if grid.n_valid < 1:
+    n_valid = sum(g.n_valid for g in grid) if isinstance(grid, (list, tuple)) else grid.n_valid
+    if n_valid < 1:
         return {"pose": pose, "H": np.zeros((3, 3)), "g": np.zeros(3), "score": 0.0,
                 "n_hit": 0, "iterations": 0, "status": NDT_TOO_FEW_CELLS}
     while True:

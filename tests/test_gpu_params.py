@@ -73,3 +73,32 @@ def test_far_from_origin_and_tiny_inputs(gpu_lib, pair):
         m.set_target(d["tx"][:3], d["ty"][:3])
         r = m.align(d["sx"][:5], d["sy"][:5], d["init"])
         assert r.status in (L.NDT_TOO_FEW_CELLS, L.NDT_TOO_FEW_HITS, L.NDT_OK, L.NDT_NOT_CONVERGED, L.NDT_DEGENERATE_HESSIAN)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_overlapping_grids_match_oracle(gpu_lib, pair, mode):
+    """Biber's four half-cell-shifted grids (params.overlap_grids = 4) on the single-pair path."""
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMatcher2D
+    from oracle import ndt2d as o
+    d = pair
+    prm = o.NdtParams(overlap=4, hessian_mode=mode)
+    grids = o.build_grids(d["tx"], d["ty"], prm)
+    ref = o.align(grids, d["sx"], d["sy"], d["init"], prm)
+    with NdtMatcher2D(overlap_grids=4, hessian_mode=mode) as m:
+        info = m.set_target(d["tx"], d["ty"])
+        assert (info.width, info.height) == (grids[0].W, grids[0].H)
+        assert info.n_valid == sum(g.n_valid for g in grids)
+        count, mean, icov = m.grid()                       # grid 0, the unshifted one
+        np.testing.assert_array_equal(count.astype(np.int64), grids[0].count)
+        for pose in (d["init"], d["pose"]):
+            H, g, s, nh = m.evaluate(d["sx"], d["sy"], pose)
+            Hm, gm, sm, nm = o.evaluate(grids, d["sx"], d["sy"], pose, prm, mirror32=True)
+            assert abs(nh - nm) <= 6 and abs(s - sm) / sm < 5e-5
+            assert np.abs(H - Hm).max() / np.abs(Hm).max() < 5e-5
+        r = m.align(d["sx"], d["sy"], d["init"])
+    assert r.status == 0 == ref["status"]
+    e = np.abs(np.array(r.pose) - np.array(ref["pose"]))
+    assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 1e-4
+    with pytest.raises(L.NdtError):
+        NdtBatch2D(overlap_grids=4)

@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dsx, sx.data(), n_s * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dsy, sy.data(), n_s * 4, hipMemcpyHostToDevice));
   GridDev g{};
   g.cell = 0.5; g.cell32 = 0.5f; g.inv_c = 2.f; g.ox = -101.f; g.oy = -101.f; g.W = 404; g.H = 404;
+  g.ngrid = 1; g.gx[0] = g.ox; g.gy[0] = g.oy;
   g.fix_scale = std::ldexp(1.0, kFixShift) / 0.5;
   const size_t nc = (size_t)g.W * g.H;
   CK(hipMalloc(&g.rec, 2 * nc * sizeof(float4))); CK(hipMalloc(&g.acc, nc * sizeof(CellAcc)));
