@@ -12,6 +12,7 @@
 
 #include "../../include/ndt_hip.h"
 #include "ndt2d_kernels.hpp"
+#include "ndt2d_build.hpp"
 #include "ndt_host.hpp"
 
 using namespace ndt;
@@ -41,6 +42,10 @@ struct ndt2d_handle {
   IterState* h_state = nullptr;            // pinned
   int last_parity = 0;
   bool pending = false;
+  // binned grid build scratch (ndt2d_build.hpp)
+  float* d_bx = nullptr; float* d_by = nullptr; size_t bcap = 0;
+  unsigned int* d_tiles = nullptr; size_t tile_cap = 0;   // total[nt] | start[nt+1] | cursor[nt]
+  bool use_binned_build = true;
   // hipGraph of the launch chain (launch-bound inner loop: one replay instead of K+1 launches)
   hipGraphExec_t graph_exec = nullptr;
   hipGraph_t graph = nullptr;
@@ -106,6 +111,74 @@ int32_t finalise_grid(ndt2d_handle* h) {
   return NDT_OK;
 }
 
+// a2 + a3 for n points: binned LDS build when the tile histogram fits in LDS (always, below
+// ~2.9 km x 2.9 km at 0.5 m cells), else scattered global atomics + k_finalise.  merge = add to
+// the cached sums (incremental submap update) instead of starting from zero.
+int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n, bool merge,
+                                unsigned long long* h_outside) {
+  GridDev& g = h->grid;
+  const size_t ncell1 = (size_t)g.W * g.H, ncell = ncell1 * g.ngrid;
+  const int ntx = (g.W + kTile - 1) >> kTileShift, nty = (g.H + kTile - 1) >> kTileShift;
+  const long long ntile_ll = (long long)ntx * nty;
+  HIP_TRY(hipMemsetAsync(h->d_outside, 0, sizeof(unsigned long long), h->stream));
+  if (h->use_binned_build && ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull) {
+    const int ntile = (int)ntile_ll;
+    if (n > h->bcap) {
+      if (h->d_bx) (void)hipFree(h->d_bx);
+      if (h->d_by) (void)hipFree(h->d_by);
+      h->d_bx = h->d_by = nullptr; h->bcap = 0;
+      const size_t want = n + n / 4 + 1024;
+      HIP_TRY(hipMalloc((void**)&h->d_bx, want * sizeof(float)));
+      HIP_TRY(hipMalloc((void**)&h->d_by, want * sizeof(float)));
+      h->bcap = want;
+    }
+    const size_t tneed = 3 * (size_t)ntile + 4;
+    if (tneed > h->tile_cap) {
+      if (h->d_tiles) (void)hipFree(h->d_tiles);
+      h->d_tiles = nullptr; h->tile_cap = 0;
+      HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
+      h->tile_cap = tneed;
+    }
+    unsigned int* d_total = h->d_tiles;
+    unsigned int* d_start = h->d_tiles + ntile;
+    unsigned int* d_cursor = h->d_tiles + 2 * ntile + 1;
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
+    const size_t chunk = (size_t)kBinThreads * kBinPerThread;
+    size_t nb = (n + chunk - 1) / chunk;
+    if (nb > 1024) nb = 1024;
+    for (int q = 0; q < g.ngrid; ++q) {
+      BinGeom bg{g.gx[q], g.gy[q], g.inv_c, g.W, g.H, ntx, ntile};
+      HIP_TRY(hipMemsetAsync(d_total, 0, ntile * sizeof(unsigned int), h->stream));
+      hipLaunchKernelGGL(k_tile_count, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream,
+                         d_x, d_y, n, bg, d_total, q == 0 ? h->d_outside : (unsigned long long*)nullptr);
+      hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile);
+      hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int),
+                         h->stream, d_x, d_y, n, bg, d_cursor, h->d_bx, h->d_by);
+      hipLaunchKernelGGL(k_tile_accumulate, dim3(ntile), dim3(kBinThreads), 0, h->stream, h->d_bx, h->d_by, d_start, g, q,
+                         ntx, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+      HIP_TRY(hipGetLastError());
+    }
+    int* hc = (int*)h->h_small;
+    unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 32);
+    HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->n_valid = hc[0];
+    if (h_outside) *h_outside = *ho;
+    if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+    return NDT_OK;
+  }
+  // fallback: scattered global atomics
+  if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc), h->stream));
+  hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, g, h->d_outside);
+  HIP_TRY(hipGetLastError());
+  unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 32);
+  HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  const int32_t st = finalise_grid(h);
+  if (h_outside) *h_outside = *ho;
+  return st;
+}
+
 int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n) {
   h->has_target = false;
   if (n == 0) return NDT_ERR_INVALID_ARG;
@@ -158,13 +231,8 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
     HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc)));
     h->cell_capacity = want;
   }
-  // a2: exact per-cell sums
-  HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc), h->stream));
-  hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, g,
-                     (unsigned long long*)nullptr);
-  HIP_TRY(hipGetLastError());
-  // a3
-  const int32_t st = finalise_grid(h);
+  // a2 + a3
+  const int32_t st = accumulate_and_finalise(h, d_x, d_y, n, /*merge=*/false, nullptr);
   if (st != NDT_OK) return st;
   h->n_points = n;
   h->has_target = true;
@@ -406,6 +474,7 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
   { const char* e = std::getenv("NDT_DEBUG_NO_GRAPH"); h->use_graph = !(e && e[0] == '1'); }
+  { const char* e = std::getenv("NDT_DEBUG_ATOMIC_BUILD"); h->use_binned_build = !(e && e[0] == '1'); }
   *out = h;
   return NDT_OK;
 }
@@ -415,7 +484,7 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
-  void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
+  void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
                  h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small};
@@ -452,15 +521,11 @@ int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y,
   if (st != NDT_OK) return st;
   HIP_TRY(hipMemcpyAsync(h->d_tx, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_ty, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_outside, 0, sizeof(unsigned long long), h->stream));
-  hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, h->d_tx, h->d_ty, n,
-                     h->grid, h->d_outside);
-  HIP_TRY(hipGetLastError());
-  unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 32);
-  HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-  const int32_t fs = finalise_grid(h);
-  if (n_outside) *n_outside = (size_t)*ho;
+  unsigned long long outside = 0;
+  const int32_t fs = accumulate_and_finalise(h, h->d_tx, h->d_ty, n, /*merge=*/true, &outside);
+  if (n_outside) *n_outside = (size_t)outside;
   if (fs != NDT_OK) { h->has_target = false; return fs; }
+  unsigned long long* ho = &outside;
   h->n_points += n - (size_t)*ho;
   return upload_static(h);
 }

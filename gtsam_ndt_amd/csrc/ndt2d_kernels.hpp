@@ -92,11 +92,22 @@ __global__ __launch_bounds__(kBlock) void k_bounds(const float* __restrict__ x,
                                                     const float* __restrict__ y, size_t n,
                                                     unsigned int* __restrict__ out /*[4]*/) {
   float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const float a = x[i], b = y[i];
-    if (isfinite(a) && isfinite(b)) {
-      xmin = fminf(xmin, a); xmax = fmaxf(xmax, a);
-      ymin = fminf(ymin, b); ymax = fmaxf(ymax, b);
+  // 8 points in flight per thread: a one-point loop pays the memory latency per trip
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += 8 * stride) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t ii = i + u * stride;
+      a[u] = ii < n ? x[ii] : NAN;
+      b[u] = ii < n ? y[ii] : NAN;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (isfinite(a[u]) && isfinite(b[u])) {
+        xmin = fminf(xmin, a[u]); xmax = fmaxf(xmax, a[u]);
+        ymin = fminf(ymin, b[u]); ymax = fmaxf(ymax, b[u]);
+      }
     }
   }
   xmin = wave_min(xmin); xmax = wave_max(xmax);

@@ -201,3 +201,36 @@ def test_edge_cases(Matcher, gpu_lib):
         assert r.status in (L.NDT_TOO_FEW_HITS, L.NDT_DEGENERATE_HESSIAN, L.NDT_OK, L.NDT_NOT_CONVERGED)
         r = m.align(d["sx"][:777], d["sy"][:777], d["init"])
         assert np.isfinite(r.pose).all()
+
+
+def test_binned_build_equals_atomic_build(Matcher, monkeypatch):
+    """The LDS-binned grid build (fast path) and the scattered-global-atomic build produce the
+    same exact sums, hence bit-identical records - for a one-shot build, an incremental update
+    and overlapping grids, at the full 1M-point size."""
+    d = synth.make_pair(3)
+    half = len(d["tx"]) // 2
+    ext = np.unique([np.argmin(d["tx"]), np.argmax(d["tx"]), np.argmin(d["ty"]), np.argmax(d["ty"])])
+    first = np.union1d(np.arange(half), ext)
+    rest = np.setdiff1d(np.arange(len(d["tx"])), first)
+    out = {}
+    for name, env in (("binned", "0"), ("atomic", "1")):
+        monkeypatch.setenv("NDT_DEBUG_ATOMIC_BUILD", env)
+        with Matcher() as m:
+            info = m.set_target(d["tx"], d["ty"])
+            full = m.grid() + (info.n_valid,)
+            m.set_target(d["tx"][first], d["ty"][first])
+            assert m.add_target_points(d["tx"][rest], d["ty"][rest]) == 0
+            inc = m.grid()
+            assert m.add_target_points(d["tx"][:10] + 1e4, d["ty"][:10]) == 10      # outside: counted, ignored
+        with Matcher(overlap_grids=4) as m:
+            ov = m.set_target(d["tx"][:200000], d["ty"][:200000]).n_valid
+            r = m.align(d["sx"], d["sy"], d["init"])
+        out[name] = (full, inc, ov, r.pose)
+    (fa, ia, oa, pa), (fb, ib, ob, pb) = out["binned"], out["atomic"]
+    for u, v in zip(fa[:3], fb[:3]):
+        np.testing.assert_array_equal(u, v)
+    assert fa[3] == fb[3] and oa == ob and pa == pb
+    for u, v in zip(ia, ib):
+        np.testing.assert_array_equal(u, v)
+    for u, v in zip(fa[:3], ia):
+        np.testing.assert_array_equal(u, v)
