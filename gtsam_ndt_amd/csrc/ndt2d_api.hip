@@ -287,13 +287,11 @@ int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
       h->graph_mode == h->prm.hessian_mode)
     return NDT_OK;
   drop_graph(h);
-  HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-  for (int k = 0; k < launches; ++k) launch_iter(h, blocks, k);
-  hipGraph_t g = nullptr;
-  const hipError_t e = hipStreamEndCapture(h->stream, &g);
-  if (e != hipSuccess || !g) { set_error("hipStreamEndCapture failed"); (void)hipGetLastError(); return NDT_ERR_HIP; }
-  h->graph = g;
-  HIP_TRY(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+  const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON, four = h->prm.overlap_grids == 4;
+  const void* func = newton ? (four ? (const void*)&k_iterate<1, 0, kIterThreads, 4> : (const void*)&k_iterate<1, 0, kIterThreads, 1>)
+                            : (four ? (const void*)&k_iterate<0, 0, kIterThreads, 4> : (const void*)&k_iterate<0, 0, kIterThreads, 1>);
+  HIP_TRY(build_chain_graph(func, dim3(blocks), dim3(kIterThreads), (void*)h->d_static, (void*)h->d_call, (void*)h->d_dyn,
+                            launches, &h->graph, &h->graph_exec));
   h->graph_launches = launches; h->graph_blocks = blocks; h->graph_mode = h->prm.hessian_mode;
   return NDT_OK;
 }

@@ -1,6 +1,7 @@
 // C-ABI of the 3D SE(3) variant (included at the end of ndt2d_api.hip: one translation unit).
 #pragma once
 #include "ndt3d_kernels.hpp"
+#include "ndt3d_build.hpp"
 
 struct ndt3d_handle {
   int device = 0;
@@ -14,6 +15,8 @@ struct ndt3d_handle {
   int* d_counters = nullptr;          // [2]
   void* h_small = nullptr;            // pinned 64 B
   float *d_t[3] = {nullptr, nullptr, nullptr}; size_t tcap = 0;
+  float *d_b[3] = {nullptr, nullptr, nullptr}; size_t bcap = 0;      // binned build scratch
+  unsigned int* d_tiles = nullptr; size_t tile_cap = 0;
   float *d_s[3] = {nullptr, nullptr, nullptr}; size_t scap = 0;
   ndt::AlignStatic3* d_static = nullptr;
   ndt::AlignCall3* d_call = nullptr;
@@ -93,13 +96,44 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
     HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc3)));
     h->cell_capacity = want;
   }
-  HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));
-  hipLaunchKernelGGL(k_accumulate3, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, g);
-  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
-  hipLaunchKernelGGL(k_finalise3, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, g,
-                     h->prm.min_points, h->prm.eig_ratio, h->d_counters);
-  HIP_TRY(hipGetLastError());
+  const int ntx = (g.W + (1 << kT3x) - 1) >> kT3x, nty = (g.H + (1 << kT3y) - 1) >> kT3y, ntz = (g.D + (1 << kT3z) - 1) >> kT3z;
+  const long long ntile_ll = (long long)ntx * nty * ntz;
+  if (ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull) {
+    // binned build (ndt3d_build.hpp)
+    const int ntile = (int)ntile_ll;
+    int32_t st = ensure3(h->d_b, &h->bcap, n);
+    if (st != NDT_OK) return st;
+    const size_t tneed = 3 * (size_t)ntile + 4;
+    if (tneed > h->tile_cap) {
+      if (h->d_tiles) (void)hipFree(h->d_tiles);
+      h->d_tiles = nullptr; h->tile_cap = 0;
+      HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
+      h->tile_cap = tneed;
+    }
+    unsigned int* d_total = h->d_tiles;
+    unsigned int* d_start = h->d_tiles + ntile;
+    unsigned int* d_cursor = h->d_tiles + 2 * ntile + 1;
+    const BinGeom3 bg{g.ox, g.oy, g.oz, g.inv_c, g.W, g.H, g.D, ntx, nty, ntile};
+    size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
+    if (nb > 1024) nb = 1024;
+    HIP_TRY(hipMemsetAsync(d_total, 0, ntile * sizeof(unsigned int), h->stream));
+    hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
+                       dz, n, bg, d_total);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile);
+    hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
+                       dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2]);
+    hipLaunchKernelGGL(k_tile_accumulate3, dim3(ntile), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1], h->d_b[2],
+                       d_start, g, ntx, nty, h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));
+    hipLaunchKernelGGL(k_accumulate3, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, g);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_finalise3, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, g,
+                       h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+    HIP_TRY(hipGetLastError());
+  }
   int* hc = (int*)h->h_small;
   HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -115,14 +149,8 @@ int32_t ensure_graph3(ndt3d_handle* h, int launches) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   h->graph_exec = nullptr; h->graph = nullptr; h->graph_launches = 0;
-  HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-  for (int k = 0; k < launches; ++k)
-    hipLaunchKernelGGL(k_iterate3, dim3(kMaxBlocks), dim3(kBlock), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
-  hipGraph_t g = nullptr;
-  const hipError_t e = hipStreamEndCapture(h->stream, &g);
-  if (e != hipSuccess || !g) { set_error("hipStreamEndCapture failed"); (void)hipGetLastError(); return NDT_ERR_HIP; }
-  h->graph = g;
-  HIP_TRY(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+  HIP_TRY(build_chain_graph((const void*)&k_iterate3, dim3(kMaxBlocks), dim3(kBlock), (void*)h->d_static, (void*)h->d_call,
+                            (void*)h->d_dyn, launches, &h->graph, &h->graph_exec));
   h->graph_launches = launches;
   return NDT_OK;
 }
@@ -226,7 +254,7 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   void* dev[] = {h->d_bounds, h->d_counters, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
-                 h->d_s[0], h->d_s[1], h->d_s[2], h->grid.rec, h->grid.acc};
+                 h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small};
   for (void* p : host) if (p) (void)hipHostFree(p);

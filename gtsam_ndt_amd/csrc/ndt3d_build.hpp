@@ -1,0 +1,150 @@
+// Binned 3D voxel-grid build: the 3D twin of ndt2d_build.hpp (8 x 8 x 4-voxel tiles).  The
+// atomic path (k_accumulate3) suffers from same-address contention on floor / ceiling voxels
+// (thousands of points per voxel); here that contention is confined to LDS.
+#pragma once
+#include "ndt2d_build.hpp"
+#include "ndt3d_kernels.hpp"
+
+namespace ndt {
+
+constexpr int kT3x = 3, kT3y = 3, kT3z = 2;                        // log2 tile edge: 8 x 8 x 4
+constexpr int kTile3Cells = 1 << (kT3x + kT3y + kT3z);             // 256
+
+struct BinGeom3 {
+  float ox, oy, oz, inv_c;
+  int W, H, D, ntx, nty, ntile;
+};
+
+__device__ __forceinline__ int tile_of3(const BinGeom3& g, float px, float py, float pz) {
+  const float fx = (px - g.ox) * g.inv_c, fy = (py - g.oy) * g.inv_c, fz = (pz - g.oz) * g.inv_c;
+  const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H) & (fz >= 0.f) & (fz < (float)g.D);
+  return in ? ((((int)fz >> kT3z) * g.nty + ((int)fy >> kT3y)) * g.ntx + ((int)fx >> kT3x)) : -1;
+}
+
+__global__ __launch_bounds__(kBinThreads) void k_tile_count3(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ z, size_t n, BinGeom3 g,
+                                                              unsigned int* __restrict__ tile_total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int s_hist[];
+  for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) s_hist[t] = 0u;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * kBinThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kBinThreads) {
+    const int t = tile_of3(g, x[i], y[i], z[i]);
+    if (t >= 0) atomicAdd(&s_hist[t], 1u);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) {
+    const unsigned int c = s_hist[t];
+    if (c) atomicAdd(&tile_total[t], c);
+  }
+}
+
+__global__ __launch_bounds__(kBinThreads) void k_tile_scatter3(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ z, size_t n, BinGeom3 g,
+                                                                unsigned int* __restrict__ tile_cursor,
+                                                                float* __restrict__ bx, float* __restrict__ by,
+                                                                float* __restrict__ bz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int s_mem[];
+  unsigned int* s_hist = s_mem;
+  unsigned int* s_base = s_mem + g.ntile;
+  const size_t chunk = (size_t)kBinThreads * 4;
+  for (size_t base = (size_t)blockIdx.x * chunk; base < n; base += (size_t)gridDim.x * chunk) {
+    for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) s_hist[t] = 0u;
+    __syncthreads();
+    float px[4], py[4], pz[4];
+    int tile[4];
+    unsigned int rank[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t i = base + (size_t)u * kBinThreads + threadIdx.x;
+      px[u] = i < n ? x[i] : NAN; py[u] = i < n ? y[i] : NAN; pz[u] = i < n ? z[i] : NAN;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      tile[u] = tile_of3(g, px[u], py[u], pz[u]);
+      rank[u] = tile[u] >= 0 ? atomicAdd(&s_hist[tile[u]], 1u) : 0u;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) {
+      const unsigned int c = s_hist[t];
+      s_base[t] = c ? atomicAdd(&tile_cursor[t], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (tile[u] >= 0) {
+        const unsigned int dst = s_base[tile[u]] + rank[u];
+        bx[dst] = px[u]; by[dst] = py[u]; bz[dst] = pz[u];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// per tile: LDS sums, then the finalise of k_finalise3 (shared device function below)
+__device__ __forceinline__ bool finalise_sums3(const CellAcc3& c, double cx, double cy, double cz, double fix_scale,
+                                               int min_points, double eig_ratio, float4& ra, float4& rb, float4& rc);
+
+__global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* __restrict__ bx, const float* __restrict__ by,
+                                                                   const float* __restrict__ bz,
+                                                                   const unsigned int* __restrict__ tile_start, Grid3Dev g,
+                                                                   int ntx, int nty, int min_points, double eig_ratio,
+                                                                   int* __restrict__ counters) {
+  __shared__ unsigned int s_n[kTile3Cells];
+  __shared__ unsigned long long s_sum[9][kTile3Cells];
+  const int tile = blockIdx.x;
+  const int tx0 = (tile % ntx) << kT3x, ty0 = ((tile / ntx) % nty) << kT3y, tz0 = (tile / (ntx * nty)) << kT3z;
+  for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
+    s_n[c] = 0u;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s_sum[j][c] = 0ull;
+  }
+  __syncthreads();
+  const unsigned int p0 = tile_start[tile], p1 = tile_start[tile + 1];
+  for (unsigned int i = p0 + threadIdx.x; i < p1; i += kBinThreads) {
+    const float px = bx[i], py = by[i], pz = bz[i];
+    const int ix = (int)((px - g.ox) * g.inv_c), iy = (int)((py - g.oy) * g.inv_c), iz = (int)((pz - g.oz) * g.inv_c);
+    const int ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
+    const int uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
+    const int uz = fix_coord(pz, cell_centre(g.oz, iz, g.cell), g.fix_scale);
+    const int c = (((iz - tz0) << kT3y) + (iy - ty0) << kT3x) + (ix - tx0);
+    atomicAdd(&s_n[c], 1u);
+    atomicAdd(&s_sum[0][c], (unsigned long long)(long long)ux);
+    atomicAdd(&s_sum[1][c], (unsigned long long)(long long)uy);
+    atomicAdd(&s_sum[2][c], (unsigned long long)(long long)uz);
+    atomicAdd(&s_sum[3][c], prod64(ux, ux));
+    atomicAdd(&s_sum[4][c], prod64(ux, uy));
+    atomicAdd(&s_sum[5][c], prod64(ux, uz));
+    atomicAdd(&s_sum[6][c], prod64(uy, uy));
+    atomicAdd(&s_sum[7][c], prod64(uy, uz));
+    atomicAdd(&s_sum[8][c], prod64(uz, uz));
+  }
+  __syncthreads();
+  int nvalid = 0, nover = 0;
+  for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
+    const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
+    if (ix < g.W && iy < g.H && iz < g.D) {
+      const size_t k = ((size_t)iz * g.H + iy) * g.W + ix;
+      CellAcc3 a;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) a.s[j] = (long long)s_sum[j][c];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) a.ss[j] = (long long)s_sum[3 + j][c];
+      a.n = s_n[c]; a.pad = 0u;
+      float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+      if (a.n > kMaxCellCount) nover++;
+      else if (finalise_sums3(a, cell_centre(g.ox, ix, g.cell), cell_centre(g.oy, iy, g.cell), cell_centre(g.oz, iz, g.cell),
+                              g.fix_scale, min_points, eig_ratio, ra, rb, rc))
+        nvalid++;
+      g.acc[k] = a;
+      g.rec[4 * k] = ra; g.rec[4 * k + 1] = rb; g.rec[4 * k + 2] = rc;
+    }
+  }
+  nvalid = (int)wave_sum((float)nvalid);
+  nover = (int)wave_sum((float)nover);
+  if ((threadIdx.x & 63) == 0) {
+    if (nvalid) atomicAdd(&counters[0], nvalid);
+    if (nover) atomicAdd(&counters[1], nover);
+  }
+}
+
+}  // namespace ndt

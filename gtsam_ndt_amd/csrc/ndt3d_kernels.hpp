@@ -128,59 +128,66 @@ __device__ __forceinline__ void jacobi_rot(double& app, double& aqq, double& apq
   }
 }
 
+// sums -> (mean, n | Sigma^-1) for one voxel; false when the voxel is not usable
+__device__ __forceinline__ bool finalise_sums3(const CellAcc3& c, double cx, double cy, double cz, double fix_scale,
+                                               int min_points, double eig_ratio, float4& ra, float4& rb, float4& rc) {
+  const int n = (int)c.n;
+  if (n < min_points || n < 2) return false;
+  const double inv_s = 1.0 / fix_scale, dn = (double)n;
+  const double mx = fma((double)c.s[0] / dn, inv_s, cx);
+  const double my = fma((double)c.s[1] / dn, inv_s, cy);
+  const double mz = fma((double)c.s[2] / dn, inv_s, cz);
+  const double den = 1.0 / (dn * fix_scale * fix_scale * (dn - 1.0));
+  double axx = to_double(sub128(mul_s64(n, c.ss[0]), mul_s64(c.s[0], c.s[0]))) * den;
+  double axy = to_double(sub128(mul_s64(n, c.ss[1]), mul_s64(c.s[0], c.s[1]))) * den;
+  double axz = to_double(sub128(mul_s64(n, c.ss[2]), mul_s64(c.s[0], c.s[2]))) * den;
+  double ayy = to_double(sub128(mul_s64(n, c.ss[3]), mul_s64(c.s[1], c.s[1]))) * den;
+  double ayz = to_double(sub128(mul_s64(n, c.ss[4]), mul_s64(c.s[1], c.s[2]))) * den;
+  double azz = to_double(sub128(mul_s64(n, c.ss[5]), mul_s64(c.s[2], c.s[2]))) * den;
+  double v0[3] = {1, 0, 0}, v1[3] = {0, 1, 0}, v2[3] = {0, 0, 1};   // eigenvector columns
+  for (int sweep = 0; sweep < 6; ++sweep) {
+    jacobi_rot(axx, ayy, axy, axz, ayz, v0, v1);   // (p,q) = (0,1), r = 2
+    jacobi_rot(axx, azz, axz, axy, ayz, v0, v2);   // (0,2), r = 1
+    jacobi_rot(ayy, azz, ayz, axy, axz, v1, v2);   // (1,2), r = 0
+  }
+  const double lmax = fmax(axx, fmax(ayy, azz));
+  if (!(lmax > 0.0)) return false;
+  const double lim = eig_ratio * lmax;
+  const double i0 = 1.0 / fmax(axx, lim), i1 = 1.0 / fmax(ayy, lim), i2 = 1.0 / fmax(azz, lim);
+  const double cxx = i0 * v0[0] * v0[0] + i1 * v1[0] * v1[0] + i2 * v2[0] * v2[0];
+  const double cxy = i0 * v0[0] * v0[1] + i1 * v1[0] * v1[1] + i2 * v2[0] * v2[1];
+  const double cxz = i0 * v0[0] * v0[2] + i1 * v1[0] * v1[2] + i2 * v2[0] * v2[2];
+  const double cyy = i0 * v0[1] * v0[1] + i1 * v1[1] * v1[1] + i2 * v2[1] * v2[1];
+  const double cyz = i0 * v0[1] * v0[2] + i1 * v1[1] * v1[2] + i2 * v2[1] * v2[2];
+  const double czz = i0 * v0[2] * v0[2] + i1 * v1[2] * v1[2] + i2 * v2[2] * v2[2];
+  ra = make_float4((float)mx, (float)my, (float)mz, (float)n);
+  rb = make_float4((float)cxx, (float)cxy, (float)cxz, (float)cyy);
+  rc = make_float4((float)cyz, (float)czz, 0.f, 0.f);
+  return true;
+}
+
 __global__ __launch_bounds__(kBlock) void k_finalise3(Grid3Dev g, int min_points, double eig_ratio,
                                                        int* __restrict__ counters) {
   const size_t ncell = (size_t)g.W * g.H * g.D;
   const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= ncell) return;
   const CellAcc3 c = g.acc[k];
-  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
-  float2 rc = make_float2(0.f, 0.f);
-  const int n = (int)c.n;
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
   bool ok = false;
-  if (c.n > kMaxCellCount) atomicAdd(&counters[1], 1);
-  if (n >= min_points && n >= 2 && c.n <= kMaxCellCount) {
+  if (c.n > kMaxCellCount) {
+    atomicAdd(&counters[1], 1);
+  } else if ((int)c.n >= min_points) {
     const unsigned int k32 = (unsigned int)k, w32 = (unsigned int)g.W, h32 = (unsigned int)g.H;
     const int ix = (int)(k32 % w32), iy = (int)((k32 / w32) % h32), iz = (int)(k32 / (w32 * h32));
-    const double inv_s = 1.0 / g.fix_scale, dn = (double)n;
-    const double mx = fma((double)c.s[0] / dn, inv_s, cell_centre(g.ox, ix, g.cell));
-    const double my = fma((double)c.s[1] / dn, inv_s, cell_centre(g.oy, iy, g.cell));
-    const double mz = fma((double)c.s[2] / dn, inv_s, cell_centre(g.oz, iz, g.cell));
-    const double den = 1.0 / (dn * g.fix_scale * g.fix_scale * (dn - 1.0));
-    double axx = to_double(sub128(mul_s64(n, c.ss[0]), mul_s64(c.s[0], c.s[0]))) * den;
-    double axy = to_double(sub128(mul_s64(n, c.ss[1]), mul_s64(c.s[0], c.s[1]))) * den;
-    double axz = to_double(sub128(mul_s64(n, c.ss[2]), mul_s64(c.s[0], c.s[2]))) * den;
-    double ayy = to_double(sub128(mul_s64(n, c.ss[3]), mul_s64(c.s[1], c.s[1]))) * den;
-    double ayz = to_double(sub128(mul_s64(n, c.ss[4]), mul_s64(c.s[1], c.s[2]))) * den;
-    double azz = to_double(sub128(mul_s64(n, c.ss[5]), mul_s64(c.s[2], c.s[2]))) * den;
-    double v0[3] = {1, 0, 0}, v1[3] = {0, 1, 0}, v2[3] = {0, 0, 1};   // eigenvector columns
-    for (int sweep = 0; sweep < 6; ++sweep) {
-      jacobi_rot(axx, ayy, axy, axz, ayz, v0, v1);   // (p,q) = (0,1), r = 2
-      jacobi_rot(axx, azz, axz, axy, ayz, v0, v2);   // (0,2), r = 1
-      jacobi_rot(ayy, azz, ayz, axy, axz, v1, v2);   // (1,2), r = 0
-    }
-    const double lmax = fmax(axx, fmax(ayy, azz));
-    if (lmax > 0.0) {
-      const double lim = eig_ratio * lmax;
-      const double i0 = 1.0 / fmax(axx, lim), i1 = 1.0 / fmax(ayy, lim), i2 = 1.0 / fmax(azz, lim);
-      const double cxx = i0 * v0[0] * v0[0] + i1 * v1[0] * v1[0] + i2 * v2[0] * v2[0];
-      const double cxy = i0 * v0[0] * v0[1] + i1 * v1[0] * v1[1] + i2 * v2[0] * v2[1];
-      const double cxz = i0 * v0[0] * v0[2] + i1 * v1[0] * v1[2] + i2 * v2[0] * v2[2];
-      const double cyy = i0 * v0[1] * v0[1] + i1 * v1[1] * v1[1] + i2 * v2[1] * v2[1];
-      const double cyz = i0 * v0[1] * v0[2] + i1 * v1[1] * v1[2] + i2 * v2[1] * v2[2];
-      const double czz = i0 * v0[2] * v0[2] + i1 * v1[2] * v1[2] + i2 * v2[2] * v2[2];
-      ra = make_float4((float)mx, (float)my, (float)mz, (float)n);
-      rb = make_float4((float)cxx, (float)cxy, (float)cxz, (float)cyy);
-      rc = make_float2((float)cyz, (float)czz);
-      ok = true;
-    }
+    ok = finalise_sums3(c, cell_centre(g.ox, ix, g.cell), cell_centre(g.oy, iy, g.cell), cell_centre(g.oz, iz, g.cell),
+                        g.fix_scale, min_points, eig_ratio, ra, rb, rc);
   }
   const unsigned long long valid_mask = __ballot(ok);      // one atomic per wave
   if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(valid_mask | (1ull << 63)) && valid_mask)
     atomicAdd(&counters[0], (int)__popcll(valid_mask));
   g.rec[4 * k] = ra;
   g.rec[4 * k + 1] = rb;
-  g.rec[4 * k + 2] = make_float4(rc.x, rc.y, 0.f, 0.f);
+  g.rec[4 * k + 2] = rc;
 }
 
 // ---------------------------------------------------------------------------- solve (6x6)

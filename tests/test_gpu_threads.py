@@ -35,6 +35,8 @@ def test_two_handles_two_threads(gpu_lib):
         t.start()
     for t in th:
         t.join(timeout=120)
-    assert not errs and all(o is not None for o in out)
+    assert not errs, repr(errs)
+    assert all(o is not None for o in out)
     for a, b in zip(out, serial):
-        assert a.pose == b.pose and a.iterations == b.iterations and np.array_equal(a.H, b.H)
+        assert a.status == b.status and a.iterations == b.iterations, (a, b)
+        assert a.pose == b.pose and np.array_equal(a.H, b.H), (a.pose, b.pose)
