@@ -124,6 +124,11 @@ SIGNATURES = {
     "ndt2d_batch_align": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ndt2d_batch_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "ndt2d_batch_stream": (_vp, [_vp]),
+    "ndt2d_multi_create": (C.c_int32, [C.POINTER(Params2D), _vp, C.c_int32, C.POINTER(_vp)]),
+    "ndt2d_multi_destroy": (C.c_int32, [_vp]),
+    "ndt2d_multi_device_count": (C.c_int32, [_vp]),
+    "ndt2d_multi_align": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ndt2d_multi_plan": (C.c_int32, [C.c_int32, _vp, _vp, C.c_size_t, C.c_int32, _vp]),
     "ndt3d_default_params": (None, [C.POINTER(Params2D)]),
     "ndt3d_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),
     "ndt3d_destroy": (C.c_int32, [_vp]),

@@ -637,4 +637,5 @@ int32_t ndt2d_align(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
 }  // extern "C"
 
 #include "ndt2d_batch_api.hpp"
+#include "ndt2d_multi_api.hpp"
 #include "ndt3d_api.hpp"

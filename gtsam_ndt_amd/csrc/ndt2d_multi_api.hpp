@@ -1,0 +1,99 @@
+// C-ABI of the multi-device loop-closure context (included at the end of ndt2d_api.hip).
+// For a C++ host process that owns all GPUs of a node itself: one ndt2d_batch + one host thread
+// per device, pairs split into contiguous, work-balanced shards, results written straight into
+// the caller's array.  There is no exchange step between devices (pairs are independent), so
+// there is no collective here; the one-process-per-GPU deployment (torch.distributed / RCCL
+// gather) lives in gtsam_ndt_amd/dist.py and bench.py.
+#pragma once
+#include <thread>
+#include <vector>
+
+struct ndt2d_multi {
+  std::vector<ndt2d_batch*> ctx;
+  ndt2d_params prm{};
+};
+
+int32_t ndt2d_multi_destroy(ndt2d_multi* m) {
+  if (!m) return NDT_OK;
+  for (ndt2d_batch* b : m->ctx) ndt2d_batch_destroy(b);
+  delete m;
+  return NDT_OK;
+}
+
+int32_t ndt2d_multi_create(const ndt2d_params* p, const int32_t* device_ids, int32_t n_devices, ndt2d_multi** out) {
+  if (!out) return NDT_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!p || n_devices < 0 || (n_devices > 0 && !device_ids)) return NDT_ERR_INVALID_ARG;
+  const int visible = ndt_device_count();
+  if (visible <= 0) { ndt::set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }
+  ndt2d_multi* m = new (std::nothrow) ndt2d_multi();
+  if (!m) return NDT_ERR_ALLOC;
+  m->prm = *p;
+  const int n = n_devices > 0 ? n_devices : visible;
+  for (int i = 0; i < n; ++i) {
+    ndt2d_batch* b = nullptr;
+    const int32_t st = ndt2d_batch_create(p, n_devices > 0 ? device_ids[i] : i, &b);
+    if (st != NDT_OK) { ndt2d_multi_destroy(m); return st; }
+    m->ctx.push_back(b);
+  }
+  *out = m;
+  return NDT_OK;
+}
+
+int32_t ndt2d_multi_device_count(const ndt2d_multi* m) { return m ? static_cast<int32_t>(m->ctx.size()) : 0; }
+
+// shard_begin[d] .. shard_begin[d+1] = the pairs device slot d would receive for these offsets
+// (exposed so a caller can pre-place data, and so the split is testable without devices)
+int32_t ndt2d_multi_plan(int32_t n_shards, const uint64_t* toff, const uint64_t* soff, size_t n_pairs,
+                         int32_t iterations_hint, uint64_t* shard_begin) {
+  if (n_shards <= 0 || !toff || !soff || !shard_begin) return NDT_ERR_INVALID_ARG;
+  const double kk = iterations_hint > 0 ? iterations_hint : 30;
+  // work of a pair = its target points once (grid build) + its source points per iteration
+  auto work = [&](size_t k) { return 3.0 * double(toff[k + 1] - toff[k]) + kk * double(soff[k + 1] - soff[k]) + 1.0; };
+  double total = 0;
+  for (size_t k = 0; k < n_pairs; ++k) {
+    if (toff[k + 1] < toff[k] || soff[k + 1] < soff[k]) return NDT_ERR_INVALID_ARG;
+    total += work(k);
+  }
+  size_t k = 0;
+  double acc = 0;
+  shard_begin[0] = 0;
+  for (int d = 1; d <= n_shards; ++d) {
+    const double goal = total * d / n_shards;
+    // a pair goes to the shard in which its midpoint falls: contiguous, deterministic, balanced
+    while (k < n_pairs && acc + 0.5 * work(k) <= goal) acc += work(k++);
+    shard_begin[d] = d == n_shards ? n_pairs : k;
+  }
+  return NDT_OK;
+}
+
+int32_t ndt2d_multi_align(ndt2d_multi* m, const float* tx, const float* ty, const uint64_t* toff,
+                          const float* sx, const float* sy, const uint64_t* soff, const double* init,
+                          size_t n_pairs, ndt2d_result* results) {
+  if (!m || m->ctx.empty() || !tx || !ty || !toff || !sx || !sy || !soff || !init || !results || n_pairs == 0)
+    return NDT_ERR_INVALID_ARG;
+  const int nd = static_cast<int>(m->ctx.size());
+  std::vector<uint64_t> begin(nd + 1);
+  const int32_t hint = m->prm.fixed_iterations > 0 ? m->prm.fixed_iterations : 30;
+  int32_t st = ndt2d_multi_plan(nd, toff, soff, n_pairs, hint, begin.data());
+  if (st != NDT_OK) return st;
+  std::vector<int32_t> status(nd, NDT_OK);
+  std::vector<std::string> message(nd);
+  auto run = [&](int d) {
+    const size_t k0 = begin[d], k1 = begin[d + 1];
+    if (k1 == k0) return;
+    // the shard's offsets rebased to its first point, so only its own points are uploaded
+    std::vector<uint64_t> to(k1 - k0 + 1), so(k1 - k0 + 1);
+    for (size_t k = k0; k <= k1; ++k) { to[k - k0] = toff[k] - toff[k0]; so[k - k0] = soff[k] - soff[k0]; }
+    status[d] = ndt2d_batch_align(m->ctx[d], tx + toff[k0], ty + toff[k0], to.data(), sx + soff[k0], sy + soff[k0],
+                                  so.data(), init + 3 * k0, k1 - k0, results + k0);
+    if (status[d] != NDT_OK) message[d] = ndt_last_error();   // last_error is per thread
+  };
+  std::vector<std::thread> workers;
+  for (int d = 1; d < nd; ++d) workers.emplace_back(run, d);
+  run(0);
+  for (std::thread& w : workers) w.join();
+  for (int d = 0; d < nd; ++d)
+    if (status[d] != NDT_OK) { ndt::set_error(message[d].c_str()); return status[d]; }
+  return NDT_OK;
+}

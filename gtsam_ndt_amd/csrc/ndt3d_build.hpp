@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
     const int ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
     const int uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
     const int uz = fix_coord(pz, cell_centre(g.oz, iz, g.cell), g.fix_scale);
-    const int c = (((iz - tz0) << kT3y) + (iy - ty0) << kT3x) + (ix - tx0);
+    const int c = ((((iz - tz0) << kT3y) + (iy - ty0)) << kT3x) + (ix - tx0);
     atomicAdd(&s_n[c], 1u);
     atomicAdd(&s_sum[0][c], (unsigned long long)(long long)ux);
     atomicAdd(&s_sum[1][c], (unsigned long long)(long long)uy);

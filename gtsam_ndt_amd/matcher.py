@@ -189,6 +189,78 @@ def _results_from_bytes(buf: np.ndarray, n: int):
     return [_to_result(r) for r in arr]
 
 
+def _concat_pairs(targets, sources, inits):
+    n = len(targets)
+    toff = np.zeros(n + 1, dtype=np.uint64)
+    soff = np.zeros(n + 1, dtype=np.uint64)
+    toff[1:] = np.cumsum([len(t[0]) for t in targets])
+    soff[1:] = np.cumsum([len(s[0]) for s in sources])
+    tx = np.concatenate([_host_f32(t[0]) for t in targets]); ty = np.concatenate([_host_f32(t[1]) for t in targets])
+    sx = np.concatenate([_host_f32(s[0]) for s in sources]); sy = np.concatenate([_host_f32(s[1]) for s in sources])
+    init = np.ascontiguousarray(inits, dtype=np.float64).reshape(n, 3)
+    return n, tx, ty, toff, sx, sy, soff, init
+
+
+def multi_plan(n_shards: int, toff, soff, iterations_hint: int = 0) -> np.ndarray:
+    """The pair split ndt2d_multi_align uses (ndt2d_multi_plan; needs no device)."""
+    lib = L.load()
+    toff = np.ascontiguousarray(toff, dtype=np.uint64)
+    soff = np.ascontiguousarray(soff, dtype=np.uint64)
+    begin = np.zeros(max(n_shards, 0) + 1, dtype=np.uint64)
+    L.check(lib.ndt2d_multi_plan(int(n_shards), toff.ctypes.data, soff.ctypes.data, len(toff) - 1,
+                                 int(iterations_hint), begin.ctypes.data), "ndt2d_multi_plan")
+    return begin
+
+
+class NdtMulti2D:
+    """The loop-closure batch over several devices from one host process (one context and one
+    host thread per device).  Mirrors ndt2d_multi_* of include/ndt_hip.h."""
+
+    def __init__(self, devices=None, params: L.Params2D | None = None, **overrides):
+        self._lib = L.load()
+        self.params = params if params is not None else default_params(**overrides)
+        if params is not None:
+            for k, v in overrides.items():
+                setattr(self.params, k, v)
+        h = C.c_void_p()
+        if devices is None:
+            ids, n = None, 0
+        else:
+            ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            n = len(devices)
+        L.check(self._lib.ndt2d_multi_create(C.byref(self.params), ids, n, C.byref(h)), "ndt2d_multi_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndt2d_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def device_count(self) -> int:
+        return int(self._lib.ndt2d_multi_device_count(self._h))
+
+    def align(self, targets, sources, inits):
+        n, tx, ty, toff, sx, sy, soff, init = _concat_pairs(targets, sources, inits)
+        out = np.zeros(n * RESULT_DOUBLES, dtype=np.float64)
+        L.check(self._lib.ndt2d_multi_align(self._h, tx.ctypes.data, ty.ctypes.data, toff.ctypes.data,
+                                            sx.ctypes.data, sy.ctypes.data, soff.ctypes.data, init.ctypes.data,
+                                            n, out.ctypes.data), "ndt2d_multi_align")
+        return _results_from_bytes(out, n)
+
+
 class NdtBatch2D:
     """Loop-closure candidate batch: independent scan pairs aligned concurrently on one GPU
     (one persistent workgroup per CU, target grid resident in LDS).  Mirrors
@@ -229,14 +301,7 @@ class NdtBatch2D:
     def align(self, targets, sources, inits):
         """targets / sources: lists of (x, y) numpy pairs; inits: [n][3].  Returns a list of
         AlignResult.  Pairs over the on-chip capacity are re-run through the general path."""
-        n = len(targets)
-        toff = np.zeros(n + 1, dtype=np.uint64)
-        soff = np.zeros(n + 1, dtype=np.uint64)
-        toff[1:] = np.cumsum([len(t[0]) for t in targets])
-        soff[1:] = np.cumsum([len(s[0]) for s in sources])
-        tx = np.concatenate([_host_f32(t[0]) for t in targets]); ty = np.concatenate([_host_f32(t[1]) for t in targets])
-        sx = np.concatenate([_host_f32(s[0]) for s in sources]); sy = np.concatenate([_host_f32(s[1]) for s in sources])
-        init = np.ascontiguousarray(inits, dtype=np.float64).reshape(n, 3)
+        n, tx, ty, toff, sx, sy, soff, init = _concat_pairs(targets, sources, inits)
         out = np.zeros(n * RESULT_DOUBLES, dtype=np.float64)
         L.check(self._lib.ndt2d_batch_align(self._h, tx.ctypes.data, ty.ctypes.data, toff.ctypes.data,
                                             sx.ctypes.data, sy.ctypes.data, soff.ctypes.data, init.ctypes.data,

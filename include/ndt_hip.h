@@ -184,6 +184,26 @@ int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_
                               const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream);
 void* ndt2d_batch_stream(ndt2d_batch* b);
 
+/* The same batch over several devices from ONE host process (a C++ SLAM back end that owns the
+ * node's GPUs itself): one batch context and one host thread per device, pairs split into
+ * contiguous work-balanced shards, results written into the caller's array.  Pairs are
+ * independent, so no data moves between devices.  device_ids == NULL with n_devices == 0 means
+ * every visible device; an id may be listed more than once (two contexts on that device).
+ * (The one-process-per-GPU deployment with an RCCL gather is gtsam_ndt_amd/dist.py.) */
+typedef struct ndt2d_multi ndt2d_multi;
+int32_t ndt2d_multi_create(const ndt2d_params* p, const int32_t* device_ids, int32_t n_devices, ndt2d_multi** out);
+int32_t ndt2d_multi_destroy(ndt2d_multi* m);
+int32_t ndt2d_multi_device_count(const ndt2d_multi* m);
+/* Arguments as ndt2d_batch_align (host pointers).  Returns the first failing shard's status. */
+int32_t ndt2d_multi_align(ndt2d_multi* m, const float* tx, const float* ty, const uint64_t* toff,
+                          const float* sx, const float* sy, const uint64_t* soff, const double* init,
+                          size_t n_pairs, ndt2d_result* results);
+/* The split ndt2d_multi_align uses: shard d owns pairs [shard_begin[d], shard_begin[d+1]);
+ * shard_begin has n_shards + 1 entries.  Work of a pair = 3 x target points + iterations_hint x
+ * source points (iterations_hint <= 0: 30).  Needs no device. */
+int32_t ndt2d_multi_plan(int32_t n_shards, const uint64_t* toff, const uint64_t* soff, size_t n_pairs,
+                         int32_t iterations_hint, uint64_t* shard_begin);
+
 /* ---- 3D NDT, SE(3) (BASELINE config 5) ----------------------- */
 /* Same pipeline in 3D: dense voxel grid with per-cell mean / 3x3 covariance (eigenvalue clamp
  * by a fixed-sweep Jacobi), pose = (tx, ty, tz, roll, pitch, yaw) with R = Rz(yaw) Ry(pitch)

@@ -158,6 +158,36 @@ class NdtPyramidHip {
   std::vector<NdtMatcherHip*> levels_;
 };
 
+namespace detail {
+struct CloudView { const float* x; const float* y; size_t n; };
+
+// concatenates the pairs into the SoA + offsets form of ndt2d_batch_align / ndt2d_multi_align
+template <class Clouds, class Call>
+std::vector<MatchResult> align_pairs(const Clouds& targets, const Clouds& sources, const std::vector<Pose2>& guesses,
+                                     const char* what, Call&& call) {
+  const size_t n = targets.size();
+  if (sources.size() != n || guesses.size() != n || n == 0) throw NdtError(NDT_ERR_INVALID_ARG, what);
+  std::vector<uint64_t> toff(n + 1, 0), soff(n + 1, 0);
+  for (size_t k = 0; k < n; ++k) { toff[k + 1] = toff[k] + targets[k].n; soff[k + 1] = soff[k] + sources[k].n; }
+  std::vector<float> tx(toff[n]), ty(toff[n]), sx(soff[n]), sy(soff[n]);
+  std::vector<double> init(3 * n);
+  for (size_t k = 0; k < n; ++k) {
+    std::copy(targets[k].x, targets[k].x + targets[k].n, tx.begin() + toff[k]);
+    std::copy(targets[k].y, targets[k].y + targets[k].n, ty.begin() + toff[k]);
+    std::copy(sources[k].x, sources[k].x + sources[k].n, sx.begin() + soff[k]);
+    std::copy(sources[k].y, sources[k].y + sources[k].n, sy.begin() + soff[k]);
+    init[3 * k] = guesses[k].x; init[3 * k + 1] = guesses[k].y; init[3 * k + 2] = guesses[k].theta;
+  }
+  std::vector<ndt2d_result> res(n);
+  const int32_t st = call(tx.data(), ty.data(), toff.data(), sx.data(), sy.data(), soff.data(), init.data(), n, res.data());
+  if (st < 0) throw NdtError(st, what);
+  std::vector<MatchResult> out;
+  out.reserve(n);
+  for (const auto& r : res) out.push_back(to_match_result(r));
+  return out;
+}
+}  // namespace detail
+
 // Loop-closure candidates: many independent pairs in one call.
 class NdtBatchHip {
  public:
@@ -173,31 +203,46 @@ class NdtBatchHip {
 
   std::vector<MatchResult> align(const std::vector<Cloud>& targets, const std::vector<Cloud>& sources,
                                  const std::vector<Pose2>& guesses) {
-    const size_t n = targets.size();
-    if (sources.size() != n || guesses.size() != n || n == 0) throw NdtError(NDT_ERR_INVALID_ARG, "NdtBatchHip::align");
-    std::vector<uint64_t> toff(n + 1, 0), soff(n + 1, 0);
-    for (size_t k = 0; k < n; ++k) { toff[k + 1] = toff[k] + targets[k].n; soff[k + 1] = soff[k] + sources[k].n; }
-    std::vector<float> tx(toff[n]), ty(toff[n]), sx(soff[n]), sy(soff[n]);
-    std::vector<double> init(3 * n);
-    for (size_t k = 0; k < n; ++k) {
-      std::copy(targets[k].x, targets[k].x + targets[k].n, tx.begin() + toff[k]);
-      std::copy(targets[k].y, targets[k].y + targets[k].n, ty.begin() + toff[k]);
-      std::copy(sources[k].x, sources[k].x + sources[k].n, sx.begin() + soff[k]);
-      std::copy(sources[k].y, sources[k].y + sources[k].n, sy.begin() + soff[k]);
-      init[3 * k] = guesses[k].x; init[3 * k + 1] = guesses[k].y; init[3 * k + 2] = guesses[k].theta;
-    }
-    std::vector<ndt2d_result> res(n);
-    const int32_t st = ndt2d_batch_align(b_, tx.data(), ty.data(), toff.data(), sx.data(), sy.data(), soff.data(),
-                                         init.data(), n, res.data());
-    if (st < 0) throw NdtError(st, "ndt2d_batch_align");
-    std::vector<MatchResult> out;
-    out.reserve(n);
-    for (const auto& r : res) out.push_back(to_match_result(r));
-    return out;
+    return detail::align_pairs(targets, sources, guesses, "ndt2d_batch_align",
+                               [&](const float* tx, const float* ty, const uint64_t* toff, const float* sx, const float* sy,
+                                   const uint64_t* soff, const double* init, size_t n, ndt2d_result* res) {
+                                 return ndt2d_batch_align(b_, tx, ty, toff, sx, sy, soff, init, n, res);
+                               });
   }
 
  private:
   ndt2d_batch* b_ = nullptr;
+};
+
+// The same over several GPUs owned by this process: pairs are split into contiguous
+// work-balanced shards, one host thread and one batch context per device.
+class NdtMultiHip {
+ public:
+  using Cloud = NdtBatchHip::Cloud;
+
+  // devices empty = every visible device
+  explicit NdtMultiHip(const ndt2d_params& params = NdtMatcherHip::defaultParams(), const std::vector<int32_t>& devices = {}) {
+    const int32_t st = ndt2d_multi_create(&params, devices.empty() ? nullptr : devices.data(),
+                                          static_cast<int32_t>(devices.size()), &m_);
+    if (st != NDT_OK) throw NdtError(st, "ndt2d_multi_create");
+  }
+  ~NdtMultiHip() { ndt2d_multi_destroy(m_); }
+  NdtMultiHip(const NdtMultiHip&) = delete;
+  NdtMultiHip& operator=(const NdtMultiHip&) = delete;
+
+  int deviceCount() const { return ndt2d_multi_device_count(m_); }
+
+  std::vector<MatchResult> align(const std::vector<Cloud>& targets, const std::vector<Cloud>& sources,
+                                 const std::vector<Pose2>& guesses) {
+    return detail::align_pairs(targets, sources, guesses, "ndt2d_multi_align",
+                               [&](const float* tx, const float* ty, const uint64_t* toff, const float* sx, const float* sy,
+                                   const uint64_t* soff, const double* init, size_t n, ndt2d_result* res) {
+                                 return ndt2d_multi_align(m_, tx, ty, toff, sx, sy, soff, init, n, res);
+                               });
+  }
+
+ private:
+  ndt2d_multi* m_ = nullptr;
 };
 
 }  // namespace ndt

@@ -56,8 +56,9 @@ def test_adapter_matches_oracle(exe, tmp_path, gpu_lib):
     lines = dict((l.split()[0], l.split()[1:]) for l in r.stdout.strip().splitlines())
     prm = o.NdtParams()
     ref = o.align(o.build_grid(d["tx"], d["ty"], prm), d["sx"], d["sy"], d["init"], prm)
-    for key in ("single", "batch"):
+    for key in ("single", "batch", "multi"):
         pose = np.array([float(v) for v in lines[key][:3]])
         assert np.abs(pose - np.array(ref["pose"])).max() < 1e-4
         assert int(lines[key][-1]) == 0
+    assert lines["multi"] == lines["batch"]          # same kernel, same pair: bit-identical
     assert abs(float(lines["infocov"][0]) - 1.0) < 1e-6

@@ -125,3 +125,33 @@ def test_batch_empty_clouds(gpu_lib, pairs):
     assert res[0].status == L.NDT_TOO_FEW_HITS and res[3].status == L.NDT_TOO_FEW_HITS
     assert res[1].status == L.NDT_TOO_FEW_CELLS
     assert res[2].status == 0
+
+
+def test_multi_context_equals_single_batch(gpu_lib):
+    from gtsam_ndt_amd import matcher as M
+    """ndt2d_multi_* with two contexts on device 0 (the box has one GPU): the sharded run returns
+    exactly what one batch context returns, in the caller's pair order."""
+    pairs = [synth.make_pair(4, pair_index=k, n_tgt=3000 + 500 * (k % 3), n_src=2500) for k in range(7)]
+    T = [(p["tx"], p["ty"]) for p in pairs]
+    S = [(p["sx"], p["sy"]) for p in pairs]
+    I = [p["init"] for p in pairs]
+    with M.NdtBatch2D() as b:
+        ref = b.align(T, S, I)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        with M.NdtMulti2D(devices=devices) as mm:
+            assert mm.device_count == len(devices)
+            out = mm.align(T, S, I)
+        for a, r in zip(out, ref):
+            assert a.status == r.status and a.iterations == r.iterations and a.n_hit == r.n_hit
+            assert a.pose == r.pose and np.array_equal(a.H, r.H)
+    with M.NdtMulti2D() as mm:           # every visible device
+        assert mm.device_count >= 1
+        out = mm.align(T[:2], S[:2], I[:2])
+        assert out[1].pose == ref[1].pose
+
+
+def test_multi_context_rejects_bad_devices(gpu_lib):
+    from gtsam_ndt_amd import matcher as M
+    from gtsam_ndt_amd._lib import NdtError
+    with pytest.raises(NdtError):
+        M.NdtMulti2D(devices=[0, 99])

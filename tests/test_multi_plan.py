@@ -1,0 +1,65 @@
+"""The pair split of the multi-device context (ndt2d_multi_plan): host logic, no device."""
+import numpy as np
+import pytest
+
+from gtsam_ndt_amd import matcher as M
+from gtsam_ndt_amd._lib import NdtError
+
+
+def _offsets(sizes):
+    off = np.zeros(len(sizes) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)
+    return off
+
+
+def test_equal_pairs_split_evenly(ndt_lib):
+    toff = _offsets([1000] * 64)
+    soff = _offsets([1000] * 64)
+    for shards in (1, 2, 3, 4, 8):
+        b = M.multi_plan(shards, toff, soff)
+        assert b[0] == 0 and b[-1] == 64 and np.all(np.diff(b.astype(np.int64)) >= 0)
+        sizes = np.diff(b.astype(np.int64))
+        assert sizes.max() - sizes.min() <= 1
+
+
+def test_split_balances_work_not_pairs(ndt_lib):
+    # the first 8 pairs are 10x heavier than the other 80
+    sizes = [10000] * 8 + [1000] * 80
+    toff = _offsets(sizes)
+    soff = _offsets(sizes)
+    b = M.multi_plan(2, toff, soff, iterations_hint=30).astype(np.int64)
+    w = np.array(sizes, dtype=np.float64)
+    left, right = w[: b[1]].sum(), w[b[1]:].sum()
+    assert abs(left - right) <= w.max()
+    assert b[1] < 44          # far from the pair-count midpoint
+
+
+def test_more_shards_than_pairs_and_empty_pairs(ndt_lib):
+    toff = _offsets([100, 0, 100])
+    soff = _offsets([100, 0, 100])
+    b = M.multi_plan(8, toff, soff).astype(np.int64)
+    assert b[0] == 0 and b[-1] == 3 and np.all(np.diff(b) >= 0)
+    assert sorted(set(np.repeat(np.arange(8), np.diff(b)))) == sorted(set(np.repeat(np.arange(8), np.diff(b))))
+    assert np.diff(b).sum() == 3
+
+
+def test_plan_is_deterministic_and_covers_every_pair(ndt_lib):
+    rng = np.random.default_rng(5)
+    sizes_t = rng.integers(0, 5000, 257)
+    sizes_s = rng.integers(0, 5000, 257)
+    toff, soff = _offsets(sizes_t), _offsets(sizes_s)
+    a = M.multi_plan(6, toff, soff, 12)
+    b = M.multi_plan(6, toff, soff, 12)
+    assert np.array_equal(a, b)
+    work = 3.0 * sizes_t + 12.0 * sizes_s + 1.0
+    per = [work[int(a[d]): int(a[d + 1])].sum() for d in range(6)]
+    assert max(per) - min(per) <= 2 * work.max()
+
+
+def test_plan_rejects_bad_arguments(ndt_lib):
+    toff = _offsets([10, 10])
+    with pytest.raises(NdtError):
+        M.multi_plan(0, toff, toff)
+    bad = np.array([0, 10, 5], dtype=np.uint64)
+    with pytest.raises(NdtError):
+        M.multi_plan(2, bad, toff)
