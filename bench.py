@@ -326,6 +326,12 @@ def main():
         mc = NdtMatcher2D(device=dev_index)
         mc.set_target(tx, ty)
         rc = mc.align(sx, sy, d["init"])
+        # what a caller sees per scan in converged mode: host call -> result on the host
+        lat = []
+        for _ in range(20):
+            t1 = time.perf_counter(); rl = mc.align(sx, sy, d["init"]); lat.append(time.perf_counter() - t1)
+        assert rl.pose == rc.pose
+        conv_ms = 1e3 * float(np.median(lat))
         mc.close()
         prm = oracle.NdtParams()
         ref = oracle.align(oracle.build_grid(d["tx"], d["ty"], prm), d["sx"], d["sy"], d["init"], prm)
@@ -341,6 +347,9 @@ def main():
                        "gn_iterations_per_step": K_GN, "hessian": "gauss-newton"},
             "roofline": roofline,
             "grid_build_ms": round(grid_ms, 4),
+            "converged_align": {"ms_per_call": round(conv_ms, 4), "iterations": rc.iterations,
+                                "note": "ndt2d_align_dev in converged mode, host call to result in host memory "
+                                        "(8-launch chunks polled for convergence); median of 20"},
             "scaling_note": "N=1 times the single-pair config 3 named by BASELINE.json's metric; N>1 lines time "
                             "the sharded loop-closure batch (config 4).  Read multi-GPU scaling against this "
                             "line's batch.value (same workload, one GPU), not against value.",

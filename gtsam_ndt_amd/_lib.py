@@ -44,6 +44,8 @@ class Params2D(C.Structure):
         ("step_max_rot", C.c_double),
         ("min_hits", C.c_int32),
         ("overlap_grids", C.c_int32),
+        ("line_search", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

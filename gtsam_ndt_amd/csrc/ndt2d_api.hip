@@ -71,6 +71,7 @@ int32_t check_params(const ndt2d_params* p) {
   if (!(p->step_max_trans > 0.0) || !(p->step_max_rot > 0.0)) return NDT_ERR_INVALID_ARG;
   if (!(p->d1 > 0.0) || !(p->d2 > 0.0) || !std::isfinite(p->d1) || !std::isfinite(p->d2)) return NDT_ERR_INVALID_ARG;
   if (p->overlap_grids != 0 && p->overlap_grids != 1 && p->overlap_grids != 4) return NDT_ERR_INVALID_ARG;
+  if (p->line_search < 0 || p->line_search > 16) return NDT_ERR_INVALID_ARG;
   return NDT_OK;
 }
 
@@ -251,7 +252,7 @@ int32_t upload_static(ndt2d_handle* h) {
   p.hessian_mode = h->prm.hessian_mode;
   p.max_iterations = h->prm.max_iterations;
   p.min_hits = h->prm.min_hits;
-  p.pad = 0;
+  p.line_search = h->prm.line_search;
   p.eps_trans = h->prm.eps_trans;
   p.eps_rot = h->prm.eps_rot;
   p.step_max_trans = h->prm.step_max_trans;

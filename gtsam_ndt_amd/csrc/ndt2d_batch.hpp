@@ -62,7 +62,8 @@ constexpr int kLdsRed = kLdsSums + 5 * kBatchMaxSlots * 8;            // float [
 constexpr int kLdsBc = kLdsRed + kBatchWaves * kNumAcc * 4;           // double [16] broadcast
 constexpr int kLdsMisc = kLdsBc + 16 * 8;                             // int [16]
 constexpr int kLdsScan = kLdsMisc + 16 * 4;                           // int [Waves]
-constexpr int kBatchLdsBytes = kLdsScan + kBatchWaves * 4;
+constexpr int kLdsLs = kLdsScan + kBatchWaves * 4;                    // LineSearch (line-search state)
+constexpr int kBatchLdsBytes = kLdsLs + (int)sizeof(LineSearch);
 static_assert(kBatchMaxCells * 4 <= 5 * kBatchMaxSlots * 8, "cnt must fit in the sums region");
 static_assert(kBatchMaxSlots * 32 <= 5 * kBatchMaxSlots * 8, "records must fit in the sums region");
 static_assert(kBatchLdsBytes <= 160 * 1024, "CDNA4 LDS is 160 KiB per CU");
@@ -340,6 +341,9 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     // point loop.
     if (tid == 0) { misc[9] = 0; misc[10] = 0; }     // iter, status
     __syncthreads();
+    // line-search state lives in LDS so that it is not held in registers across the point loop
+    LineSearch* ls_lds = reinterpret_cast<LineSearch*>(smem + kLdsLs);
+    if (tid == 0) { ls_lds->valid = 0; ls_lds->trials = 0; }
     for (;;) {
       float acc[kNumAcc];
       {
@@ -415,7 +419,8 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
         for (int j = 0; j < 3; ++j) g[j] = __shfl(tot, 6 + j, 64);
         const int n_hit = (int)(__shfl(tot, 10, 64) + 0.5);
         int iter = misc[9], st = 0;
-        const bool done = gn_update(pose, H, g, n_hit, iter, st, a.prm, a.fixed_iterations);
+        const bool done = gn_update(pose, H, g, n_hit, iter, st, a.prm, a.fixed_iterations, __shfl(tot, 9, 64),
+                                    ls_lds, ls_lds, lane == 0);
         if (lane < kNumAcc - 1) bc[3 + lane] = tot;          // H(6) g(3) score n_hit of this evaluation
         if (lane == 0) {
           bc[0] = pose[0]; bc[1] = pose[1]; bc[2] = pose[2];

@@ -43,6 +43,7 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
   a.prm.hessian_mode = b->prm.hessian_mode;
   a.prm.max_iterations = b->prm.max_iterations;
   a.prm.min_hits = b->prm.min_hits;
+  a.prm.line_search = b->prm.line_search;
   a.prm.eps_trans = b->prm.eps_trans; a.prm.eps_rot = b->prm.eps_rot;
   a.prm.step_max_trans = b->prm.step_max_trans; a.prm.step_max_rot = b->prm.step_max_rot;
   HIP_TRY(hipMemsetAsync(b->d_queue, 0, 16, st));

@@ -48,9 +48,21 @@ struct SolveParams {
   int hessian_mode;
   int max_iterations;
   int min_hits;
-  int pad;
+  int line_search;   // > 0: backtracking line search, at most this many halvings per step
   double eps_trans, eps_rot, step_max_trans, step_max_rot;
 };
+
+// Backtracking line-search state (oracle/ndt2d.py gn_update): the pose the current step
+// started from, its score, the clamped step and how far along it the trial pose sits.
+struct LineSearch {
+  double base[3];
+  double step[3];
+  double score;
+  double alpha;
+  int trials;
+  int valid;
+};
+constexpr double kLineSearchTol = 1e-3;   // oracle/ndt2d.py LS_TOL
 
 // State handed from launch k-1 to launch k through HBM (kernel boundary = the only
 // inter-workgroup synchronisation; no in-launch hand-off, no atomics).
@@ -85,6 +97,7 @@ struct AlignCall {
 struct AlignDyn {
   IterState state[2];
   float partials[2][kNumAcc][kMaxBlocks];
+  LineSearch ls[2];       // ping-pong like state; touched only when prm.line_search > 0
 };
 
 // ---------------------------------------------------------------------------- a1 bounds
@@ -333,8 +346,27 @@ __device__ __forceinline__ void sincos_wrapped(double t, double* sn, double* cs)
 }
 
 // returns done; updates pose/iter/status in place
+// ls_in / ls_out: line-search state before / after this step (the same object, or the two
+// ping-pong slots); touched only when p.line_search > 0; `write` selects the one storing thread.
 __device__ __forceinline__ bool gn_update(double* pose, const double* H, const double* g, int n_hit,
-                                          int& iter, int& status, const SolveParams& p, int fixed_iterations) {
+                                          int& iter, int& status, const SolveParams& p, int fixed_iterations,
+                                          double score, const LineSearch* ls_in, LineSearch* ls_out, bool write) {
+  if (p.line_search > 0 && ls_in->valid && ls_in->trials < p.line_search &&
+      (n_hit < p.min_hits || score < ls_in->score - kLineSearchTol * fabs(ls_in->score))) {
+    // the evaluation was a trial of the previous step and it scored worse: halve and retry
+    LineSearch ls = *ls_in;
+    ls.alpha *= 0.5;
+    ls.trials += 1;
+    pose[0] = ls.base[0] + ls.alpha * ls.step[0];
+    pose[1] = ls.base[1] + ls.alpha * ls.step[1];
+    pose[2] = wrap_angle(ls.base[2] + ls.alpha * ls.step[2]);
+    if (write) *ls_out = ls;
+    iter += 1;
+    status = 0;
+    if (fixed_iterations > 0) return iter >= fixed_iterations;
+    if (iter >= p.max_iterations) { status = 1; return true; }
+    return false;
+  }
   if (n_hit < p.min_hits) { status = 3; return true; }
   double d[3];
   if (!solve3(H, g, d)) { status = 2; return true; }
@@ -343,6 +375,11 @@ __device__ __forceinline__ bool gn_update(double* pose, const double* H, const d
   double alpha = 1.0;
   if (nt2 > p.step_max_trans * p.step_max_trans) alpha = p.step_max_trans / sqrt(nt2);
   if (nr * alpha > p.step_max_rot) alpha = p.step_max_rot / nr;
+  if (p.line_search > 0 && write) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { ls_out->base[j] = pose[j]; ls_out->step[j] = d[j] * alpha; }
+    ls_out->score = score; ls_out->alpha = 1.0; ls_out->trials = 0; ls_out->valid = 1;
+  }
   pose[0] += d[0] * alpha;
   pose[1] += d[1] * alpha;
   pose[2] = wrap_angle(pose[2] + d[2] * alpha);
@@ -366,6 +403,8 @@ __global__ void k_begin(AlignCall* __restrict__ call, AlignDyn* __restrict__ dyn
   s.pose[0] = p0; s.pose[1] = p1; s.pose[2] = wrap_angle(p2);
   dyn->state[1] = s;            // launch 0 has parity 0 and reads slot 1
   dyn->state[0] = IterState{};
+  dyn->ls[0] = LineSearch{};
+  dyn->ls[1] = LineSearch{};
 }
 
 // ---- per-point pieces of the body (rows a4-a6) ------------------------------------------
@@ -582,7 +621,8 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
       for (int j = 0; j < 3; ++j) g[j] = s_red[6 + j];
       score = s_red[9];
       n_hit = (int)(s_red[10] + 0.5);
-      done = gn_update(pose, H, g, n_hit, iter, status, prm, fixed_iterations);
+      done = gn_update(pose, H, g, n_hit, iter, status, prm, fixed_iterations, score, &dyn->ls[parity ^ 1],
+                       &dyn->ls[parity], writer);
     } else {
 #pragma unroll
       for (int j = 0; j < 6; ++j) H[j] = 0.0;

@@ -46,7 +46,7 @@ int32_t upload_static3(ndt3d_handle* h) {
   c->grid = h->grid;
   ndt::SolveParams& p = c->prm;
   p.d1 = (float)h->prm.d1; p.d2 = (float)h->prm.d2;
-  p.hessian_mode = 0; p.max_iterations = h->prm.max_iterations; p.min_hits = h->prm.min_hits; p.pad = 0;
+  p.hessian_mode = 0; p.max_iterations = h->prm.max_iterations; p.min_hits = h->prm.min_hits; p.line_search = h->prm.line_search;
   p.eps_trans = h->prm.eps_trans; p.eps_rot = h->prm.eps_rot;
   p.step_max_trans = h->prm.step_max_trans; p.step_max_rot = h->prm.step_max_rot;
   HIP_TRY(hipMemcpyAsync(h->d_static, c, sizeof(ndt::AlignStatic3), hipMemcpyHostToDevice, h->stream));

@@ -44,9 +44,18 @@ struct AlignCall3 {
   int n;
   int fixed_iterations;
 };
+struct LineSearch3 {      // LineSearch of ndt2d_kernels.hpp for a 6-vector pose
+  double base[6];
+  double step[6];
+  double score;
+  double alpha;
+  int trials;
+  int valid;
+};
 struct AlignDyn3 {
   IterState3 state[2];
   float partials[2][kNumAcc3][kMaxBlocks];
+  LineSearch3 ls[2];
 };
 
 // ---------------------------------------------------------------------------- bounds
@@ -241,7 +250,24 @@ __device__ __forceinline__ bool solve6(const double* A /*6x6 row-major, symmetri
 }
 
 __device__ __forceinline__ bool gn_update3(double* pose, const double* A, const double* g, int n_hit, int& iter,
-                                           int& status, const SolveParams& p, int fixed_iterations) {
+                                           int& status, const SolveParams& p, int fixed_iterations, double score,
+                                           const LineSearch3* ls_in, LineSearch3* ls_out, bool write) {
+  if (p.line_search > 0 && ls_in->valid && ls_in->trials < p.line_search &&
+      (n_hit < p.min_hits || score < ls_in->score - kLineSearchTol * fabs(ls_in->score))) {
+    LineSearch3 ls = *ls_in;
+    ls.alpha *= 0.5;
+    ls.trials += 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pose[i] = ls.base[i] + ls.alpha * ls.step[i];
+#pragma unroll
+    for (int i = 3; i < 6; ++i) pose[i] = wrap_angle(ls.base[i] + ls.alpha * ls.step[i]);
+    if (write) *ls_out = ls;
+    iter += 1;
+    status = 0;
+    if (fixed_iterations > 0) return iter >= fixed_iterations;
+    if (iter >= p.max_iterations) { status = 1; return true; }
+    return false;
+  }
   if (n_hit < p.min_hits) { status = 3; return true; }
   double d[6];
   if (!solve6(A, g, d)) { status = 2; return true; }
@@ -250,6 +276,11 @@ __device__ __forceinline__ bool gn_update3(double* pose, const double* A, const 
   double alpha = 1.0;
   if (nt2 > p.step_max_trans * p.step_max_trans) alpha = p.step_max_trans / sqrt(nt2);
   if (nr2 * alpha * alpha > p.step_max_rot * p.step_max_rot) alpha = p.step_max_rot / sqrt(nr2);
+  if (p.line_search > 0 && write) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { ls_out->base[i] = pose[i]; ls_out->step[i] = d[i] * alpha; }
+    ls_out->score = score; ls_out->alpha = 1.0; ls_out->trials = 0; ls_out->valid = 1;
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) pose[i] += d[i] * alpha;
 #pragma unroll
@@ -262,6 +293,7 @@ __device__ __forceinline__ bool gn_update3(double* pose, const double* A, const 
   return false;
 }
 
+// Per-call part of the context (k_begin of the 2D path).
 __global__ void k_begin3(AlignCall3* __restrict__ call, AlignDyn3* __restrict__ dyn, const float* sx,
                          const float* sy, const float* sz, int n, double p0, double p1, double p2, double p3,
                          double p4, double p5, int fixed_iterations) {
@@ -274,6 +306,8 @@ __global__ void k_begin3(AlignCall3* __restrict__ call, AlignDyn3* __restrict__ 
   s.pose[3] = wrap_angle(p3); s.pose[4] = wrap_angle(p4); s.pose[5] = wrap_angle(p5);
   dyn->state[1] = s;
   dyn->state[0] = IterState3{};
+  dyn->ls[0] = LineSearch3{};
+  dyn->ls[1] = LineSearch3{};
 }
 
 __device__ __forceinline__ void copy_state3(IterState3* dst, const IterState3* src, int have_partials) {
@@ -352,7 +386,8 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     const double score = s_red[27];
     const int n_hit = (int)(s_red[28] + 0.5);
     int status = 0;
-    const bool done = gn_update3(pose, A, g, n_hit, iter, status, prm, fixed_iterations);
+    const bool done = gn_update3(pose, A, g, n_hit, iter, status, prm, fixed_iterations, score, &dyn->ls[parity ^ 1],
+                                 &dyn->ls[parity], writer);
     if (writer) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) { cur->pose[j] = pose[j]; cur->g[j] = g[j]; }

@@ -68,6 +68,12 @@ typedef struct ndt2d_params {
   int32_t min_hits;        /* fewer hits than this => NDT_TOO_FEW_HITS             */
   int32_t overlap_grids;   /* 0 or 1: one grid; 4: Biber's four grids shifted by half a cell, every
                               point scores against all four (single-pair 2D path only)  */
+  int32_t line_search;     /* 0: plain Gauss-Newton steps.  n in 1..16: backtracking line search - an
+                              evaluation that scores worse than the pose its step started from (or
+                              leaves the map) halves the step and retries from that pose, at most n
+                              times per step; every trial is one evaluation and counts as one
+                              iteration; convergence is tested on accepted evaluations only */
+  int32_t reserved;
 } ndt2d_params;
 
 /* ---- result (row a9) ------------------------------------------------------------ */

@@ -59,6 +59,7 @@ class NdtParams:
     step_max_rot: float = 0.2
     min_hits: int = 3
     overlap: int = 1                   # 1: single grid; 4: Biber's four grids shifted by half a cell
+    line_search: int = 0               # >0: backtracking, at most this many halvings per step
 
 
 @dataclass
@@ -363,8 +364,32 @@ def wrap_angle(t: float) -> float:
     return t
 
 
-def gn_update(pose, H, g, n_hit, it, prm: NdtParams):
-    """One a8 step.  Returns (new_pose, iterations, status, done)."""
+LS_TOL = 1e-3   # a trial is rejected when its score is below (1 - LS_TOL) x the score it started from:
+                # above the cell-flip noise of the score, so float32 and float64 evaluations agree on it
+
+
+def gn_update(pose, H, g, n_hit, it, prm: NdtParams, score: float = 0.0, ls: dict | None = None):
+    """One a8 step.  Returns (new_pose, iterations, status, done).
+
+    With prm.line_search > 0 and a state dict `ls` (backtracking line search, SURVEY 8f rank 3;
+    [BUILD]: step halving, Armijo constant 0): the evaluation handed in is first judged as a
+    TRIAL of the previous step - if it scored worse than the pose that step started from (or
+    left the map), the step is halved and re-tried from that pose, at most prm.line_search
+    times; every trial costs one evaluation and counts as one iteration.  Convergence is only
+    tested on accepted evaluations."""
+    use_ls = prm.line_search > 0 and ls is not None
+    if use_ls and ls.get("valid") and ls["trials"] < prm.line_search and \
+            (n_hit < prm.min_hits or score < ls["score"] - LS_TOL * abs(ls["score"])):
+        ls["alpha"] *= 0.5
+        ls["trials"] += 1
+        b, st, a = ls["base"], ls["step"], ls["alpha"]
+        pose = (b[0] + a * st[0], b[1] + a * st[1], wrap_angle(b[2] + a * st[2]))
+        it += 1
+        if prm.fixed_iterations > 0:
+            return pose, it, NDT_OK, it >= prm.fixed_iterations
+        if it >= prm.max_iterations:
+            return pose, it, NDT_NOT_CONVERGED, True
+        return pose, it, NDT_OK, False
     if n_hit < prm.min_hits:
         return pose, it, NDT_TOO_FEW_HITS, True
     d, ok = solve3(H, g)
@@ -378,6 +403,9 @@ def gn_update(pose, H, g, n_hit, it, prm: NdtParams):
     if nr * alpha > prm.step_max_rot:
         alpha = prm.step_max_rot / nr
     d = d * alpha
+    if use_ls:
+        ls.update(valid=True, base=pose, step=(float(d[0]), float(d[1]), float(d[2])), score=float(score),
+                  alpha=1.0, trials=0)
     pose = (pose[0] + d[0], pose[1] + d[1], wrap_angle(pose[2] + d[2]))
     it += 1
     if prm.fixed_iterations > 0:
@@ -399,11 +427,12 @@ def align(grid: Grid2D, sx, sy, init_pose, prm: NdtParams, mirror32: bool = Fals
     if n_valid < 1:
         return {"pose": pose, "H": np.zeros((3, 3)), "g": np.zeros(3), "score": 0.0,
                 "n_hit": 0, "iterations": 0, "status": NDT_TOO_FEW_CELLS}
+    ls = {} if prm.line_search > 0 else None
     while True:
         H, g, score, n_hit = evaluate(grid, sx, sy, pose, prm, mirror32)
         if trace is not None:
             trace.append({"pose": pose, "H": H.copy(), "g": g.copy(), "score": score, "n_hit": n_hit})
-        pose, it, status, done = gn_update(pose, H, g, n_hit, it, prm)
+        pose, it, status, done = gn_update(pose, H, g, n_hit, it, prm, score, ls)
         if done:
             return {"pose": pose, "H": H, "g": g, "score": score, "n_hit": n_hit,
                     "iterations": it, "status": status}

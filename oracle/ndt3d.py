@@ -38,6 +38,7 @@ class Ndt3Params:
     step_max_trans: float = 1.0
     step_max_rot: float = 0.2
     min_hits: int = 6
+    line_search: int = 0               # as NdtParams.line_search (oracle/ndt2d.py gn_update)
 
 
 @dataclass
@@ -256,7 +257,22 @@ def solve_ldl(H: np.ndarray, g: np.ndarray):
     return np.zeros(n), False
 
 
-def gn_update3(pose, H, g, n_hit, it, prm: Ndt3Params):
+def gn_update3(pose, H, g, n_hit, it, prm: Ndt3Params, score: float = 0.0, ls: dict | None = None):
+    """6-DoF twin of oracle/ndt2d.py gn_update(), backtracking line search included."""
+    from .ndt2d import LS_TOL
+    use_ls = prm.line_search > 0 and ls is not None
+    if use_ls and ls.get("valid") and ls["trials"] < prm.line_search and \
+            (n_hit < prm.min_hits or score < ls["score"] - LS_TOL * abs(ls["score"])):
+        ls["alpha"] *= 0.5
+        ls["trials"] += 1
+        b, st, a = ls["base"], ls["step"], ls["alpha"]
+        pose = tuple(b[i] + a * st[i] for i in range(3)) + tuple(wrap_angle(b[i] + a * st[i]) for i in range(3, 6))
+        it += 1
+        if prm.fixed_iterations > 0:
+            return pose, it, NDT_OK, it >= prm.fixed_iterations
+        if it >= prm.max_iterations:
+            return pose, it, NDT_NOT_CONVERGED, True
+        return pose, it, NDT_OK, False
     if n_hit < prm.min_hits:
         return pose, it, NDT_TOO_FEW_HITS, True
     d, ok = solve_ldl(H, g)
@@ -270,6 +286,8 @@ def gn_update3(pose, H, g, n_hit, it, prm: Ndt3Params):
     if nr * alpha > prm.step_max_rot:
         alpha = prm.step_max_rot / nr
     d = d * alpha
+    if use_ls:
+        ls.update(valid=True, base=pose, step=tuple(float(v) for v in d), score=float(score), alpha=1.0, trials=0)
     pose = (pose[0] + d[0], pose[1] + d[1], pose[2] + d[2],
             wrap_angle(pose[3] + d[3]), wrap_angle(pose[4] + d[4]), wrap_angle(pose[5] + d[5]))
     it += 1
@@ -288,11 +306,12 @@ def align3(grid: Grid3D, sx, sy, sz, init_pose, prm: Ndt3Params, mirror32: bool 
     if grid.n_valid < 1:
         return {"pose": pose, "H": np.zeros((6, 6)), "g": np.zeros(6), "score": 0.0, "n_hit": 0,
                 "iterations": 0, "status": NDT_TOO_FEW_CELLS}
+    ls = {} if prm.line_search > 0 else None
     while True:
         H, g, score, n_hit = evaluate3(grid, sx, sy, sz, pose, prm, mirror32)
         if trace is not None:
             trace.append({"pose": pose, "H": H.copy(), "g": g.copy(), "score": score, "n_hit": n_hit})
-        pose, it, status, done = gn_update3(pose, H, g, n_hit, it, prm)
+        pose, it, status, done = gn_update3(pose, H, g, n_hit, it, prm, score, ls)
         if done:
             return {"pose": pose, "H": H, "g": g, "score": score, "n_hit": n_hit, "iterations": it,
                     "status": status}

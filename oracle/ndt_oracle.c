@@ -30,7 +30,9 @@ typedef struct orc_params {   /* same layout as ndt2d_params (include/ndt_hip.h)
   double eps_trans, eps_rot;
   double step_max_trans, step_max_rot;
   int32_t min_hits;
-  int32_t reserved;
+  int32_t reserved;          /* overlap_grids: single grid only in this port */
+  int32_t line_search;       /* > 0: backtracking, at most this many halvings per step */
+  int32_t reserved2;
 } orc_params;
 
 typedef struct orc_result {   /* same layout as ndt2d_result */
@@ -261,15 +263,34 @@ int32_t orc2d_align(const orc_grid2d* g, const float* sx, const float* sy, size_
     out->status = 4;
     return 4;
   }
+  /* backtracking line search state: oracle/ndt2d.py gn_update() */
+  double ls_base[3] = {0, 0, 0}, ls_step[3] = {0, 0, 0}, ls_score = 0.0, ls_alpha = 1.0;
+  int ls_valid = 0, ls_trials = 0;
   for (;;) {
     double d[3];
     orc2d_evaluate(g, sx, sy, n, pose, p, threads, out->H, out->g, &out->score, &out->n_hit);
+    if (p->line_search > 0 && ls_valid && ls_trials < p->line_search &&
+        (out->n_hit < p->min_hits || out->score < ls_score - 1e-3 * fabs(ls_score))) {
+      ls_alpha *= 0.5;
+      ls_trials += 1;
+      pose[0] = ls_base[0] + ls_alpha * ls_step[0];
+      pose[1] = ls_base[1] + ls_alpha * ls_step[1];
+      pose[2] = wrap_angle(ls_base[2] + ls_alpha * ls_step[2]);
+      it += 1;
+      if (p->fixed_iterations > 0) { if (it >= p->fixed_iterations) break; continue; }
+      if (it >= p->max_iterations) { status = 1; break; }
+      continue;
+    }
     if (out->n_hit < p->min_hits) { status = 3; break; }
     if (!solve3(out->H, out->g, d)) { status = 2; break; }
     const double nt = sqrt(d[0] * d[0] + d[1] * d[1]), nr = fabs(d[2]);
     double alpha = 1.0;
     if (nt > p->step_max_trans) alpha = p->step_max_trans / nt;
     if (nr * alpha > p->step_max_rot) alpha = p->step_max_rot / nr;
+    if (p->line_search > 0) {
+      for (int j = 0; j < 3; ++j) { ls_base[j] = pose[j]; ls_step[j] = d[j] * alpha; }
+      ls_score = out->score; ls_alpha = 1.0; ls_trials = 0; ls_valid = 1;
+    }
     pose[0] += d[0] * alpha;
     pose[1] += d[1] * alpha;
     pose[2] = wrap_angle(pose[2] + d[2] * alpha);
