@@ -349,7 +349,7 @@ def main():
             "grid_build_ms": round(grid_ms, 4),
             "converged_align": {"ms_per_call": round(conv_ms, 4), "iterations": rc.iterations,
                                 "note": "ndt2d_align_dev in converged mode, host call to result in host memory "
-                                        "(8-launch chunks polled for convergence); median of 20"},
+                                        "(16-launch chunks, done flag raised in pinned host memory); median of 20"},
             "scaling_note": "N=1 times the single-pair config 3 named by BASELINE.json's metric; N>1 lines time "
                             "the sharded loop-closure batch (config 4).  Read multi-GPU scaling against this "
                             "line's batch.value (same workload, one GPU), not against value.",

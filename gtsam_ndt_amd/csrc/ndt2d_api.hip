@@ -40,6 +40,8 @@ struct ndt2d_handle {
   AlignDyn* d_dyn = nullptr;
   AlignStatic* h_static = nullptr;         // pinned
   IterState* h_state = nullptr;            // pinned
+  int* h_flag = nullptr;                   // pinned: set by the launch that ends a converged-mode loop
+  hipEvent_t chunk_ev[2] = {nullptr, nullptr};
   int last_parity = 0;
   bool pending = false;
   // binned grid build scratch (ndt2d_build.hpp)
@@ -51,6 +53,7 @@ struct ndt2d_handle {
   hipGraph_t graph = nullptr;
   int graph_launches = 0, graph_blocks = 0, graph_mode = -1;
   bool use_graph = true;
+  int check_every = 16;                    // converged mode: launches per chunk (NDT_DEBUG_CHUNK overrides)
 };
 
 namespace {
@@ -311,27 +314,26 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
     h->h_state->done = 2;               // marks "result already on the host"
     return NDT_OK;
   }
-  hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, d_sx, d_sy, (int)n, pose[0], pose[1],
-                     pose[2], fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations);
   const int fixed = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
   const int K = fixed > 0 ? fixed : h->prm.max_iterations;
   const int blocks = blocks_for(n);
+  const bool chunked = h->use_graph && check_every > 0 && fixed == 0;
+  __atomic_store_n(h->h_flag, 0, __ATOMIC_RELAXED);
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, d_sx, d_sy, (int)n, pose[0], pose[1],
+                     pose[2], fixed, chunked ? h->h_state : (IterState*)nullptr, chunked ? h->h_flag : (int*)nullptr);
   int k = 0;
   if (h->use_graph) {
-    if (check_every > 0 && fixed == 0) {
-      // converged mode: replay an even-length chunk until the done flag is seen
+    if (chunked) {
+      // converged mode: chunks of launches until the finishing launch raises the host flag
       const int chunk = check_every + (check_every & 1);
       const int32_t gs = ensure_graph(h, chunk, blocks);
       if (gs != NDT_OK) return gs;
-      while (k <= K) {
-        HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
-        k += chunk;
-        if (k > K) break;
-        HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[1], sizeof(IterState), hipMemcpyDeviceToHost,
-                               h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->h_state->done) break;
-      }
+      bool seen = false;
+      HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->chunk_ev, h->h_flag, chunk, K + 1, &seen));
+      HIP_TRY(hipGetLastError());
+      h->pending = !seen;                              // seen: the result is in h_state already
+      h->last_parity = 1;                              // even chunk length: the last launch had parity 1
+      return NDT_OK;
     } else {
       const int32_t gs = ensure_graph(h, K + 1, blocks);
       if (gs != NDT_OK) return gs;
@@ -470,9 +472,14 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipMalloc((void**)&h->d_dyn, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_static, sizeof(AlignStatic), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_state, sizeof(IterState), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  *h->h_flag = 0;
+  for (hipEvent_t& e : h->chunk_ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
   { const char* e = std::getenv("NDT_DEBUG_NO_GRAPH"); h->use_graph = !(e && e[0] == '1'); }
+  { const char* e = std::getenv("NDT_DEBUG_CHUNK"); const int v = e ? std::atoi(e) : 0; if (v >= 2 && v <= 128) h->check_every = v; }
   { const char* e = std::getenv("NDT_DEBUG_ATOMIC_BUILD"); h->use_binned_build = !(e && e[0] == '1'); }
   *out = h;
   return NDT_OK;
@@ -486,8 +493,9 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
                  h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {h->h_static, h->h_state, h->h_small};
+  void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag};
   for (void* p : host) if (p) (void)hipHostFree(p);
+  for (hipEvent_t e : h->chunk_ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return NDT_OK;
@@ -618,7 +626,7 @@ int32_t ndt2d_align_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, s
                         const double init_pose[3], ndt2d_result* out) {
   if (!h || !d_sx || !d_sy || !init_pose || !out) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  const int32_t st = run_align(h, d_sx, d_sy, n, init_pose, -1, 8);
+  const int32_t st = run_align(h, d_sx, d_sy, n, init_pose, -1, h->check_every);
   if (st != NDT_OK) return st;
   return ndt2d_align_finish(h, out);
 }

@@ -93,6 +93,10 @@ struct AlignCall {
   const float* sy;
   int n;
   int fixed_iterations;
+  // converged mode: pinned host memory the finishing launch writes the final state and a flag
+  // into, so the host sees the end of the loop without a copy or a stream sync (null = off)
+  IterState* host_state;
+  int* host_flag;
 };
 struct AlignDyn {
   IterState state[2];
@@ -393,12 +397,15 @@ __device__ __forceinline__ bool gn_update(double* pose, const double* H, const d
 
 // Per-call part of the context, written from kernel arguments (no host buffer lifetime).
 __global__ void k_begin(AlignCall* __restrict__ call, AlignDyn* __restrict__ dyn, const float* sx,
-                        const float* sy, int n, double p0, double p1, double p2, int fixed_iterations) {
+                        const float* sy, int n, double p0, double p1, double p2, int fixed_iterations,
+                        IterState* host_state, int* host_flag) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   call->sx = sx;
   call->sy = sy;
   call->n = n;
   call->fixed_iterations = fixed_iterations;
+  call->host_state = host_state;
+  call->host_flag = host_flag;
   IterState s = {};
   s.pose[0] = p0; s.pose[1] = p1; s.pose[2] = wrap_angle(p2);
   dyn->state[1] = s;            // launch 0 has parity 0 and reads slot 1
@@ -575,6 +582,8 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
   const int fixed_iterations = call->fixed_iterations;
   const float* __restrict__ sx = call->sx;
   const float* __restrict__ sy = call->sy;
+  IterState* const host_state = call->host_state;
+  int* const host_flag = call->host_flag;
   float4 pv[3];
   if (!(EXP & 1) && wave < 4) {          // waves 0..3 own the 12 partial rows
     const float* part = &dyn->partials[parity ^ 1][0][0];
@@ -587,7 +596,8 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
   asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.rec),
                "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations), "s"(prm.eps_trans),
                "s"(prm.eps_rot), "s"(prm.step_max_trans), "s"(prm.step_max_rot), "s"(ps_pose0), "s"(ps_pose1),
-               "s"(ps_pose2), "s"(ps_iter), "s"(ps_done), "s"(ps_have), "s"(fixed_iterations));
+               "s"(ps_pose2), "s"(ps_iter), "s"(ps_done), "s"(ps_have), "s"(fixed_iterations), "s"(host_state),
+               "s"(host_flag));
   const int stride = kMaxBlocks * THREADS;
   int i = blockIdx.x * THREADS + tid;
   float x = 0.f, y = 0.f, x1 = 0.f, y1 = 0.f;
@@ -645,6 +655,11 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
       o.have_partials = 1;
       o.pad = 0;
       *cur = o;
+      if (done && host_flag) {           // tell the host directly: state first, then the flag
+        *host_state = o;
+        __threadfence_system();
+        __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     if (done) return;                    // uniform
   } else if (writer) {

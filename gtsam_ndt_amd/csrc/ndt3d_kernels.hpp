@@ -39,10 +39,13 @@ struct AlignStatic3 {
   Grid3Dev grid;
   SolveParams prm;
 };
+struct IterState3;
 struct AlignCall3 {
   const float* sx; const float* sy; const float* sz;
   int n;
   int fixed_iterations;
+  IterState3* host_state;    // as AlignCall: pinned host memory for the finishing launch, or null
+  int* host_flag;
 };
 struct LineSearch3 {      // LineSearch of ndt2d_kernels.hpp for a 6-vector pose
   double base[6];
@@ -296,11 +299,13 @@ __device__ __forceinline__ bool gn_update3(double* pose, const double* A, const 
 // Per-call part of the context (k_begin of the 2D path).
 __global__ void k_begin3(AlignCall3* __restrict__ call, AlignDyn3* __restrict__ dyn, const float* sx,
                          const float* sy, const float* sz, int n, double p0, double p1, double p2, double p3,
-                         double p4, double p5, int fixed_iterations) {
+                         double p4, double p5, int fixed_iterations, IterState3* host_state, int* host_flag) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   call->sx = sx; call->sy = sy; call->sz = sz;
   call->n = n;
   call->fixed_iterations = fixed_iterations;
+  call->host_state = host_state;
+  call->host_flag = host_flag;
   IterState3 s = {};
   s.pose[0] = p0; s.pose[1] = p1; s.pose[2] = p2;
   s.pose[3] = wrap_angle(p3); s.pose[4] = wrap_angle(p4); s.pose[5] = wrap_angle(p5);
@@ -340,6 +345,8 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
   const float* __restrict__ sx = call->sx;
   const float* __restrict__ sy = call->sy;
   const float* __restrict__ sz = call->sz;
+  IterState3* const host_state = call->host_state;
+  int* const host_flag = call->host_flag;
   float4 pv[8];
   {
     const float* part = &dyn->partials[parity ^ 1][0][0];
@@ -389,13 +396,21 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     const bool done = gn_update3(pose, A, g, n_hit, iter, status, prm, fixed_iterations, score, &dyn->ls[parity ^ 1],
                                  &dyn->ls[parity], writer);
     if (writer) {
+      auto store = [&](IterState3* o) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) { cur->pose[j] = pose[j]; cur->g[j] = g[j]; }
+        for (int j = 0; j < 6; ++j) { o->pose[j] = pose[j]; o->g[j] = g[j]; }
 #pragma unroll
-      for (int j = 0; j < 21; ++j) cur->H[j] = s_red[j];
-      cur->score = score;
-      cur->n_hit = n_hit; cur->iter = iter; cur->status = status;
-      cur->done = done ? 1 : 0; cur->have_partials = 1; cur->pad = 0;
+        for (int j = 0; j < 21; ++j) o->H[j] = s_red[j];
+        o->score = score;
+        o->n_hit = n_hit; o->iter = iter; o->status = status;
+        o->done = done ? 1 : 0; o->have_partials = 1; o->pad = 0;
+      };
+      store(cur);
+      if (done && host_flag) {           // tell the host directly: state first, then the flag
+        store(host_state);
+        __threadfence_system();
+        __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     if (done) return;
   } else if (writer) {
