@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--batch-points", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="N=1: skip the extra loop-closure batch figure")
+    ap.add_argument("--host-path", action="store_true",
+                    help="N=1: also time the host-pointer entry points (PCIe-inclusive; reported beside value)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--with-3d", action="store_true",
                     help="N=1: also time BASELINE config 5 (3D SE(3), 131072-point pair) and report it in '3d'")
@@ -140,8 +142,24 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
     h = nd.pack_pairs(pairs)
     t = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
     truth = np.array([p["pose"] for p in pairs])
-    del pairs, h
+    del pairs
     b = NdtBatch2D(device=dev_index, fixed_iterations=K_GN)
+    host_ms = None
+    if dist is None and a.host_path:
+        # the same batch through the host-pointer entry point (pageable host arrays -> upload ->
+        # kernel -> results back): the PCIe-inclusive figure DESIGN.md section 7 quotes; never `value`
+        from gtsam_ndt_amd import _lib as L
+        from gtsam_ndt_amd.matcher import RESULT_DOUBLES
+        outh = np.zeros(ppr * RESULT_DOUBLES, dtype=np.float64)
+        lat = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            L.check(b._lib.ndt2d_batch_align(b._h, h["tx"].ctypes.data, h["ty"].ctypes.data, h["toff"].ctypes.data,
+                                             h["sx"].ctypes.data, h["sy"].ctypes.data, h["soff"].ctypes.data,
+                                             h["init"].ctypes.data, ppr, outh.ctypes.data), "ndt2d_batch_align")
+            lat.append(time.perf_counter() - t0)
+        host_ms = 1e3 * min(lat[1:])
+    del h
     # one explicit (non-default) stream carries the kernel, the HIP events and - through
     # torch.distributed's stream ordering - the RCCL all_gather that consumes the results
     side = torch.cuda.Stream(device=dev)
@@ -212,6 +230,13 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
                                   "dtheta_rad": float(err[:, 2].max()),
                                   "note": "fixed 30 iterations vs the generating pose (sampling noise included)"},
     }
+    if host_ms is not None:
+        nbytes = ppr * npts * 16
+        out["host_path"] = {"ms_per_step_incl_pcie": round(host_ms, 2),
+                            "iters_per_s_incl_pcie": round(ppr * K_GN / (host_ms * 1e-3), 1),
+                            "uploaded_MB": round(nbytes / 1e6, 1),
+                            "note": "ndt2d_batch_align with pageable host arrays: upload + kernel + results; "
+                                    "reported beside value, never as value"}
     b.close()
     return out
 
@@ -358,6 +383,20 @@ def main():
                                     "cpu_ref": "oracle/ndt2d.py float64 (reference implementation unavailable)"},
         }
         m.close()
+        if a.host_path:
+            mh = NdtMatcher2D(device=dev_index, fixed_iterations=K_GN)
+            lt, la = [], []
+            for _ in range(5):
+                t1 = time.perf_counter(); mh.set_target(d["tx"], d["ty"]); lt.append(time.perf_counter() - t1)
+            for _ in range(10):
+                t1 = time.perf_counter(); rh = mh.align(d["sx"], d["sy"], d["init"]); la.append(time.perf_counter() - t1)
+            mh.close()
+            assert rh.iterations == K_GN
+            out["host_path"] = {"set_target_ms_incl_pcie": round(1e3 * float(np.median(lt[1:])), 4),
+                                "align_ms_incl_pcie": round(1e3 * float(np.median(la[1:])), 4),
+                                "iters_per_s_incl_pcie": round(K_GN / float(np.median(la[1:])), 1),
+                                "note": "ndt2d_set_target / ndt2d_align with pageable host arrays (8 MB / 0.8 MB "
+                                        "uploads included); reported beside value, never as value"}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, a.cpu_seconds)
         if not a.no_batch:
