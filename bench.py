@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--batch-points", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="N=1: skip the extra loop-closure batch figure")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="N=1: skip the converged-mode call latency (keeps a profile's k_iterate population to the timed steps)")
     ap.add_argument("--host-path", action="store_true",
                     help="N=1: also time the host-pointer entry points (PCIe-inclusive; reported beside value)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -353,10 +355,10 @@ def main():
         rc = mc.align(sx, sy, d["init"])
         # what a caller sees per scan in converged mode: host call -> result on the host
         lat = []
-        for _ in range(20):
+        for _ in range(0 if a.no_latency else 20):
             t1 = time.perf_counter(); rl = mc.align(sx, sy, d["init"]); lat.append(time.perf_counter() - t1)
-        assert rl.pose == rc.pose
-        conv_ms = 1e3 * float(np.median(lat))
+            assert rl.pose == rc.pose
+        conv_ms = 1e3 * float(np.median(lat)) if lat else None
         mc.close()
         prm = oracle.NdtParams()
         ref = oracle.align(oracle.build_grid(d["tx"], d["ty"], prm), d["sx"], d["sy"], d["init"], prm)
@@ -372,7 +374,7 @@ def main():
                        "gn_iterations_per_step": K_GN, "hessian": "gauss-newton"},
             "roofline": roofline,
             "grid_build_ms": round(grid_ms, 4),
-            "converged_align": {"ms_per_call": round(conv_ms, 4), "iterations": rc.iterations,
+            "converged_align": {"ms_per_call": None if conv_ms is None else round(conv_ms, 4), "iterations": rc.iterations,
                                 "note": "ndt2d_align_dev in converged mode, host call to result in host memory "
                                         "(16-launch chunks, done flag raised in pinned host memory); median of 20"},
             "scaling_note": "N=1 times the single-pair config 3 named by BASELINE.json's metric; N>1 lines time "
