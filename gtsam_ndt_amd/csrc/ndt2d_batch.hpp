@@ -45,7 +45,8 @@ struct BatchArgs {
   int n_pairs;
   int min_points;
   int fixed_iterations;
-  int pad;
+  int chain;                 // 1: a later level of a coarse-to-fine run - start from out[pair].pose,
+                             // add to its iteration count, leave pairs whose earlier level failed
   double cell;
   double eig_ratio;
   SolveParams prm;
@@ -184,6 +185,14 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     const float* __restrict__ sy = a.sy + s0;
     double pose[3] = {a.init[3 * pair], a.init[3 * pair + 1], wrap_angle(a.init[3 * pair + 2])};
     ResultDev* out = a.out + pair;
+    int iter_base = 0;
+    if (a.chain) {                                   // uniform
+      const int pst = __builtin_amdgcn_readfirstlane(out->status);
+      if (pst != 0 && pst != 1) return;              // the coarser level's failure is the pair's result
+      pose[0] = out->pose[0]; pose[1] = out->pose[1]; pose[2] = out->pose[2];
+      iter_base = __builtin_amdgcn_readfirstlane(out->iterations);
+      __syncthreads();                               // every wave has read out[pair] before anyone rewrites it
+    }
 
     // ---- a1: bounding box of the target and grid geometry (oracle/ndt2d.py grid_geometry)
     {
@@ -234,7 +243,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     static_assert(kFixShift == 22, "fix_scale literal");
     __syncthreads();                                 // misc is rewritten below
     if (status != 0) {                               // uniform
-      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, 0, 0, status);
+      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, iter_base, 0, status);
       return;
     }
 
@@ -257,7 +266,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     int s = block_excl_scan(local, s_scan, &nslot);
     nslot = __builtin_amdgcn_readfirstlane(nslot);
     if (nslot > kBatchMaxSlots - 1 || nslot < 1) {   // uniform (record 0 is the dummy)
-      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, 0, 0, nslot < 1 ? 4 : kStatusCapacity);
+      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, iter_base, 0, nslot < 1 ? 4 : kStatusCapacity);
       return;
     }
     for (int k = c0; k < c1; ++k) {
@@ -331,7 +340,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     }
     if (__builtin_amdgcn_readfirstlane(misc[6]) < 1) {   // uniform
       __syncthreads();
-      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, 0, 0, 4);
+      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, iter_base, 0, 4);
       return;
     }
 
@@ -436,7 +445,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       __syncthreads();
     }
     if (tid == 0)
-      write_result(out, pose, &bc[3], &bc[9], bc[12], misc[9], (int)(bc[13] + 0.5), misc[10]);
+      write_result(out, pose, &bc[3], &bc[9], bc[12], misc[9] + iter_base, (int)(bc[13] + 0.5), misc[10]);
   }
 }
 

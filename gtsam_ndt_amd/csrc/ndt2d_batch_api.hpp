@@ -1,12 +1,15 @@
 // C-ABI of the loop-closure batch (included at the end of ndt2d_api.hip: one translation unit,
 // so the kernels of ndt2d_kernels.hpp are defined once).
 #pragma once
+#include <vector>
+
 #include "ndt2d_batch.hpp"
 
 struct ndt2d_batch {
   int device = 0;
   hipStream_t stream = nullptr;
-  ndt2d_params prm{};
+  ndt2d_params prm{};                 // the finest (last) level
+  std::vector<ndt2d_params> levels;   // coarse to fine; one entry unless created as a pyramid
   int n_cu = 0;
   unsigned int* d_queue = nullptr;
   // staging for the host-pointer entry point
@@ -16,7 +19,7 @@ struct ndt2d_batch {
   double* d_init = nullptr;
   ndt2d_result* d_out = nullptr;
   size_t pcap = 0;
-  ndt2d_handle* fallback = nullptr;   // global-memory path for pairs over the LDS capacity
+  std::vector<ndt2d_handle*> fallback;   // global-memory path (one handle per level) for pairs over the LDS capacity
 };
 
 static_assert(sizeof(ndt::ResultDev) == sizeof(ndt2d_result), "ResultDev mirrors ndt2d_result");
@@ -35,24 +38,30 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
   a.out = reinterpret_cast<ndt::ResultDev*>(d_out);
   a.queue = b->d_queue;
   a.n_pairs = (int)n_pairs;
-  a.min_points = b->prm.min_points;
-  a.fixed_iterations = b->prm.fixed_iterations;
-  a.cell = b->prm.cell_size;
-  a.eig_ratio = b->prm.eig_ratio;
-  a.prm.d1 = (float)b->prm.d1; a.prm.d2 = (float)b->prm.d2;
-  a.prm.hessian_mode = b->prm.hessian_mode;
-  a.prm.max_iterations = b->prm.max_iterations;
-  a.prm.min_hits = b->prm.min_hits;
-  a.prm.line_search = b->prm.line_search;
-  a.prm.eps_trans = b->prm.eps_trans; a.prm.eps_rot = b->prm.eps_rot;
-  a.prm.step_max_trans = b->prm.step_max_trans; a.prm.step_max_rot = b->prm.step_max_rot;
-  HIP_TRY(hipMemsetAsync(b->d_queue, 0, 16, st));
   const int blocks = (int)(n_pairs < (size_t)b->n_cu ? n_pairs : (size_t)b->n_cu);
-  if (b->prm.hessian_mode == NDT_HESSIAN_NEWTON)
-    hipLaunchKernelGGL(ndt::k_batch<1>, dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
-  else
-    hipLaunchKernelGGL(ndt::k_batch<0>, dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
-  HIP_TRY(hipGetLastError());
+  // one launch per resolution level; a later level starts every pair from the pose the
+  // previous one left in d_out (stream order is the only synchronisation between levels)
+  for (size_t lv = 0; lv < b->levels.size(); ++lv) {
+    const ndt2d_params& p = b->levels[lv];
+    a.chain = lv > 0 ? 1 : 0;
+    a.min_points = p.min_points;
+    a.fixed_iterations = p.fixed_iterations;
+    a.cell = p.cell_size;
+    a.eig_ratio = p.eig_ratio;
+    a.prm.d1 = (float)p.d1; a.prm.d2 = (float)p.d2;
+    a.prm.hessian_mode = p.hessian_mode;
+    a.prm.max_iterations = p.max_iterations;
+    a.prm.min_hits = p.min_hits;
+    a.prm.line_search = p.line_search;
+    a.prm.eps_trans = p.eps_trans; a.prm.eps_rot = p.eps_rot;
+    a.prm.step_max_trans = p.step_max_trans; a.prm.step_max_rot = p.step_max_rot;
+    HIP_TRY(hipMemsetAsync(b->d_queue, 0, 16, st));
+    if (p.hessian_mode == NDT_HESSIAN_NEWTON)
+      hipLaunchKernelGGL(ndt::k_batch<1>, dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
+    else
+      hipLaunchKernelGGL(ndt::k_batch<0>, dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
+    HIP_TRY(hipGetLastError());
+  }
   return NDT_OK;
 }
 
@@ -70,12 +79,34 @@ int32_t ensure_dev(T** p, size_t* cap, size_t n) {
 
 extern "C" {
 
-int32_t ndt2d_batch_create(const ndt2d_params* p, int32_t device_id, ndt2d_batch** out) {
+// The library's standard coarse-to-fine schedule: 4c and 2c cells with a
+// stronger eigenvalue clamp, loose stops and a proportionally larger step limit, then `fine`.
+int32_t ndt2d_default_pyramid(const ndt2d_params* fine, ndt2d_params levels[3]) {
+  if (!fine || !levels) return NDT_ERR_INVALID_ARG;
+  const double mult[2] = {4.0, 2.0}, ratio[2] = {0.1, 0.03};
+  for (int i = 0; i < 2; ++i) {
+    ndt2d_params p = *fine;
+    p.cell_size = fine->cell_size * mult[i];
+    p.eig_ratio = ratio[i];
+    p.eps_trans = 1e-3; p.eps_rot = 1e-4;
+    p.max_iterations = 30; p.fixed_iterations = 0;
+    p.step_max_trans = fine->step_max_trans * mult[i];
+    levels[i] = p;
+  }
+  levels[2] = *fine;
+  return NDT_OK;
+}
+
+int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels, int32_t device_id, ndt2d_batch** out) {
   if (!out) return NDT_ERR_INVALID_ARG;
   *out = nullptr;
-  const int32_t st = check_params(p);
-  if (st != NDT_OK) return st;
-  if (p->overlap_grids == 4) { set_error("overlapping grids are implemented on the single-pair path only"); return NDT_ERR_INVALID_ARG; }
+  if (!levels || n_levels < 1 || n_levels > 8) return NDT_ERR_INVALID_ARG;
+  for (int32_t i = 0; i < n_levels; ++i) {
+    const int32_t st = check_params(&levels[i]);
+    if (st != NDT_OK) return st;
+    if (levels[i].overlap_grids == 4) { set_error("overlapping grids are implemented on the single-pair path only"); return NDT_ERR_INVALID_ARG; }
+  }
+  const ndt2d_params* p = &levels[n_levels - 1];
   const int ndev = ndt_device_count();
   if (ndev <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }
   if (device_id < 0 || device_id >= ndev) return NDT_ERR_INVALID_ARG;
@@ -83,6 +114,7 @@ int32_t ndt2d_batch_create(const ndt2d_params* p, int32_t device_id, ndt2d_batch
   if (!b) return NDT_ERR_ALLOC;
   b->device = device_id;
   b->prm = *p;
+  b->levels.assign(levels, levels + n_levels);
   auto fail = [&](int32_t code) { ndt2d_batch_destroy(b); return code; };
   if (hipSetDevice(device_id) != hipSuccess) return fail(NDT_ERR_HIP);
   hipDeviceProp_t prop;
@@ -99,13 +131,18 @@ int32_t ndt2d_batch_create(const ndt2d_params* p, int32_t device_id, ndt2d_batch
   return NDT_OK;
 }
 
+int32_t ndt2d_batch_create(const ndt2d_params* p, int32_t device_id, ndt2d_batch** out) {
+  if (!p) { if (out) *out = nullptr; return NDT_ERR_INVALID_ARG; }
+  return ndt2d_batch_create_pyramid(p, 1, device_id, out);
+}
+
 int32_t ndt2d_batch_destroy(ndt2d_batch* b) {
   if (!b) return NDT_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void* dev[] = {b->d_queue, b->d_tx, b->d_ty, b->d_sx, b->d_sy, b->d_toff, b->d_soff, b->d_init, b->d_out};
   for (void* p : dev) if (p) (void)hipFree(p);
-  if (b->fallback) ndt2d_destroy(b->fallback);
+  for (ndt2d_handle* f : b->fallback) ndt2d_destroy(f);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return NDT_OK;
@@ -161,12 +198,25 @@ int32_t ndt2d_batch_align(ndt2d_batch* b, const float* tx, const float* ty, cons
   // pairs whose grid does not fit the on-chip capacity go through the global-memory path
   for (size_t k = 0; k < n_pairs; ++k) {
     if (results[k].status != NDT_ERR_CAPACITY) continue;
-    if (!b->fallback) {
-      st = ndt2d_create(&b->prm, b->device, &b->fallback);
-      if (st != NDT_OK) return st;
+    if (b->fallback.empty()) {
+      for (const ndt2d_params& lp : b->levels) {
+        ndt2d_handle* f = nullptr;
+        st = ndt2d_create(&lp, b->device, &f);
+        if (st != NDT_OK) return st;
+        b->fallback.push_back(f);
+      }
     }
-    st = ndt2d_set_target(b->fallback, tx + toff[k], ty + toff[k], toff[k + 1] - toff[k]);
-    if (st == NDT_OK) st = ndt2d_align(b->fallback, sx + soff[k], sy + soff[k], soff[k + 1] - soff[k], init + 3 * k, &results[k]);
+    double pose[3] = {init[3 * k], init[3 * k + 1], init[3 * k + 2]};
+    int total = 0;
+    for (ndt2d_handle* f : b->fallback) {
+      st = ndt2d_set_target(f, tx + toff[k], ty + toff[k], toff[k + 1] - toff[k]);
+      if (st == NDT_OK) st = ndt2d_align(f, sx + soff[k], sy + soff[k], soff[k + 1] - soff[k], pose, &results[k]);
+      if (st < 0) break;
+      total += results[k].iterations;
+      results[k].iterations = total;
+      if (results[k].status != NDT_OK && results[k].status != NDT_NOT_CONVERGED) break;
+      for (int j = 0; j < 3; ++j) pose[j] = results[k].pose[j];
+    }
     if (st < 0) return st;
   }
   return NDT_OK;

@@ -11,6 +11,7 @@
 struct ndt2d_multi {
   std::vector<ndt2d_batch*> ctx;
   ndt2d_params prm{};
+  int32_t iterations_hint = 30;      // expected evaluations per pair over all levels (shard balancing)
 };
 
 int32_t ndt2d_multi_destroy(ndt2d_multi* m) {
@@ -20,24 +21,33 @@ int32_t ndt2d_multi_destroy(ndt2d_multi* m) {
   return NDT_OK;
 }
 
-int32_t ndt2d_multi_create(const ndt2d_params* p, const int32_t* device_ids, int32_t n_devices, ndt2d_multi** out) {
+int32_t ndt2d_multi_create_pyramid(const ndt2d_params* levels, int32_t n_levels, const int32_t* device_ids,
+                                   int32_t n_devices, ndt2d_multi** out) {
   if (!out) return NDT_ERR_INVALID_ARG;
   *out = nullptr;
-  if (!p || n_devices < 0 || (n_devices > 0 && !device_ids)) return NDT_ERR_INVALID_ARG;
+  if (!levels || n_levels < 1 || n_devices < 0 || (n_devices > 0 && !device_ids)) return NDT_ERR_INVALID_ARG;
   const int visible = ndt_device_count();
   if (visible <= 0) { ndt::set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }
   ndt2d_multi* m = new (std::nothrow) ndt2d_multi();
   if (!m) return NDT_ERR_ALLOC;
-  m->prm = *p;
+  m->prm = levels[n_levels - 1];
+  m->iterations_hint = 0;
+  for (int32_t i = 0; i < n_levels; ++i)
+    m->iterations_hint += levels[i].fixed_iterations > 0 ? levels[i].fixed_iterations : 30;
   const int n = n_devices > 0 ? n_devices : visible;
   for (int i = 0; i < n; ++i) {
     ndt2d_batch* b = nullptr;
-    const int32_t st = ndt2d_batch_create(p, n_devices > 0 ? device_ids[i] : i, &b);
+    const int32_t st = ndt2d_batch_create_pyramid(levels, n_levels, n_devices > 0 ? device_ids[i] : i, &b);
     if (st != NDT_OK) { ndt2d_multi_destroy(m); return st; }
     m->ctx.push_back(b);
   }
   *out = m;
   return NDT_OK;
+}
+
+int32_t ndt2d_multi_create(const ndt2d_params* p, const int32_t* device_ids, int32_t n_devices, ndt2d_multi** out) {
+  if (!p) { if (out) *out = nullptr; return NDT_ERR_INVALID_ARG; }
+  return ndt2d_multi_create_pyramid(p, 1, device_ids, n_devices, out);
 }
 
 int32_t ndt2d_multi_device_count(const ndt2d_multi* m) { return m ? static_cast<int32_t>(m->ctx.size()) : 0; }
@@ -74,8 +84,7 @@ int32_t ndt2d_multi_align(ndt2d_multi* m, const float* tx, const float* ty, cons
     return NDT_ERR_INVALID_ARG;
   const int nd = static_cast<int>(m->ctx.size());
   std::vector<uint64_t> begin(nd + 1);
-  const int32_t hint = m->prm.fixed_iterations > 0 ? m->prm.fixed_iterations : 30;
-  int32_t st = ndt2d_multi_plan(nd, toff, soff, n_pairs, hint, begin.data());
+  int32_t st = ndt2d_multi_plan(nd, toff, soff, n_pairs, m->iterations_hint, begin.data());
   if (st != NDT_OK) return st;
   std::vector<int32_t> status(nd, NDT_OK);
   std::vector<std::string> message(nd);

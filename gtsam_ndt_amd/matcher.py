@@ -189,6 +189,23 @@ def _results_from_bytes(buf: np.ndarray, n: int):
     return [_to_result(r) for r in arr]
 
 
+def pyramid_params(fine: L.Params2D | None = None, **overrides):
+    """The library's standard 3-level coarse-to-fine schedule (ndt2d_default_pyramid) as a
+    ctypes array of ndt2d_params, for NdtBatch2D(levels=...) / NdtMulti2D(levels=...)."""
+    lib = L.load()
+    fine = fine if fine is not None else default_params(**overrides)
+    levels = (L.Params2D * 3)()
+    L.check(lib.ndt2d_default_pyramid(C.byref(fine), levels), "ndt2d_default_pyramid")
+    return levels
+
+
+def _as_levels(levels):
+    if isinstance(levels, C.Array):
+        return levels, len(levels)
+    arr = (L.Params2D * len(levels))(*levels)
+    return arr, len(levels)
+
+
 def _concat_pairs(targets, sources, inits):
     n = len(targets)
     toff = np.zeros(n + 1, dtype=np.uint64)
@@ -216,7 +233,8 @@ class NdtMulti2D:
     """The loop-closure batch over several devices from one host process (one context and one
     host thread per device).  Mirrors ndt2d_multi_* of include/ndt_hip.h."""
 
-    def __init__(self, devices=None, params: L.Params2D | None = None, **overrides):
+    def __init__(self, devices=None, params: L.Params2D | None = None, levels=None, **overrides):
+        """levels: coarse-to-fine list of Params2D (e.g. pyramid_params()); otherwise one level."""
         self._lib = L.load()
         self.params = params if params is not None else default_params(**overrides)
         if params is not None:
@@ -228,7 +246,12 @@ class NdtMulti2D:
         else:
             ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
             n = len(devices)
-        L.check(self._lib.ndt2d_multi_create(C.byref(self.params), ids, n, C.byref(h)), "ndt2d_multi_create")
+        if levels is not None:
+            self._levels, nl = _as_levels(levels)
+            self.params = self._levels[nl - 1]
+            L.check(self._lib.ndt2d_multi_create_pyramid(self._levels, nl, ids, n, C.byref(h)), "ndt2d_multi_create_pyramid")
+        else:
+            L.check(self._lib.ndt2d_multi_create(C.byref(self.params), ids, n, C.byref(h)), "ndt2d_multi_create")
         self._h = h
 
     def close(self):
@@ -266,14 +289,21 @@ class NdtBatch2D:
     (one persistent workgroup per CU, target grid resident in LDS).  Mirrors
     ndt2d_batch_* of include/ndt_hip.h."""
 
-    def __init__(self, device: int = 0, params: L.Params2D | None = None, **overrides):
+    def __init__(self, device: int = 0, params: L.Params2D | None = None, levels=None, **overrides):
+        """levels: coarse-to-fine list of Params2D (e.g. pyramid_params()); otherwise one level."""
         self._lib = L.load()
         self.params = params if params is not None else default_params(**overrides)
         if params is not None:
             for k, v in overrides.items():
                 setattr(self.params, k, v)
         h = C.c_void_p()
-        L.check(self._lib.ndt2d_batch_create(C.byref(self.params), int(device), C.byref(h)), "ndt2d_batch_create")
+        if levels is not None:
+            self._levels, nl = _as_levels(levels)
+            self.params = self._levels[nl - 1]
+            L.check(self._lib.ndt2d_batch_create_pyramid(self._levels, nl, int(device), C.byref(h)),
+                    "ndt2d_batch_create_pyramid")
+        else:
+            L.check(self._lib.ndt2d_batch_create(C.byref(self.params), int(device), C.byref(h)), "ndt2d_batch_create")
         self._h = h
         self._keep = None
 

@@ -179,6 +179,14 @@ int32_t ndt2d_polar_to_points_dev(const float* d_ranges, size_t n, double angle_
  * point re-runs such pairs through the general path transparently. */
 typedef struct ndt2d_batch ndt2d_batch;
 int32_t ndt2d_batch_create(const ndt2d_params* p, int32_t device_id, ndt2d_batch** out);
+/* Coarse-to-fine over the batch (loop-closure candidates start from poor guesses): levels[0..n)
+ * ordered coarse to fine, at most 8; every pair runs level 0 from its init and each later level
+ * from the pose the previous one reached; a level that ends with a status other than NDT_OK /
+ * NDT_NOT_CONVERGED ends the pair with that status; iterations are summed over levels and
+ * H, g, score, n_hit are those of the last level run.  One kernel launch per level, the clouds
+ * stay where they are.  ndt2d_default_pyramid fills the standard 3-level schedule (4c, 2c, c). */
+int32_t ndt2d_default_pyramid(const ndt2d_params* fine, ndt2d_params levels[3]);
+int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels, int32_t device_id, ndt2d_batch** out);
 int32_t ndt2d_batch_destroy(ndt2d_batch* b);
 int32_t ndt2d_batch_align(ndt2d_batch* b, const float* tx, const float* ty, const uint64_t* toff,
                           const float* sx, const float* sy, const uint64_t* soff, const double* init,
@@ -198,6 +206,8 @@ void* ndt2d_batch_stream(ndt2d_batch* b);
  * (The one-process-per-GPU deployment with an RCCL gather is gtsam_ndt_amd/dist.py.) */
 typedef struct ndt2d_multi ndt2d_multi;
 int32_t ndt2d_multi_create(const ndt2d_params* p, const int32_t* device_ids, int32_t n_devices, ndt2d_multi** out);
+int32_t ndt2d_multi_create_pyramid(const ndt2d_params* levels, int32_t n_levels, const int32_t* device_ids,
+                                   int32_t n_devices, ndt2d_multi** out);
 int32_t ndt2d_multi_destroy(ndt2d_multi* m);
 int32_t ndt2d_multi_device_count(const ndt2d_multi* m);
 /* Arguments as ndt2d_batch_align (host pointers).  Returns the first failing shard's status. */

@@ -197,6 +197,18 @@ class NdtBatchHip {
     const int32_t st = ndt2d_batch_create(&params, device, &b_);
     if (st != NDT_OK) throw NdtError(st, "ndt2d_batch_create");
   }
+  // coarse-to-fine: `levels` ordered coarse to fine (see standardPyramid)
+  NdtBatchHip(const std::vector<ndt2d_params>& levels, int device) {
+    const int32_t st = ndt2d_batch_create_pyramid(levels.data(), static_cast<int32_t>(levels.size()), device, &b_);
+    if (st != NDT_OK) throw NdtError(st, "ndt2d_batch_create_pyramid");
+  }
+  // the library's 3-level schedule (4c, 2c, c) around `fine`
+  static std::vector<ndt2d_params> standardPyramid(const ndt2d_params& fine = NdtMatcherHip::defaultParams()) {
+    std::vector<ndt2d_params> lv(3);
+    const int32_t st = ndt2d_default_pyramid(&fine, lv.data());
+    if (st != NDT_OK) throw NdtError(st, "ndt2d_default_pyramid");
+    return lv;
+  }
   ~NdtBatchHip() { ndt2d_batch_destroy(b_); }
   NdtBatchHip(const NdtBatchHip&) = delete;
   NdtBatchHip& operator=(const NdtBatchHip&) = delete;
@@ -225,6 +237,12 @@ class NdtMultiHip {
     const int32_t st = ndt2d_multi_create(&params, devices.empty() ? nullptr : devices.data(),
                                           static_cast<int32_t>(devices.size()), &m_);
     if (st != NDT_OK) throw NdtError(st, "ndt2d_multi_create");
+  }
+  NdtMultiHip(const std::vector<ndt2d_params>& levels, const std::vector<int32_t>& devices) {
+    const int32_t st = ndt2d_multi_create_pyramid(levels.data(), static_cast<int32_t>(levels.size()),
+                                                  devices.empty() ? nullptr : devices.data(),
+                                                  static_cast<int32_t>(devices.size()), &m_);
+    if (st != NDT_OK) throw NdtError(st, "ndt2d_multi_create_pyramid");
   }
   ~NdtMultiHip() { ndt2d_multi_destroy(m_); }
   NdtMultiHip(const NdtMultiHip&) = delete;

@@ -35,6 +35,9 @@ int main(int argc, char** argv) {
     const ndt::NdtBatchHip::Cloud t{tx.data(), ty.data(), tx.size()}, s{sx.data(), sy.data(), sx.size()};
     const auto rs = b.align({t, t}, {s, s}, {guess, guess});
     std::printf("batch %.17g %.17g %.17g %d %d\n", rs[1].pose.x, rs[1].pose.y, rs[1].pose.theta, rs[1].iterations, rs[1].status);
+    ndt::NdtBatchHip bp(ndt::NdtBatchHip::standardPyramid(), 0);
+    const auto rp = bp.align({t}, {s}, {ndt::Pose2{guess.x + 0.5, guess.y - 0.4, guess.theta + 0.04}});
+    std::printf("pyramid %.17g %.17g %.17g %d %d\n", rp[0].pose.x, rp[0].pose.y, rp[0].pose.theta, rp[0].iterations, rp[0].status);
     ndt::NdtMultiHip mm(ndt::NdtMatcherHip::defaultParams(), {0, 0});   // two contexts on device 0
     const auto rm = mm.align({t, t, t}, {s, s, s}, {guess, guess, guess});
     std::printf("multi %.17g %.17g %.17g %d %d\n", rm[2].pose.x, rm[2].pose.y, rm[2].pose.theta, rm[2].iterations, rm[2].status);

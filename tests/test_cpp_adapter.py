@@ -61,4 +61,11 @@ def test_adapter_matches_oracle(exe, tmp_path, gpu_lib):
         assert np.abs(pose - np.array(ref["pose"])).max() < 1e-4
         assert int(lines[key][-1]) == 0
     assert lines["multi"] == lines["batch"]          # same kernel, same pair: bit-identical
+    # the coarse-to-fine batch through the adapter = the same call through the ctypes binding
+    from gtsam_ndt_amd.matcher import NdtBatch2D, pyramid_params
+    guess = (d["init"][0] + 0.5, d["init"][1] - 0.4, d["init"][2] + 0.04)
+    with NdtBatch2D(levels=pyramid_params()) as bp:
+        rp = bp.align([(d["tx"], d["ty"])], [(d["sx"], d["sy"])], [guess])[0]
+    got = [float(v) for v in lines["pyramid"][:3]]
+    assert got == list(rp.pose) and int(lines["pyramid"][3]) == rp.iterations and int(lines["pyramid"][4]) == rp.status
     assert abs(float(lines["infocov"][0]) - 1.0) < 1e-6

@@ -155,3 +155,58 @@ def test_multi_context_rejects_bad_devices(gpu_lib):
     from gtsam_ndt_amd._lib import NdtError
     with pytest.raises(NdtError):
         M.NdtMulti2D(devices=[0, 99])
+
+
+def _oracle_pyramid(p, init, levels):
+    """The frozen composition: level k starts from level k-1's pose; a status other than OK /
+    NOT_CONVERGED ends the pair; iterations add up (include/ndt_hip.h, ndt2d_batch_create_pyramid)."""
+    from oracle import ndt2d as o
+    pose, total, r = tuple(init), 0, None
+    for lv in levels:
+        prm = o.NdtParams(cell_size=lv.cell_size, min_points=lv.min_points, eig_ratio=lv.eig_ratio, d1=lv.d1, d2=lv.d2,
+                          hessian_mode=lv.hessian_mode, max_iterations=lv.max_iterations,
+                          fixed_iterations=lv.fixed_iterations, eps_trans=lv.eps_trans, eps_rot=lv.eps_rot,
+                          step_max_trans=lv.step_max_trans, step_max_rot=lv.step_max_rot, min_hits=lv.min_hits)
+        r = o.align(o.build_grid(p["tx"], p["ty"], prm), p["sx"], p["sy"], pose, prm)
+        total += r["iterations"]
+        if r["status"] not in (o.NDT_OK, o.NDT_NOT_CONVERGED):
+            break
+        pose = r["pose"]
+    r["iterations"] = total
+    return r
+
+
+def test_batch_pyramid_matches_oracle_composition_and_widens_the_basin(gpu_lib, pairs):
+    """Coarse-to-fine over the batch (one launch per level, poses chained on the device)."""
+    from gtsam_ndt_amd import matcher as M
+    levels = M.pyramid_params()
+    # guesses 0.5 m / 0.04 rad off the generating pose: outside the single-level basin
+    rng = np.random.default_rng(3)
+    sub = pairs[:8]
+    inits = [tuple(np.array(p["pose"]) + rng.uniform([-0.5, -0.5, -0.04], [0.5, 0.5, 0.04])) for p in sub]
+    T = [(p["tx"], p["ty"]) for p in sub]
+    S = [(p["sx"], p["sy"]) for p in sub]
+    with M.NdtBatch2D(levels=levels) as b:
+        res = b.align(T, S, inits)
+    with M.NdtBatch2D() as b1:
+        flat = b1.align(T, S, inits)
+    near = lambda r, p: np.abs(np.array(r.pose) - np.array(p["pose"])).max() < 0.02
+    n_pyr = sum(near(r, p) for r, p in zip(res, sub))
+    n_flat = sum(near(r, p) for r, p in zip(flat, sub))
+    assert n_pyr >= n_flat and n_pyr >= 6, (n_pyr, n_flat)
+    for p, init, r in zip(sub, inits, res):
+        ref = _oracle_pyramid(p, init, levels)
+        assert r.status == ref["status"]
+        if near(r, p):          # trajectories that reach the optimum are stable; compare those to 1e-4
+            e = np.abs(np.array(r.pose) - np.array(ref["pose"]))
+            assert e.max() < 1e-4, (r.pose, ref["pose"])
+            assert abs(r.iterations - ref["iterations"]) <= 6
+    # the multi-device context takes the same schedule
+    with M.NdtMulti2D(devices=[0, 0], levels=levels) as mm:
+        rm = mm.align(T, S, inits)
+    assert [r.pose for r in rm] == [r.pose for r in res]
+    # a level that fails ends the pair with that status: 3 target points give no valid cell at any level
+    with M.NdtBatch2D(levels=levels) as b:
+        bad = b.align([(sub[0]["tx"][:3], sub[0]["ty"][:3]), T[1]], [S[0], S[1]], inits[:2])
+    assert bad[0].status == 4 and bad[0].iterations == 0
+    assert bad[1].pose == res[1].pose
