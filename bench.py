@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-batch", action="store_true", help="N=1: skip the extra loop-closure batch figure")
     ap.add_argument("--no-latency", action="store_true",
                     help="N=1: skip the converged-mode call latency (keeps a profile's k_iterate population to the timed steps)")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="N=1: also time BASELINE configs 1 and 2 (single pair) and config 5 (3D) for the per-config table")
     ap.add_argument("--host-path", action="store_true",
                     help="N=1: also time the host-pointer entry points (PCIe-inclusive; reported beside value)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -77,6 +79,49 @@ def hip_events_ms(stream_ptr: int, fn):
     e1.record(s)
     e1.synchronize()
     return e0.elapsed_time(e1)
+
+
+def stream_copy_GBps(dev, nbytes: int = 1 << 30, reps: int = 5) -> float:
+    """On-box streaming ceiling (SURVEY.md 8d asks for it beside the 8 TB/s spec): a device-to-
+    device copy of `nbytes`, counted as read + write traffic, best of `reps`."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    src.zero_()
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); dst.copy_(src); e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    return best
+
+
+def single_pair_rate(dev, dev_index, cfg: int, steps: int, warmup: int):
+    """Fixed-K alignments of one synthetic pair of BASELINE config `cfg` (1 or 2), as the
+    config-3 headline is timed: grid cached, inputs in HBM, HIP events over the timed region."""
+    from gtsam_ndt_amd import synth
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(cfg)
+    tx, ty, sx, sy = (torch.from_numpy(d[k]).to(dev) for k in ("tx", "ty", "sx", "sy"))
+    with NdtMatcher2D(device=dev_index, fixed_iterations=K_GN) as m:
+        m.set_target(tx, ty)
+        for _ in range(warmup):
+            m.align_async(sx, sy, d["init"])
+        m.finish()
+        t0 = time.perf_counter()
+        ev_ms = hip_events_ms(m.stream, lambda: [m.align_async(sx, sy, d["init"]) for _ in range(steps)])
+        m.finish()
+        el = time.perf_counter() - t0
+    n_src = int(sx.numel())
+    launch_us = 1e3 * ev_ms / (steps * (K_GN + 1))
+    alg = n_src * BYTES_PER_POINT_ITER
+    return {"config": cfg, "n_target": int(tx.numel()), "n_source": n_src,
+            "iters_per_s": round(steps * K_GN / el, 1), "avg_launch_us": round(launch_us, 3),
+            "algorithmic_GBps": round(alg / (launch_us * 1e-6) / 1e9, 1),
+            "frac_of_8TBps": round(alg / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
 
 
 def load_traffic():
@@ -269,6 +314,7 @@ def run_3d(a, dev, dev_index):
             "grid_build_ms_incl_upload": round(grid_ms, 3), "iterations": r.iterations,
             "pose_after_30": list(r.pose), "true_pose": list(d["pose"]),
             "roofline": {"bound": "hbm", "kernel": "k_iterate3", "algorithmic_bytes_per_launch": alg,
+                         "traffic": (load_traffic() or {}).get("bytes_per_launch_3d"),
                          "avg_launch_us_incl_host_sync": round(per_launch_us, 3),
                          "achieved": round(alg / (per_launch_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / (per_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
@@ -403,8 +449,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(d, a.cpu_seconds)
         if not a.no_batch:
             out["batch"] = run_batch(a, dev, dev_index, 0, 1, None, barrier)
-        if a.with_3d:
+        if a.with_3d or a.all_configs:
             out["3d"] = run_3d(a, dev, dev_index)
+        if a.all_configs:
+            out["configs_1_2"] = [single_pair_rate(dev, dev_index, c, a.steps, a.warmup) for c in (1, 2)]
+        copy_peak = stream_copy_GBps(dev)
+        out["roofline"]["stream_copy_GBps"] = round(copy_peak, 1)
+        out["roofline"]["frac_of_stream_copy"] = round(out["roofline"]["achieved"] / copy_peak, 4)
+        if "batch" in out:
+            out["batch"]["roofline"]["stream_copy_GBps"] = round(copy_peak, 1)
+            out["batch"]["roofline"]["frac_of_stream_copy"] = round(out["batch"]["roofline"]["achieved"] / copy_peak, 4)
     else:
         out = run_batch(a, dev, dev_index, rank, world, dist, barrier)
 

@@ -70,9 +70,10 @@ def traffic(kernel_prefix):
 
 it = traffic("k_iterate<")
 ba = traffic("k_batch<")
+i3 = traffic("k_iterate3")
 summary = {
     "source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes "
-              "(--kernel-trace only) of `bench.py --no-cpu-baseline --no-latency --steps 10 --warmup 2` on one MI355X",
+              "(--kernel-trace only) of `bench.py --no-cpu-baseline --no-latency --with-3d --steps 10 --warmup 2` on one MI355X",
     "units": "counter values are KiB; FETCH_SIZE scaled by the factor measured on the 1 GiB calibration reads "
              f"(tools/pmc_calib.hip): {fetch_scale:.4f} (MI355X_MICROARCH.md: gfx950 reports half of streamed "
              "reads); WRITE_SIZE taken as is (calibration: 1 GiB of stores reads 1048576 KiB)",
@@ -82,6 +83,9 @@ summary = {
 if it:
     summary["k_iterate"] = dict(it, algorithmic_bytes=3200000)
     summary["bytes_per_launch"] = it["read_bytes"] + it["write_bytes"]
+if i3:
+    summary["k_iterate3"] = dict(i3, algorithmic_bytes=6815744)
+    summary["bytes_per_launch_3d"] = i3["read_bytes"] + i3["write_bytes"]
 if ba:
     summary["k_batch"] = dict(ba, pairs=512)
     summary["batch_bytes_per_launch"] = ba["read_bytes"] + ba["write_bytes"]
