@@ -157,6 +157,45 @@ def to_source_frame(xw, yw, pose):
     return c * dx + s * dy, (-s) * dx + c * dy
 
 
+def lidar_scan2d(sc: Scene2D, pose, n_beams: int = 1440, fov: float = 2.0 * math.pi, seed: int = 0,
+                 sigma_r: float = 0.01, max_range: float = 30.0):
+    """What a planar lidar at `pose` (x, y, heading) sees of the scene: n_beams ranges over `fov`
+    (first beam at heading - fov/2, increment fov/n_beams), nearest segment hit per beam
+    (occlusion), Irwin-Hall(4) range noise of standard deviation sigma_r, +inf where nothing
+    within max_range is hit.  Returns (ranges float32 [n_beams], angle_min, angle_inc) in the
+    sensor frame - the input format of ndt2d_polar_to_points_dev.  Point density falls with
+    range and surfaces hide each other, unlike sample_scene()'s uniform arc-length sampling."""
+    px, py, th = pose
+    inc = fov / n_beams
+    a_min = -0.5 * fov
+    ang = th + a_min + inc * np.arange(n_beams, dtype=np.float64)
+    dx, dy = np.cos(ang)[:, None], np.sin(ang)[:, None]                    # [beams, 1]
+    ex, ey = (sc.bx - sc.ax)[None, :], (sc.by - sc.ay)[None, :]            # [1, segments]
+    wx, wy = (sc.ax - px)[None, :], (sc.ay - py)[None, :]
+    den = dx * ey - dy * ex
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = (wx * ey - wy * ex) / den                                      # distance along the beam
+        u = (wx * dy - wy * dx) / den                                      # position along the segment
+    hit = (np.abs(den) > 1e-12) & (t > 1e-6) & (u >= 0.0) & (u <= 1.0)
+    t = np.where(hit, t, np.inf)
+    r = t.min(axis=1)
+    i = np.arange(n_beams, dtype=np.uint64) * np.uint64(8)
+    noise = ((uniform01(seed, i) + uniform01(seed, i + np.uint64(1)))
+             + (uniform01(seed, i + np.uint64(2)) + uniform01(seed, i + np.uint64(3))) - 2.0) * (_SQRT3 * sigma_r)
+    r = np.where(r <= max_range, r + noise, np.inf)
+    return r.astype(np.float32), a_min, inc
+
+
+def scan_points(ranges, angle_min, angle_inc, range_min: float = 0.05, range_max: float = 30.0):
+    """Host restatement of ndt2d_polar_to_points_dev (float64 trig, float32 result)."""
+    r = np.asarray(ranges, dtype=np.float64)
+    ang = angle_min + angle_inc * np.arange(r.size, dtype=np.float64)
+    ok = np.isfinite(r) & (r >= range_min) & (r <= range_max)
+    x = np.where(ok, r * np.cos(ang), np.nan).astype(np.float32)
+    y = np.where(ok, r * np.sin(ang), np.nan).astype(np.float32)
+    return x, y
+
+
 T_STAR = (0.10, -0.08, 0.01)
 SIGMA = 0.03
 

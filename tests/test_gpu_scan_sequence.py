@@ -1,0 +1,64 @@
+"""The path as a SLAM front end drives it: range/bearing scans of a moving planar lidar (ray
+cast against the scene: range-dependent density, occlusion) -> ndt2d_polar_to_points_dev ->
+scan-to-submap alignment -> incremental submap update, scan after scan.  Each step is compared
+with the CPU oracle given the very same float32 points."""
+import math
+
+import numpy as np
+import pytest
+
+from gtsam_ndt_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+POSES = [(8.0 + 1.5 * k, 10.0 + 0.8 * k, 0.1 * k) for k in range(6)]
+
+
+def _world(x, y, pose):
+    c, s = np.float32(math.cos(pose[2])), np.float32(math.sin(pose[2]))
+    return ((c * x - s * y) + np.float32(pose[0])).astype(np.float32), ((s * x + c * y) + np.float32(pose[1])).astype(np.float32)
+
+
+def test_scan_to_submap_sequence_matches_oracle(gpu_lib):
+    import torch
+    from gtsam_ndt_amd.matcher import NdtMatcher2D, polar_to_points
+    from oracle import ndt2d as o
+    sc = synth.room_scene(4242, 30.0)
+    prm = o.NdtParams()
+    tx = ty = None
+    with NdtMatcher2D() as m:
+        for k, p in enumerate(POSES):
+            r, a0, da = synth.lidar_scan2d(sc, p, n_beams=7200, seed=100 + k)
+            dx, dy = polar_to_points(torch.from_numpy(r).cuda(), a0, da, 0.05, 30.0)     # device conversion
+            x, y = dx.cpu().numpy(), dy.cpu().numpy()
+            hx, hy = synth.scan_points(r, a0, da)
+            assert np.array_equal(np.isnan(x), np.isnan(hx))
+            np.testing.assert_allclose(x[~np.isnan(x)], hx[~np.isnan(hx)], rtol=0, atol=4e-6)
+            np.testing.assert_allclose(y[~np.isnan(y)], hy[~np.isnan(hy)], rtol=0, atol=4e-6)
+            if k == 0:
+                ok = ~np.isnan(x)
+                tx, ty = _world(x[ok], y[ok], p)
+                lo, hi = (tx.min(), ty.min()), (tx.max(), ty.max())
+                m.set_target(tx, ty)
+                continue
+            guess = (p[0] + 0.05, p[1] - 0.04, p[2] + 0.01)             # odometry-grade initial guess
+            # the device gets the scan as converted, NaN points (no return) included: they are ignored
+            got = m.align(dx, dy, guess)
+            ok = ~np.isnan(x)
+            ref = o.align(o.build_grid(tx, ty, prm), x[ok], y[ok], guess, prm)
+            assert got.status == 0 == ref["status"]
+            e = np.abs(np.array(got.pose) - np.array(ref["pose"]))
+            assert e.max() < 1e-4, (k, got.pose, ref["pose"])                # BASELINE: 1e-4 m / 1e-4 rad
+            assert abs(got.iterations - ref["iterations"]) <= 3 and got.n_hit == ref["n_hit"]
+            assert np.abs(np.array(got.pose) - np.array(p)).max() < 5e-3     # and it is the right answer
+            # submap update with the estimate (the oracle's, so that both sides keep identical inputs)
+            wx, wy = _world(x[ok], y[ok], ref["pose"])
+            inb = (wx >= lo[0]) & (wx <= hi[0]) & (wy >= lo[1]) & (wy <= hi[1])
+            assert m.add_target_points(wx[inb], wy[inb]) == 0
+            tx, ty = np.concatenate([tx, wx[inb]]), np.concatenate([ty, wy[inb]])
+        # the incrementally grown submap is the grid a rebuild from all points gives
+        g = o.build_grid(tx, ty, prm)
+        count, mean, icov = m.grid()
+        np.testing.assert_array_equal(count.astype(np.int64), g.count)
+        info = m.grid_info()
+        assert (info.width, info.height, info.n_valid) == (g.W, g.H, g.n_valid)

@@ -42,3 +42,37 @@ def test_config3_scan_sits_inside_the_submap():
     assert np.abs(d["tx"]).max() <= 100.5
     # the scan is expressed in the sensor frame: centred near the origin, 50 m across
     assert np.abs(d["sx"]).max() < 26.0 and np.abs(d["sy"]).max() < 26.0
+
+
+def test_lidar_scan2d_square_room_is_analytic():
+    """Sensor at the centre of a 10 m square: range along bearing a is 5 / max(|cos a|, |sin a|)."""
+    import math
+    sq = synth.Scene2D(np.array([0.0, 10.0, 10.0, 0.0]), np.array([0.0, 0.0, 10.0, 10.0]),
+                       np.array([10.0, 10.0, 0.0, 0.0]), np.array([0.0, 10.0, 10.0, 0.0]))
+    r, a0, da = synth.lidar_scan2d(sq, (5.0, 5.0, 0.0), n_beams=720, sigma_r=0.0)
+    ang = a0 + da * np.arange(720)
+    want = 5.0 / np.maximum(np.abs(np.cos(ang)), np.abs(np.sin(ang)))
+    np.testing.assert_allclose(r, want.astype(np.float32), rtol=1e-6)
+    # heading only rotates the beam fan; an occluder in front of the +x wall shortens those beams
+    r2, _, _ = synth.lidar_scan2d(sq, (5.0, 5.0, math.pi / 2), n_beams=720, sigma_r=0.0)
+    np.testing.assert_allclose(np.roll(r2, 180), r, rtol=1e-5)
+    occ = sq.concat(synth.Scene2D(np.array([7.0]), np.array([4.0]), np.array([7.0]), np.array([6.0])))
+    r3, _, _ = synth.lidar_scan2d(occ, (5.0, 5.0, 0.0), n_beams=720, sigma_r=0.0)
+    mid = 360                                   # bearing 0
+    assert abs(r3[mid] - 2.0) < 1e-6 and np.all(r3 <= r + 1e-6) and (r3 < r - 1.0).sum() > 50
+    # out of range -> +inf; scan_points turns those into NaN points
+    r4, a0, da = synth.lidar_scan2d(sq, (5.0, 5.0, 0.0), n_beams=90, sigma_r=0.0, max_range=5.5)
+    x, y = synth.scan_points(r4, a0, da)
+    assert np.isinf(r4).any() and np.array_equal(np.isnan(x), np.isinf(r4)) and np.array_equal(np.isnan(x), np.isnan(y))
+
+
+def test_lidar_scan2d_is_reproducible_and_noisy():
+    sc = synth.room_scene(4242, 30.0)
+    a = synth.lidar_scan2d(sc, (8.0, 10.0, 0.2), n_beams=1440, seed=3)[0]
+    b = synth.lidar_scan2d(sc, (8.0, 10.0, 0.2), n_beams=1440, seed=3)[0]
+    c = synth.lidar_scan2d(sc, (8.0, 10.0, 0.2), n_beams=1440, seed=4)[0]
+    clean = synth.lidar_scan2d(sc, (8.0, 10.0, 0.2), n_beams=1440, seed=3, sigma_r=0.0)[0]
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    ok = np.isfinite(clean)
+    assert ok.mean() > 0.9
+    assert 0.007 < np.std((a - clean)[ok]) < 0.013 and np.abs(a - clean)[ok].max() <= 2 * np.sqrt(3) * 0.01 + 1e-6
