@@ -520,6 +520,39 @@ int32_t ndt2d_set_target_dev(ndt2d_handle* h, const float* d_x, const float* d_y
   return set_target_impl(h, d_x, d_y, n);
 }
 
+int32_t ndt2d_add_target_points_dev(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n,
+                                    const double pose[3], size_t* n_outside, void* stream) {
+  if (!h || !d_x || !d_y || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  // order after the caller's producer stream, as ndt2d_set_target_dev does
+  if (stream && (hipStream_t)stream != h->stream) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ev, 0);
+    (void)hipEventDestroy(ev);
+    HIP_TRY(e);
+  }
+  const float* px = d_x;
+  const float* py = d_y;
+  if (pose) {
+    const int32_t st = ensure_points(&h->d_tx, &h->d_ty, &h->tcap, n);
+    if (st != NDT_OK) return st;
+    const float cs = (float)std::cos(pose[2]), sn = (float)std::sin(pose[2]);
+    hipLaunchKernelGGL(k_transform_points, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, d_x, d_y,
+                       n, cs, sn, (float)pose[0], (float)pose[1], h->d_tx, h->d_ty);
+    HIP_TRY(hipGetLastError());
+    px = h->d_tx; py = h->d_ty;
+  }
+  unsigned long long outside = 0;
+  const int32_t fs = accumulate_and_finalise(h, px, py, n, /*merge=*/true, &outside);
+  if (n_outside) *n_outside = (size_t)outside;
+  if (fs != NDT_OK) { h->has_target = false; return fs; }
+  h->n_points += n - (size_t)outside;
+  return upload_static(h);
+}
+
 int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y, size_t n, size_t* n_outside) {
   if (!h || !x || !y || n == 0) return NDT_ERR_INVALID_ARG;
   if (!h->has_target) return NDT_ERR_NO_TARGET;

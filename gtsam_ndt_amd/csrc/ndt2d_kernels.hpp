@@ -104,6 +104,21 @@ struct AlignDyn {
   LineSearch ls[2];       // ping-pong like state; touched only when prm.line_search > 0
 };
 
+// A scan moved into the map frame with the pose an alignment returned, before it is merged into
+// the submap (ndt2d_add_target_points_dev): float32 products and sums in a fixed order (no
+// contraction), so that a host restatement reproduces the points bit for bit.
+__global__ __launch_bounds__(kBlock) void k_transform_points(const float* __restrict__ x, const float* __restrict__ y,
+                                                              size_t n, float cs, float sn, float tx, float ty,
+                                                              float* __restrict__ ox, float* __restrict__ oy) {
+#pragma clang fp contract(off)      // hipcc's __fmul_rn is a plain `*` and would be fused into an fma
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[i], py = y[i];
+  const float a = cs * px, b = sn * py, c = sn * px, d = cs * py;
+  ox[i] = (a - b) + tx;
+  oy[i] = (c + d) + ty;
+}
+
 // ---------------------------------------------------------------------------- a1 bounds
 __global__ __launch_bounds__(kBlock) void k_bounds(const float* __restrict__ x,
                                                     const float* __restrict__ y, size_t n,

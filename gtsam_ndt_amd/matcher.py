@@ -116,9 +116,21 @@ class NdtMatcher2D:
         L.check(st, "ndt2d_set_target")
         return self.grid_info()
 
-    def add_target_points(self, x, y) -> int:
-        x, y = _host_f32(x), _host_f32(y)
+    def add_target_points(self, x, y, pose=None) -> int:
+        """Merge more points into the cached grid; returns how many fell outside its extent.
+        Device tensors may carry a pose (tx, ty, theta) that moves them into the map frame first."""
         out = C.c_size_t(0)
+        if _is_dev(x):
+            import torch
+            n = x.numel()
+            p = (C.c_double * 3)(*[float(v) for v in pose]) if pose is not None else None
+            L.check(self._lib.ndt2d_add_target_points_dev(self._h, _dev_ptr(x, n), _dev_ptr(y, n), n, p, C.byref(out),
+                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "ndt2d_add_target_points_dev")
+            return int(out.value)
+        if pose is not None:
+            raise ValueError("pose is applied on the device: pass device tensors")
+        x, y = _host_f32(x), _host_f32(y)
         L.check(self._lib.ndt2d_add_target_points(self._h, x.ctypes.data, y.ctypes.data, x.size, C.byref(out)),
                 "ndt2d_add_target_points")
         return int(out.value)

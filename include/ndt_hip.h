@@ -132,6 +132,14 @@ int32_t ndt2d_set_target_dev(ndt2d_handle* h, const float* d_x, const float* d_y
  * are counted in *n_outside (may be NULL) and ignored. */
 int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y, size_t n,
                                 size_t* n_outside);
+/* The same with the points already on the device, optionally moved into the map frame first:
+ * pose != NULL applies p' = R(theta) p + t in float32 (x' = (cs*x - sn*y) + tx, y' = (sn*x + cs*y)
+ * + ty with cs, sn = (float)cos/sin(theta), every operation rounded separately) - the pose an
+ * alignment of that scan returned - so a scan goes ranges -> points -> align -> submap without
+ * leaving the GPU.  NaN points (no return) are ignored.  `stream` is the stream that produced
+ * d_x/d_y (NULL: already complete); the call returns when the grid is updated. */
+int32_t ndt2d_add_target_points_dev(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n,
+                                    const double pose[3], size_t* n_outside, void* stream);
 int32_t ndt2d_get_grid_info(ndt2d_handle* h, ndt2d_grid_info* info);
 /* Copies the finalised cell records to host arrays of width*height entries each
  * (any pointer may be NULL): count, mean (x,y interleaved), icov (a,b,c interleaved). */

@@ -91,6 +91,15 @@ class NdtMatcherHip {
     check(ndt2d_add_target_points(h_, x, y, n, &outside), "ndt2d_add_target_points");
     return outside;
   }
+  // points already on the device, moved into the map frame by `pose` first (nullptr: as they are)
+  size_t addTargetPointsDev(const float* d_x, const float* d_y, size_t n, const Pose2* pose = nullptr,
+                            void* producer_stream = nullptr) {
+    size_t outside = 0;
+    const double p[3] = {pose ? pose->x : 0.0, pose ? pose->y : 0.0, pose ? pose->theta : 0.0};
+    check(ndt2d_add_target_points_dev(h_, d_x, d_y, n, pose ? p : nullptr, &outside, producer_stream),
+          "ndt2d_add_target_points_dev");
+    return outside;
+  }
   ndt2d_grid_info gridInfo() const { ndt2d_grid_info g; check(ndt2d_get_grid_info(h_, &g), "ndt2d_get_grid_info"); return g; }
 
   // (ii)+(iii)+solve: full alignment from an initial guess

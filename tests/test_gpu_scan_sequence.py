@@ -62,3 +62,37 @@ def test_scan_to_submap_sequence_matches_oracle(gpu_lib):
         np.testing.assert_array_equal(count.astype(np.int64), g.count)
         info = m.grid_info()
         assert (info.width, info.height, info.n_valid) == (g.W, g.H, g.n_valid)
+
+
+def test_device_side_submap_update_equals_host_side(gpu_lib):
+    """ndt2d_add_target_points_dev with a pose = transforming on the host (same float32 operation
+    order) and merging through the host entry point: identical grids, identical outside counts."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtMatcher2D, polar_to_points
+    sc = synth.room_scene(4242, 30.0)
+    r0, a0, da = synth.lidar_scan2d(sc, POSES[0], n_beams=7200, seed=100)
+    x0, y0 = synth.scan_points(r0, a0, da)
+    ok0 = ~np.isnan(x0)
+    tx, ty = _world(x0[ok0], y0[ok0], POSES[0])
+    r1, a1, da1 = synth.lidar_scan2d(sc, POSES[3], n_beams=7200, seed=103)
+    dx, dy = polar_to_points(torch.from_numpy(r1).cuda(), a1, da1, 0.05, 30.0)
+    x1, y1 = dx.cpu().numpy(), dy.cpu().numpy()
+    pose = (POSES[3][0] + 0.003, POSES[3][1] - 0.002, POSES[3][2] + 0.0004)
+    wx, wy = _world(x1, y1, pose)                                   # NaN beams stay NaN
+    with NdtMatcher2D() as a, NdtMatcher2D() as b:
+        a.set_target(tx, ty)
+        b.set_target(tx, ty)
+        out_a = a.add_target_points(wx, wy)
+        out_b = b.add_target_points(dx, dy, pose=pose)
+        assert out_a == out_b
+        ca, ma, ia = a.grid()
+        cb, mb, ib = b.grid()
+        assert ca.sum() > 1.5 * ok0.sum()                           # the second scan did go in
+        np.testing.assert_array_equal(ca, cb)
+        np.testing.assert_array_equal(ma, mb)
+        np.testing.assert_array_equal(ia, ib)
+        # without a pose the device points are merged as they are
+        c0 = a.add_target_points(torch.from_numpy(tx).cuda(), torch.from_numpy(ty).cuda())
+        d0 = b.add_target_points(tx, ty)
+        assert c0 == d0 == 0
+        np.testing.assert_array_equal(a.grid()[0], b.grid()[0])
