@@ -110,6 +110,7 @@ SIGNATURES = {
     "ndt2d_destroy": (C.c_int32, [_vp]),
     "ndt2d_set_target": (C.c_int32, [_vp, _vp, _vp, C.c_size_t]),
     "ndt2d_set_target_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "ndt2d_reserve_target": (C.c_int32, [_vp, C.c_double, C.c_double, C.c_double, C.c_double]),
     "ndt2d_add_target_points": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ndt2d_add_target_points_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp, C.POINTER(C.c_size_t), _vp]),
     "ndt2d_get_grid_info": (C.c_int32, [_vp, C.POINTER(GridInfo2D)]),

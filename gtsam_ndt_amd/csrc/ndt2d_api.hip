@@ -183,21 +183,8 @@ int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* 
   return st;
 }
 
-int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n) {
-  h->has_target = false;
-  if (n == 0) return NDT_ERR_INVALID_ARG;
-  // a1: bounding box on the device, geometry on the host (oracle/ndt2d.py grid_geometry)
-  unsigned int init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
-  unsigned int* hb = (unsigned int*)h->h_small;
-  std::memcpy(hb, init, sizeof(init));
-  HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, sizeof(init), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > 512 ? 512 : stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, sizeof(init), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  if (hb[0] == 0xFFFFFFFFu || hb[1] == 0u) { set_error("target has no finite point"); return NDT_ERR_INVALID_ARG; }
-  const float xmin = ordered_to_float(hb[0]), xmax = ordered_to_float(hb[1]);
-  const float ymin = ordered_to_float(hb[2]), ymax = ordered_to_float(hb[3]);
+// Grid geometry for a bounding box (oracle/ndt2d.py grid_geometry) and storage for its cells.
+int32_t setup_geometry(ndt2d_handle* h, float xmin, float xmax, float ymin, float ymax) {
   const double c = h->prm.cell_size;
   GridDev& g = h->grid;
   g.cell = c;
@@ -235,6 +222,25 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
     HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc)));
     h->cell_capacity = want;
   }
+  return NDT_OK;
+}
+
+int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n) {
+  h->has_target = false;
+  if (n == 0) return NDT_ERR_INVALID_ARG;
+  // a1: bounding box on the device, geometry on the host (oracle/ndt2d.py grid_geometry)
+  unsigned int init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+  unsigned int* hb = (unsigned int*)h->h_small;
+  std::memcpy(hb, init, sizeof(init));
+  HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > 512 ? 512 : stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, sizeof(init), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (hb[0] == 0xFFFFFFFFu || hb[1] == 0u) { set_error("target has no finite point"); return NDT_ERR_INVALID_ARG; }
+  const int32_t gs = setup_geometry(h, ordered_to_float(hb[0]), ordered_to_float(hb[1]), ordered_to_float(hb[2]),
+                                    ordered_to_float(hb[3]));
+  if (gs != NDT_OK) return gs;
   // a2 + a3
   const int32_t st = accumulate_and_finalise(h, d_x, d_y, n, /*merge=*/false, nullptr);
   if (st != NDT_OK) return st;
@@ -518,6 +524,23 @@ int32_t ndt2d_set_target_dev(ndt2d_handle* h, const float* d_x, const float* d_y
   HIP_TRY(hipSetDevice(h->device));
   if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // producer of d_x/d_y
   return set_target_impl(h, d_x, d_y, n);
+}
+
+int32_t ndt2d_reserve_target(ndt2d_handle* h, double xmin, double ymin, double xmax, double ymax) {
+  if (!h || !(xmin <= xmax) || !(ymin <= ymax) || !std::isfinite(xmin) || !std::isfinite(xmax) || !std::isfinite(ymin) ||
+      !std::isfinite(ymax))
+    return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  h->has_target = false;
+  const int32_t gs = setup_geometry(h, (float)xmin, (float)xmax, (float)ymin, (float)ymax);
+  if (gs != NDT_OK) return gs;
+  const size_t ncell = (size_t)h->grid.W * h->grid.H * h->grid.ngrid;
+  HIP_TRY(hipMemsetAsync(h->grid.acc, 0, ncell * sizeof(CellAcc), h->stream));
+  HIP_TRY(hipMemsetAsync(h->grid.rec, 0, 2 * ncell * sizeof(float4), h->stream));
+  h->n_valid = 0;
+  h->n_points = 0;
+  h->has_target = true;
+  return upload_static(h);
 }
 
 int32_t ndt2d_add_target_points_dev(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n,

@@ -116,6 +116,12 @@ class NdtMatcher2D:
         L.check(st, "ndt2d_set_target")
         return self.grid_info()
 
+    def reserve_target(self, xmin: float, ymin: float, xmax: float, ymax: float):
+        """Empty grid over a chosen extent; fill it with add_target_points()."""
+        L.check(self._lib.ndt2d_reserve_target(self._h, float(xmin), float(ymin), float(xmax), float(ymax)),
+                "ndt2d_reserve_target")
+        return self.grid_info()
+
     def add_target_points(self, x, y, pose=None) -> int:
         """Merge more points into the cached grid; returns how many fell outside its extent.
         Device tensors may carry a pose (tx, ty, theta) that moves them into the map frame first."""

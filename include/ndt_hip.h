@@ -127,6 +127,12 @@ int32_t ndt2d_destroy(ndt2d_handle* h);
 int32_t ndt2d_set_target(ndt2d_handle* h, const float* x, const float* y, size_t n);
 int32_t ndt2d_set_target_dev(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n,
                              void* stream);
+/* An empty grid over a caller-chosen extent (the region a submap is allowed to grow into),
+ * filled afterwards with ndt2d_add_target_points(_dev).  The geometry is what ndt2d_set_target
+ * derives from a cloud whose bounding box is [xmin, xmax] x [ymin, ymax] (as float32), so
+ * reserve + add of a cloud's own bounding box gives bit for bit the grid of ndt2d_set_target.
+ * Aligning against it before any cell is valid returns NDT_TOO_FEW_CELLS. */
+int32_t ndt2d_reserve_target(ndt2d_handle* h, double xmin, double ymin, double xmax, double ymax);
 /* Incremental submap update: bins n more points into the
  * cached grid's exact per-cell sums and re-finalises.  Points outside the cached extent
  * are counted in *n_outside (may be NULL) and ignored. */

@@ -85,6 +85,10 @@ class NdtMatcherHip {
   // (i) target grid from SoA float arrays
   void setTarget(const float* x, const float* y, size_t n) { check(ndt2d_set_target(h_, x, y, n), "ndt2d_set_target"); }
   void setTarget(const std::vector<float>& x, const std::vector<float>& y) { setTarget(x.data(), y.data(), x.size()); }
+  // empty grid over the extent the submap may grow into; fill with addTargetPoints(Dev)
+  void reserveTarget(double xmin, double ymin, double xmax, double ymax) {
+    check(ndt2d_reserve_target(h_, xmin, ymin, xmax, ymax), "ndt2d_reserve_target");
+  }
   // incremental submap update: returns the number of points outside the cached extent
   size_t addTargetPoints(const float* x, const float* y, size_t n) {
     size_t outside = 0;

@@ -96,3 +96,37 @@ def test_device_side_submap_update_equals_host_side(gpu_lib):
         d0 = b.add_target_points(tx, ty)
         assert c0 == d0 == 0
         np.testing.assert_array_equal(a.grid()[0], b.grid()[0])
+
+
+def test_reserved_extent_then_incremental_fill_equals_one_shot_build(gpu_lib):
+    """ndt2d_reserve_target: an empty grid over a chosen extent.  With the cloud's own bounding
+    box it has the geometry ndt2d_set_target derives, so filling it chunk by chunk ends in the
+    identical grid; before any cell is valid an alignment reports NDT_TOO_FEW_CELLS."""
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(2, n_tgt=60000, n_src=20000)
+    tx, ty = d["tx"], d["ty"]
+    with NdtMatcher2D() as a, NdtMatcher2D() as b:
+        ia = a.set_target(tx, ty)
+        ib = b.reserve_target(tx.min(), ty.min(), tx.max(), ty.max())
+        assert (ia.width, ia.height, ia.ox, ia.oy) == (ib.width, ib.height, ib.ox, ib.oy) and ib.n_valid == 0
+        r = b.align(d["sx"], d["sy"], d["init"])
+        assert r.status == L.NDT_TOO_FEW_CELLS and r.iterations == 0
+        for part in np.array_split(np.arange(tx.size), 5):
+            assert b.add_target_points(tx[part], ty[part]) == 0
+        assert b.grid_info().n_valid == ia.n_valid
+        for u, v in zip(a.grid(), b.grid()):
+            np.testing.assert_array_equal(u, v)
+        ra, rb = a.align(d["sx"], d["sy"], d["init"]), b.align(d["sx"], d["sy"], d["init"])
+        assert ra.pose == rb.pose and ra.iterations == rb.iterations
+        # a larger reserved region: the same cloud lands in it whole, points beyond it are counted
+        ic = b.reserve_target(tx.min() - 20.0, ty.min() - 20.0, tx.max() + 20.0, ty.max() + 20.0)
+        assert ic.width > ia.width and ic.height > ia.height
+        assert b.add_target_points(tx, ty) == 0
+        assert b.add_target_points(tx[:100] + np.float32(500.0), ty[:100]) == 100
+        rc = b.align(d["sx"], d["sy"], d["init"])
+        assert rc.status == 0 and np.abs(np.array(rc.pose) - np.array(ra.pose)).max() < 2e-3   # other cell phase
+        with pytest.raises(L.NdtError):
+            b.reserve_target(1.0, 0.0, 0.0, 1.0)
+        with pytest.raises(L.NdtError):
+            b.reserve_target(0.0, 0.0, float("nan"), 1.0)
