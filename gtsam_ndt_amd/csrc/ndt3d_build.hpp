@@ -100,23 +100,39 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
   }
   __syncthreads();
   const unsigned int p0 = tile_start[tile], p1 = tile_start[tile + 1];
-  for (unsigned int i = p0 + threadIdx.x; i < p1; i += kBinThreads) {
-    const float px = bx[i], py = by[i], pz = bz[i];
-    const int ix = (int)((px - g.ox) * g.inv_c), iy = (int)((py - g.oy) * g.inv_c), iz = (int)((pz - g.oz) * g.inv_c);
-    const int ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
-    const int uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
-    const int uz = fix_coord(pz, cell_centre(g.oz, iz, g.cell), g.fix_scale);
-    const int c = ((((iz - tz0) << kT3y) + (iy - ty0)) << kT3x) + (ix - tx0);
-    atomicAdd(&s_n[c], 1u);
-    atomicAdd(&s_sum[0][c], (unsigned long long)(long long)ux);
-    atomicAdd(&s_sum[1][c], (unsigned long long)(long long)uy);
-    atomicAdd(&s_sum[2][c], (unsigned long long)(long long)uz);
-    atomicAdd(&s_sum[3][c], prod64(ux, ux));
-    atomicAdd(&s_sum[4][c], prod64(ux, uy));
-    atomicAdd(&s_sum[5][c], prod64(ux, uz));
-    atomicAdd(&s_sum[6][c], prod64(uy, uy));
-    atomicAdd(&s_sum[7][c], prod64(uy, uz));
-    atomicAdd(&s_sum[8][c], prod64(uz, uz));
+  // 8 points in flight per thread: a lidar scan puts tens of thousands of points into the few
+  // tiles around the sensor, and a one-point loop pays the memory latency on every trip
+  constexpr int kU = 8;
+  for (unsigned int i = p0 + threadIdx.x; i < p1; i += kBinThreads * kU) {
+    float qx[kU], qy[kU], qz[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const unsigned int ii = i + u * kBinThreads;
+      qx[u] = ii < p1 ? bx[ii] : 0.f;
+      qy[u] = ii < p1 ? by[ii] : 0.f;
+      qz[u] = ii < p1 ? bz[ii] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (i + u * kBinThreads < p1) {
+        const float px = qx[u], py = qy[u], pz = qz[u];
+        const int ix = (int)((px - g.ox) * g.inv_c), iy = (int)((py - g.oy) * g.inv_c), iz = (int)((pz - g.oz) * g.inv_c);
+        const int ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
+        const int uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
+        const int uz = fix_coord(pz, cell_centre(g.oz, iz, g.cell), g.fix_scale);
+        const int c = ((((iz - tz0) << kT3y) + (iy - ty0)) << kT3x) + (ix - tx0);
+        atomicAdd(&s_n[c], 1u);
+        atomicAdd(&s_sum[0][c], (unsigned long long)(long long)ux);
+        atomicAdd(&s_sum[1][c], (unsigned long long)(long long)uy);
+        atomicAdd(&s_sum[2][c], (unsigned long long)(long long)uz);
+        atomicAdd(&s_sum[3][c], prod64(ux, ux));
+        atomicAdd(&s_sum[4][c], prod64(ux, uy));
+        atomicAdd(&s_sum[5][c], prod64(ux, uz));
+        atomicAdd(&s_sum[6][c], prod64(uy, uy));
+        atomicAdd(&s_sum[7][c], prod64(uy, uz));
+        atomicAdd(&s_sum[8][c], prod64(uz, uz));
+      }
+    }
   }
   __syncthreads();
   int nvalid = 0, nover = 0;
