@@ -46,6 +46,7 @@ class Params2D(C.Structure):
         ("overlap_grids", C.c_int32),
         ("line_search", C.c_int32),
         ("reserved", C.c_int32),
+        ("step_scale", C.c_double),
     ]
 
 

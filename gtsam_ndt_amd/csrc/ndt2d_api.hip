@@ -75,6 +75,7 @@ int32_t check_params(const ndt2d_params* p) {
   if (!(p->d1 > 0.0) || !(p->d2 > 0.0) || !std::isfinite(p->d1) || !std::isfinite(p->d2)) return NDT_ERR_INVALID_ARG;
   if (p->overlap_grids != 0 && p->overlap_grids != 1 && p->overlap_grids != 4) return NDT_ERR_INVALID_ARG;
   if (p->line_search < 0 || p->line_search > 16) return NDT_ERR_INVALID_ARG;
+  if (!(p->step_scale >= 0.0 && p->step_scale <= 8.0)) return NDT_ERR_INVALID_ARG;   // 0 means 1
   return NDT_OK;
 }
 
@@ -266,6 +267,7 @@ int32_t upload_static(ndt2d_handle* h) {
   p.eps_rot = h->prm.eps_rot;
   p.step_max_trans = h->prm.step_max_trans;
   p.step_max_rot = h->prm.step_max_rot;
+  p.step_scale = h->prm.step_scale > 0.0 ? h->prm.step_scale : 1.0;
   HIP_TRY(hipMemcpyAsync(h->d_static, c, sizeof(AlignStatic), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NDT_OK;
@@ -453,6 +455,7 @@ void ndt2d_default_params(ndt2d_params* p) {
   p->step_max_trans = 0.5;
   p->step_max_rot = 0.2;
   p->min_hits = 3;
+  p->step_scale = 1.0;
 }
 
 int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** out) {

@@ -55,6 +55,7 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
     a.prm.line_search = p.line_search;
     a.prm.eps_trans = p.eps_trans; a.prm.eps_rot = p.eps_rot;
     a.prm.step_max_trans = p.step_max_trans; a.prm.step_max_rot = p.step_max_rot;
+    a.prm.step_scale = p.step_scale > 0.0 ? p.step_scale : 1.0;
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 16, st));
     if (p.hessian_mode == NDT_HESSIAN_NEWTON)
       hipLaunchKernelGGL(ndt::k_batch<1>, dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);

@@ -50,6 +50,7 @@ struct SolveParams {
   int min_hits;
   int line_search;   // > 0: backtracking line search, at most this many halvings per step
   double eps_trans, eps_rot, step_max_trans, step_max_rot;
+  double step_scale;   // over-relaxation factor on the solved step (1 = plain)
 };
 
 // Backtracking line-search state (oracle/ndt2d.py gn_update): the pose the current step
@@ -389,6 +390,7 @@ __device__ __forceinline__ bool gn_update(double* pose, const double* H, const d
   if (n_hit < p.min_hits) { status = 3; return true; }
   double d[3];
   if (!solve3(H, g, d)) { status = 2; return true; }
+  d[0] *= p.step_scale; d[1] *= p.step_scale; d[2] *= p.step_scale;
   const double nt2 = d[0] * d[0] + d[1] * d[1];
   const double nr = fabs(d[2]);
   double alpha = 1.0;
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
   // `done` branch and they become a third dependent round trip.
   asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.rec),
                "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations), "s"(prm.eps_trans),
-               "s"(prm.eps_rot), "s"(prm.step_max_trans), "s"(prm.step_max_rot), "s"(ps_pose0), "s"(ps_pose1),
+               "s"(prm.eps_rot), "s"(prm.step_max_trans), "s"(prm.step_max_rot), "s"(prm.step_scale), "s"(ps_pose0), "s"(ps_pose1),
                "s"(ps_pose2), "s"(ps_iter), "s"(ps_done), "s"(ps_have), "s"(fixed_iterations), "s"(host_state),
                "s"(host_flag));
   const int stride = kMaxBlocks * THREADS;

@@ -51,6 +51,7 @@ int32_t upload_static3(ndt3d_handle* h) {
   p.hessian_mode = 0; p.max_iterations = h->prm.max_iterations; p.min_hits = h->prm.min_hits; p.line_search = h->prm.line_search;
   p.eps_trans = h->prm.eps_trans; p.eps_rot = h->prm.eps_rot;
   p.step_max_trans = h->prm.step_max_trans; p.step_max_rot = h->prm.step_max_rot;
+  p.step_scale = h->prm.step_scale > 0.0 ? h->prm.step_scale : 1.0;
   HIP_TRY(hipMemcpyAsync(h->d_static, c, sizeof(ndt::AlignStatic3), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NDT_OK;

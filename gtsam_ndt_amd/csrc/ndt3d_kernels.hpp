@@ -274,6 +274,8 @@ __device__ __forceinline__ bool gn_update3(double* pose, const double* A, const 
   if (n_hit < p.min_hits) { status = 3; return true; }
   double d[6];
   if (!solve6(A, g, d)) { status = 2; return true; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) d[i] *= p.step_scale;
   const double nt2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
   const double nr2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
   double alpha = 1.0;

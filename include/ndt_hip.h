@@ -74,6 +74,12 @@ typedef struct ndt2d_params {
                               times per step; every trial is one evaluation and counts as one
                               iteration; convergence is tested on accepted evaluations only */
   int32_t reserved;
+  double step_scale;       /* over-relaxation: the solved step is multiplied by this before the step
+                              limits and the convergence test.  1 = plain Gauss-Newton/Newton.  The
+                              Gauss-Newton Hessian of this score overestimates the true curvature
+                              about 3x, so 2..3 cuts the iterations to
+                              convergence 2..3x; keep 1 with NDT_HESSIAN_NEWTON.  0 means 1;
+                              valid range (0, 8] */
 } ndt2d_params;
 
 /* ---- result (row a9) ------------------------------------------------------------ */

@@ -20,7 +20,7 @@ class CParams(C.Structure):
                 ("eps_trans", C.c_double), ("eps_rot", C.c_double),
                 ("step_max_trans", C.c_double), ("step_max_rot", C.c_double),
                 ("min_hits", C.c_int32), ("reserved", C.c_int32),
-                ("line_search", C.c_int32), ("reserved2", C.c_int32)]
+                ("line_search", C.c_int32), ("reserved2", C.c_int32), ("step_scale", C.c_double)]
 
 
 class CResult(C.Structure):
@@ -57,7 +57,7 @@ def load():
 def cparams(p: NdtParams) -> CParams:
     return CParams(p.cell_size, p.min_points, p.hessian_mode, p.eig_ratio, p.d1, p.d2, p.max_iterations,
                    p.fixed_iterations, p.eps_trans, p.eps_rot, p.step_max_trans, p.step_max_rot,
-                   p.min_hits, 0, p.line_search, 0)
+                   p.min_hits, 0, p.line_search, 0, p.step_scale)
 
 
 class CGrid:

@@ -60,6 +60,7 @@ class NdtParams:
     min_hits: int = 3
     overlap: int = 1                   # 1: single grid; 4: Biber's four grids shifted by half a cell
     line_search: int = 0               # >0: backtracking, at most this many halvings per step
+    step_scale: float = 1.0            # over-relaxation factor on the solved step
 
 
 @dataclass
@@ -395,6 +396,7 @@ def gn_update(pose, H, g, n_hit, it, prm: NdtParams, score: float = 0.0, ls: dic
     d, ok = solve3(H, g)
     if not ok:
         return pose, it, NDT_DEGENERATE_HESSIAN, True
+    d = d * prm.step_scale
     nt = math.sqrt(d[0] * d[0] + d[1] * d[1])
     nr = abs(d[2])
     alpha = 1.0

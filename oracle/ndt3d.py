@@ -39,6 +39,7 @@ class Ndt3Params:
     step_max_rot: float = 0.2
     min_hits: int = 6
     line_search: int = 0               # as NdtParams.line_search (oracle/ndt2d.py gn_update)
+    step_scale: float = 1.0            # as NdtParams.step_scale
 
 
 @dataclass
@@ -278,6 +279,7 @@ def gn_update3(pose, H, g, n_hit, it, prm: Ndt3Params, score: float = 0.0, ls: d
     d, ok = solve_ldl(H, g)
     if not ok:
         return pose, it, NDT_DEGENERATE_HESSIAN, True
+    d = d * prm.step_scale
     nt = math.sqrt(d[0] ** 2 + d[1] ** 2 + d[2] ** 2)
     nr = math.sqrt(d[3] ** 2 + d[4] ** 2 + d[5] ** 2)
     alpha = 1.0

@@ -33,6 +33,7 @@ typedef struct orc_params {   /* same layout as ndt2d_params (include/ndt_hip.h)
   int32_t reserved;          /* overlap_grids: single grid only in this port */
   int32_t line_search;       /* > 0: backtracking, at most this many halvings per step */
   int32_t reserved2;
+  double step_scale;         /* over-relaxation factor on the solved step (0 means 1) */
 } orc_params;
 
 typedef struct orc_result {   /* same layout as ndt2d_result */
@@ -283,6 +284,7 @@ int32_t orc2d_align(const orc_grid2d* g, const float* sx, const float* sy, size_
     }
     if (out->n_hit < p->min_hits) { status = 3; break; }
     if (!solve3(out->H, out->g, d)) { status = 2; break; }
+    { const double w = p->step_scale > 0.0 ? p->step_scale : 1.0; d[0] *= w; d[1] *= w; d[2] *= w; }
     const double nt = sqrt(d[0] * d[0] + d[1] * d[1]), nr = fabs(d[2]);
     double alpha = 1.0;
     if (nt > p->step_max_trans) alpha = p->step_max_trans / nt;
