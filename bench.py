@@ -434,7 +434,7 @@ def main():
             "grid_build_ms": round(grid_ms, 4),
             "converged_align": {"ms_per_call": None if conv_ms is None else round(conv_ms, 4), "iterations": rc.iterations,
                                 "note": "ndt2d_align_dev in converged mode, host call to result in host memory "
-                                        "(16-launch chunks, done flag raised in pinned host memory); median of 20",
+                                        "(8-launch chunks, progress and done flag written to pinned host memory); median of 20",
                                 "relaxed": relaxed},
             "scaling_note": "N=1 times the single-pair config 3 named by BASELINE.json's metric; N>1 lines time "
                             "the sharded loop-closure batch (config 4).  Read multi-GPU scaling against this "

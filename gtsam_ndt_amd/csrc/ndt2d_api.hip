@@ -40,8 +40,7 @@ struct ndt2d_handle {
   AlignDyn* d_dyn = nullptr;
   AlignStatic* h_static = nullptr;         // pinned
   IterState* h_state = nullptr;            // pinned
-  int* h_flag = nullptr;                   // pinned: set by the launch that ends a converged-mode loop
-  hipEvent_t chunk_ev[2] = {nullptr, nullptr};
+  int* h_flag = nullptr;                   // pinned: [0] raised by the launch that ends a converged-mode loop, [1] progress
   int last_parity = 0;
   bool pending = false;
   // binned grid build scratch (ndt2d_build.hpp)
@@ -53,7 +52,7 @@ struct ndt2d_handle {
   hipGraph_t graph = nullptr;
   int graph_launches = 0, graph_blocks = 0, graph_mode = -1;
   bool use_graph = true;
-  int check_every = 16;                    // converged mode: launches per chunk (NDT_DEBUG_CHUNK overrides)
+  int check_every = 8;                     // converged mode: launches per chunk (NDT_DEBUG_CHUNK overrides)
 };
 
 namespace {
@@ -326,7 +325,8 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
   const int K = fixed > 0 ? fixed : h->prm.max_iterations;
   const int blocks = blocks_for(n);
   const bool chunked = h->use_graph && check_every > 0 && fixed == 0;
-  __atomic_store_n(h->h_flag, 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, d_sx, d_sy, (int)n, pose[0], pose[1],
                      pose[2], fixed, chunked ? h->h_state : (IterState*)nullptr, chunked ? h->h_flag : (int*)nullptr);
   int k = 0;
@@ -337,7 +337,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
       const int32_t gs = ensure_graph(h, chunk, blocks);
       if (gs != NDT_OK) return gs;
       bool seen = false;
-      HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->chunk_ev, h->h_flag, chunk, K + 1, &seen));
+      HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->h_flag, chunk, K + 1, &seen));
       HIP_TRY(hipGetLastError());
       h->pending = !seen;                              // seen: the result is in h_state already
       h->last_parity = 1;                              // even chunk length: the last launch had parity 1
@@ -483,8 +483,6 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipHostMalloc((void**)&h->h_state, sizeof(IterState), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   *h->h_flag = 0;
-  for (hipEvent_t& e : h->chunk_ev)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
   { const char* e = std::getenv("NDT_DEBUG_NO_GRAPH"); h->use_graph = !(e && e[0] == '1'); }
@@ -504,7 +502,6 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag};
   for (void* p : host) if (p) (void)hipHostFree(p);
-  for (hipEvent_t e : h->chunk_ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return NDT_OK;

@@ -672,10 +672,14 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
       o.have_partials = 1;
       o.pad = 0;
       *cur = o;
-      if (done && host_flag) {           // tell the host directly: state first, then the flag
-        *host_state = o;
-        __threadfence_system();
-        __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (host_flag) {                   // tell the host directly
+        if (done) {                      // state first, then the flag
+          *host_state = o;
+          __threadfence_system();
+          __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {                         // progress: which launch this is
+          __hip_atomic_store(host_flag + 1, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
     if (done) return;                    // uniform

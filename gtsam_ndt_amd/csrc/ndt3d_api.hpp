@@ -24,7 +24,6 @@ struct ndt3d_handle {
   ndt::AlignStatic3* h_static = nullptr;
   ndt::IterState3* h_state = nullptr;
   int* h_flag = nullptr;              // pinned: raised by the launch that ends a converged-mode loop
-  hipEvent_t chunk_ev[2] = {nullptr, nullptr};
   hipGraphExec_t graph_exec = nullptr;
   hipGraph_t graph = nullptr;
   int graph_launches = 0;
@@ -171,7 +170,8 @@ int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const floa
     return NDT_OK;
   }
   const int fixed = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
-  __atomic_store_n(h->h_flag, 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
   hipLaunchKernelGGL(k_begin3, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, dx, dy, dz, (int)n, pose[0], pose[1],
                      pose[2], pose[3], pose[4], pose[5], fixed, fixed > 0 ? (IterState3*)nullptr : h->h_state,
                      fixed > 0 ? (int*)nullptr : h->h_flag);
@@ -183,11 +183,11 @@ int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const floa
     HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
     last_parity = K & 1;
   } else {
-    const int chunk = 16;
+    const int chunk = 8;
     const int32_t gs = ensure_graph3(h, chunk);
     if (gs != NDT_OK) return gs;
     bool seen = false;
-    HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->chunk_ev, h->h_flag, chunk, K + 1, &seen));
+    HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->h_flag, chunk, K + 1, &seen));
     HIP_TRY(hipGetLastError());
     if (seen) return NDT_OK;                           // the finishing launch wrote h_state itself
     last_parity = 1;
@@ -244,8 +244,6 @@ int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** ou
   if (hipHostMalloc((void**)&h->h_state, sizeof(ndt::IterState3), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   *h->h_flag = 0;
-  for (hipEvent_t& e : h->chunk_ev)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(ndt::AlignDyn3)) != hipSuccess) return fail(NDT_ERR_HIP);
   *out = h;
@@ -261,7 +259,6 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   void* dev[] = {h->d_bounds, h->d_counters, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
                  h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
-  for (hipEvent_t e : h->chunk_ev) if (e) (void)hipEventDestroy(e);
   void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag};
   for (void* p : host) if (p) (void)hipHostFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);

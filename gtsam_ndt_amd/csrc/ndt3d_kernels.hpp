@@ -408,10 +408,14 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
         o->done = done ? 1 : 0; o->have_partials = 1; o->pad = 0;
       };
       store(cur);
-      if (done && host_flag) {           // tell the host directly: state first, then the flag
-        store(host_state);
-        __threadfence_system();
-        __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (host_flag) {                   // tell the host directly
+        if (done) {                      // state first, then the flag
+          store(host_state);
+          __threadfence_system();
+          __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {                         // progress: which launch this is
+          __hip_atomic_store(host_flag + 1, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
     if (done) return;

@@ -48,31 +48,33 @@ inline hipError_t build_chain_graph(const void* func, dim3 grid, dim3 block, voi
 
 // Converged mode of the launch-chain paths: replay `exec` (an even-length chunk of launches),
 // always one chunk ahead of the one being waited for, until the finishing launch raises *flag
-// in pinned host memory (it has written its state next to it first).  No copy and no stream
-// sync inside the loop; launches enqueued past the end exit on the `done` state (about 1.7 us
-// each).  Drains the stream before returning: the caller may release the source buffers.
+// in pinned host memory (it has written its state next to it first).  No copy, no event and no
+// stream sync inside the loop; launches enqueued past the end exit on the `done` state (about
+// 1.7 us each).  Drains the stream before returning: the caller may release the source buffers.
 // *seen = false only if max_launches went by without the flag (callers then read the state back).
-inline hipError_t run_chunks_until_flag(hipGraphExec_t exec, hipStream_t stream, hipEvent_t ev[2], int* flag,
+inline hipError_t run_chunks_until_flag(hipGraphExec_t exec, hipStream_t stream, int* flag,
                                         int chunk, int max_launches, bool* seen) {
+  // flag[0]: raised by the finishing launch; flag[1]: updates applied so far (= index of the last
+  // launch that ran its prologue), written by every launch - the host's only view of progress,
+  // so nothing but kernel launches goes into the stream
   int launched = 0, waited = 0;
-  auto launch_chunk = [&]() -> hipError_t {
-    hipError_t e = hipGraphLaunch(exec, stream);
-    if (e == hipSuccess) e = hipEventRecord(ev[launched & 1], stream);
-    ++launched;
-    return e;
-  };
-  auto raised = [&]() { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0; };
+  auto raised = [&]() { return __atomic_load_n(&flag[0], __ATOMIC_ACQUIRE) != 0; };
   *seen = false;
-  hipError_t e = launch_chunk();
-  if (e == hipSuccess) e = launch_chunk();
+  hipError_t e = hipGraphLaunch(exec, stream);
+  ++launched;
+  if (e == hipSuccess) { e = hipGraphLaunch(exec, stream); ++launched; }
+  long spins = 0;
   while (e == hipSuccess) {
-    hipError_t q = hipErrorNotReady;
-    while (!raised() && (q = hipEventQuery(ev[waited & 1])) == hipErrorNotReady) {}
-    if (raised()) break;
-    if (q != hipSuccess) { e = q; break; }
+    const int need = (waited + 1) * chunk - 1;           // chunk `waited` is through when progress reaches this
+    bool stuck = false;
+    while (!raised() && __atomic_load_n(&flag[1], __ATOMIC_ACQUIRE) < need) {
+      if ((++spins & 0xfffff) == 0 && hipStreamQuery(stream) == hipSuccess) { stuck = true; break; }   // stream drained
+    }
+    if (raised() || stuck) break;
     ++waited;
     if ((launched - 1) * chunk > max_launches) break;   // not reached: the iteration cap sets done
-    e = launch_chunk();
+    e = hipGraphLaunch(exec, stream);
+    ++launched;
   }
   const hipError_t es = hipStreamSynchronize(stream);
   if (e == hipSuccess) e = es;
