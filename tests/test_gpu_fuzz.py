@@ -1,0 +1,138 @@
+"""Seeded differential sweep: ragged, clustered, duplicated, NaN-laced clouds at random offsets and
+cell sizes through the device build and evaluation against the oracle, and the batch kernel
+against the single-pair kernel on the same inputs (two independent device implementations)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, n, centre, spread):
+    k = int(rng.integers(1, 6))
+    blobs = rng.normal(size=(k, 2)) * spread + centre
+    which = rng.integers(0, k, n)
+    aniso = rng.uniform(0.02, 1.0, size=(k, 2))
+    p = blobs[which] + rng.normal(size=(n, 2)) * aniso[which]
+    if n > 8 and rng.random() < 0.5:                       # exact duplicates
+        p[rng.integers(0, n, n // 8)] = p[rng.integers(0, n, n // 8)]
+    if n > 4 and rng.random() < 0.5:                       # a straight wall: rank-1 cells -> eigenvalue clamp
+        m = n // 4
+        p[:m, 0] = centre[0] + np.linspace(-spread, spread, m)
+        p[:m, 1] = centre[1]
+    x, y = p[:, 0].astype(np.float32), p[:, 1].astype(np.float32)
+    if rng.random() < 0.4:                                 # no-return beams
+        bad = rng.integers(0, n, max(1, n // 20))
+        x[bad] = np.nan
+        y[bad[::2]] = np.inf
+    return x, y
+
+
+def _cases(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    for i in range(n_cases):
+        centre = rng.uniform(-800, 800, 2) if rng.random() < 0.5 else rng.uniform(-5, 5, 2)
+        spread = float(rng.uniform(0.5, 20.0))
+        cell = float(rng.choice([0.1, 0.25, 0.3, 0.5, 0.75, 1.0, 2.0, 3.0]))
+        nt = int(rng.choice([3, 17, 64, 257, 1000, 4099, 20000]))
+        ns = int(rng.choice([1, 5, 63, 64, 65, 1000, 8191]))
+        tx, ty = _cloud(rng, nt, centre, spread)
+        sx, sy = _cloud(rng, ns, centre, spread)
+        pose = (float(rng.normal(0, 0.3)), float(rng.normal(0, 0.3)), float(rng.normal(0, 0.05)))
+        kw = dict(cell_size=cell, min_points=int(rng.integers(2, 7)), eig_ratio=float(rng.choice([1e-3, 1e-2, 0.1])),
+                  hessian_mode=int(rng.integers(0, 2)))
+        yield i, tx, ty, sx, sy, pose, kw
+
+
+def test_random_clouds_build_and_evaluate_like_the_oracle(gpu_lib):
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMatcher2D
+    from oracle import ndt2d as o
+    checked = 0
+    for i, tx, ty, sx, sy, pose, kw in _cases(60, seed=20261004):
+        finite = np.isfinite(tx) & np.isfinite(ty)
+        if finite.sum() == 0:
+            continue
+        prm = o.NdtParams(**kw)
+        g = o.build_grid(tx[finite], ty[finite], prm)
+        with NdtMatcher2D(**kw) as m:
+            info = m.set_target(tx, ty)                                  # non-finite points are ignored
+            assert (info.width, info.height, info.ox, info.oy) == (g.W, g.H, g.ox, g.oy), (i, kw)
+            count, mean, icov = m.grid()
+            np.testing.assert_array_equal(count.astype(np.int64), g.count, err_msg=f"case {i}")
+            assert info.n_valid == g.n_valid, (i, kw)
+            np.testing.assert_array_equal(icov[:, 0] != 0, g.valid, err_msg=f"case {i}")
+            if g.n_valid == 0:
+                r = m.align(sx, sy, pose)
+                assert r.status == L.NDT_TOO_FEW_CELLS
+                continue
+            H, gr, score, n_hit = m.evaluate(sx, sy, pose)
+            ok = np.isfinite(sx) & np.isfinite(sy)
+            Hm, gm, sm, nm = o.evaluate(g, sx[ok], sy[ok], pose, prm, mirror32=True)
+            assert abs(n_hit - nm) <= 2, (i, n_hit, nm)
+            if nm > 2 and n_hit == nm:
+                hs = max(np.abs(Hm).max(), 1e-30)
+                assert np.abs(H - Hm).max() / hs < 1e-3, (i, kw)
+                assert abs(score - sm) <= 1e-3 * max(sm, 1e-6), (i, score, sm)
+            # the batch kernel (grid in LDS) evaluates the same pair at the same pose: one update,
+            # H/g/score are those of the evaluation at the start pose
+            with NdtBatch2D(fixed_iterations=1, **kw) as b:
+                rb = b.align([(tx, ty)], [(sx, sy)], [pose])[0]
+            if rb.status in (L.NDT_OK, L.NDT_NOT_CONVERGED):
+                assert rb.n_hit == n_hit, (i, rb.n_hit, n_hit)
+                hs = max(np.abs(H).max(), 1e-30)
+                assert np.abs(rb.H - H).max() / hs < 1e-4, (i, kw)
+                assert abs(rb.score - score) <= 1e-4 * max(score, 1e-6)
+            else:
+                assert rb.status in (L.NDT_TOO_FEW_HITS, L.NDT_DEGENERATE_HESSIAN), (i, rb.status)
+            checked += 1
+    assert checked >= 40
+
+
+def test_random_clouds_3d(gpu_lib):
+    """The 3D build (binned tiles, Jacobi finalise) and evaluation on random clustered clouds."""
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    from oracle import ndt3d as o3
+    rng = np.random.default_rng(77)
+    checked = 0
+    for i in range(24):
+        centre = rng.uniform(-300, 300, 3) if i % 2 else rng.uniform(-3, 3, 3)
+        spread = float(rng.uniform(1.0, 15.0))
+        cell = float(rng.choice([0.5, 1.0, 1.5, 2.0]))
+        nt = int(rng.choice([5, 100, 1000, 5000, 30000]))
+        ns = int(rng.choice([1, 64, 65, 1000, 4097]))
+        k = int(rng.integers(1, 5))
+        blobs = rng.normal(size=(k, 3)) * spread + centre
+        sc = rng.uniform(0.05, 1.5, size=(k, 3))
+
+        def cloud(n):
+            w = rng.integers(0, k, n)
+            p = (blobs[w] + rng.normal(size=(n, 3)) * sc[w]).astype(np.float32)
+            if n > 8:                                                      # a flat floor patch: rank-2 voxels
+                p[: n // 4, 2] = np.float32(centre[2])
+            return p[:, 0].copy(), p[:, 1].copy(), p[:, 2].copy()
+
+        tx, ty, tz = cloud(nt)
+        sx, sy, sz = cloud(ns)
+        kw = dict(cell_size=cell, min_points=int(rng.integers(3, 8)), eig_ratio=float(rng.choice([1e-3, 1e-2])))
+        prm = o3.Ndt3Params(**kw)
+        g = o3.build_grid3(tx, ty, tz, prm)
+        pose = tuple(rng.normal(0, 0.2, 3)) + tuple(rng.normal(0, 0.03, 3))
+        with NdtMatcher3D(**kw) as m:
+            info = m.set_target(tx, ty, tz)
+            assert (info.width, info.height, info.depth) == g.dims, (i, kw)
+            count, mean, icov = m.grid()
+            np.testing.assert_array_equal(count.astype(np.int64), g.count, err_msg=f"case {i}")
+            assert info.n_valid == g.n_valid, (i, kw)
+            if g.n_valid == 0:
+                assert m.align(sx, sy, sz, pose).status == L.NDT_TOO_FEW_CELLS
+                continue
+            H, gr, s, nh = m.evaluate(sx, sy, sz, pose)
+            Hm, gm, sm, nm = o3.evaluate3(g, sx, sy, sz, pose, prm, mirror32=True)
+            assert abs(nh - nm) <= 2, (i, nh, nm)
+            if nm > 3 and nh == nm:
+                hs = max(np.abs(Hm).max(), 1e-30)
+                assert np.abs(H - Hm).max() / hs < 2e-3, (i, kw)
+                assert abs(s - sm) <= 2e-3 * max(sm, 1e-6)
+            checked += 1
+    assert checked >= 12
