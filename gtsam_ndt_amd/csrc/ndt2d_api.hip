@@ -48,9 +48,8 @@ struct ndt2d_handle {
   unsigned int* d_tiles = nullptr; size_t tile_cap = 0;   // total[nt] | start[nt+1] | cursor[nt]
   bool use_binned_build = true;
   // hipGraph of the launch chain (launch-bound inner loop: one replay instead of K+1 launches)
-  hipGraphExec_t graph_exec = nullptr;
-  hipGraph_t graph = nullptr;
-  int graph_launches = 0, graph_blocks = 0, graph_mode = -1;
+  ChainGraphCache graphs;
+  hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
   bool use_graph = true;
   int check_every = 8;                     // converged mode: launches per chunk (NDT_DEBUG_CHUNK overrides)
 };
@@ -285,25 +284,19 @@ void launch_iter(ndt2d_handle* h, int blocks, int k) {
 }
 
 void drop_graph(ndt2d_handle* h) {
-  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-  if (h->graph) (void)hipGraphDestroy(h->graph);
-  h->graph_exec = nullptr; h->graph = nullptr; h->graph_launches = 0;
+  h->graphs.clear();
+  h->graph_exec = nullptr;
 }
 
 // Graph of `launches` consecutive k_iterate launches starting at parity 0.  The kernels read
 // everything (grid, source pointers, n, parameters, state) from device memory, so one graph
 // serves every target and every source.
 int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
-  if (h->graph_exec && h->graph_launches == launches && h->graph_blocks == blocks &&
-      h->graph_mode == h->prm.hessian_mode)
-    return NDT_OK;
-  drop_graph(h);
   const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON, four = h->prm.overlap_grids == 4;
   const void* func = newton ? (four ? (const void*)&k_iterate<1, 0, kIterThreads, 4> : (const void*)&k_iterate<1, 0, kIterThreads, 1>)
                             : (four ? (const void*)&k_iterate<0, 0, kIterThreads, 4> : (const void*)&k_iterate<0, 0, kIterThreads, 1>);
-  HIP_TRY(build_chain_graph(func, dim3(blocks), dim3(kIterThreads), (void*)h->d_static, (void*)h->d_call, (void*)h->d_dyn,
-                            launches, &h->graph, &h->graph_exec));
-  h->graph_launches = launches; h->graph_blocks = blocks; h->graph_mode = h->prm.hessian_mode;
+  HIP_TRY(h->graphs.get(func, dim3(blocks), dim3(kIterThreads), (void*)h->d_static, (void*)h->d_call, (void*)h->d_dyn,
+                        launches, h->prm.hessian_mode, &h->graph_exec));
   return NDT_OK;
 }
 

@@ -24,9 +24,8 @@ struct ndt3d_handle {
   ndt::AlignStatic3* h_static = nullptr;
   ndt::IterState3* h_state = nullptr;
   int* h_flag = nullptr;              // pinned: raised by the launch that ends a converged-mode loop
-  hipGraphExec_t graph_exec = nullptr;
-  hipGraph_t graph = nullptr;
-  int graph_launches = 0;
+  ndt::ChainGraphCache graphs;
+  hipGraphExec_t graph_exec = nullptr;   // selected by ensure_graph3, owned by `graphs`
   bool host_result = false;           // result already in h_state (no device work was enqueued)
 };
 
@@ -147,13 +146,8 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
 
 int32_t ensure_graph3(ndt3d_handle* h, int launches) {
   using namespace ndt;
-  if (h->graph_exec && h->graph_launches == launches) return NDT_OK;
-  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-  if (h->graph) (void)hipGraphDestroy(h->graph);
-  h->graph_exec = nullptr; h->graph = nullptr; h->graph_launches = 0;
-  HIP_TRY(build_chain_graph((const void*)&k_iterate3, dim3(kMaxBlocks), dim3(kBlock), (void*)h->d_static, (void*)h->d_call,
-                            (void*)h->d_dyn, launches, &h->graph, &h->graph_exec));
-  h->graph_launches = launches;
+  HIP_TRY(h->graphs.get((const void*)&k_iterate3, dim3(kMaxBlocks), dim3(kBlock), (void*)h->d_static, (void*)h->d_call,
+                        (void*)h->d_dyn, launches, 0, &h->graph_exec));
   return NDT_OK;
 }
 
@@ -254,8 +248,7 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   if (!h) return NDT_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-  if (h->graph) (void)hipGraphDestroy(h->graph);
+  h->graphs.clear();
   void* dev[] = {h->d_bounds, h->d_counters, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
                  h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);

@@ -46,6 +46,48 @@ inline hipError_t build_chain_graph(const void* func, dim3 grid, dim3 block, voi
   return hipSuccess;
 }
 
+// A handle alternates between a few chain lengths (the converged-mode chunk, the fixed-K chain of a
+// timing run, the 2-launch chain of an evaluation): keep the last few instantiated graphs instead
+// of rebuilding one on every change.
+struct ChainGraphCache {
+  static constexpr int kSlots = 4;
+  struct Slot { int launches = 0, blocks = 0, mode = -1; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long stamp = 0; };
+  Slot slot[kSlots];
+  unsigned long clock = 0;
+
+  hipGraphExec_t find(int launches, int blocks, int mode) {
+    for (Slot& s : slot)
+      if (s.exec && s.launches == launches && s.blocks == blocks && s.mode == mode) { s.stamp = ++clock; return s.exec; }
+    return nullptr;
+  }
+  // the slot to build into: an empty one, else the least recently used (destroyed first)
+  Slot* victim() {
+    Slot* v = &slot[0];
+    for (Slot& s : slot) {
+      if (!s.exec) { v = &s; break; }
+      if (s.stamp < v->stamp) v = &s;
+    }
+    release(*v);
+    return v;
+  }
+  void release(Slot& s) {
+    if (s.exec) (void)hipGraphExecDestroy(s.exec);
+    if (s.graph) (void)hipGraphDestroy(s.graph);
+    s = Slot{};
+  }
+  void clear() { for (Slot& s : slot) release(s); }
+  hipError_t get(const void* func, dim3 grid, dim3 block, void* a0, void* a1, void* a2, int launches, int mode,
+                 hipGraphExec_t* out) {
+    if (hipGraphExec_t e = find(launches, (int)grid.x, mode)) { *out = e; return hipSuccess; }
+    Slot* s = victim();
+    const hipError_t err = build_chain_graph(func, grid, block, a0, a1, a2, launches, &s->graph, &s->exec);
+    if (err != hipSuccess) { *s = Slot{}; return err; }
+    s->launches = launches; s->blocks = (int)grid.x; s->mode = mode; s->stamp = ++clock;
+    *out = s->exec;
+    return hipSuccess;
+  }
+};
+
 // Converged mode of the launch-chain paths: replay `exec` (an even-length chunk of launches),
 // always one chunk ahead of the one being waited for, until the finishing launch raises *flag
 // in pinned host memory (it has written its state next to it first).  No copy, no event and no

@@ -22,3 +22,15 @@ for chunk in (4, 8, 12, 16, 24, 32, 64):
             lib.ndt2d_align_dev(m._h, sx.data_ptr(), sy.data_ptr(), sx.numel(), init, C.byref(out))
             lat.append(time.perf_counter() - t0)
         print(f"chunk {chunk:3d}: median {1e6*np.median(lat[5:]):.1f} us  min {1e6*min(lat):.1f} us  iters {out.iterations}")
+
+# alternating evaluate / align on one handle: the chain graphs of both lengths stay cached
+os.environ["NDT_DEBUG_CHUNK"] = "8"
+with NdtMatcher2D() as m:
+    m.set_target(tx, ty)
+    lat = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        m.evaluate(d["sx"], d["sy"], d["init"])
+        m.align(sx, sy, d["init"])
+        lat.append(time.perf_counter() - t0)
+    print(f"evaluate + align alternating: median {1e6*np.median(lat[5:]):.1f} us")
