@@ -50,6 +50,7 @@ struct ndt2d_handle {
   // hipGraph of the launch chain (launch-bound inner loop: one replay instead of K+1 launches)
   ChainGraphCache graphs;
   hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
+  ChunkRun chunk_run;                      // converged-mode loop begun by ndt2d_align_dev_async
   bool use_graph = true;
   int check_every = 8;                     // converged mode: launches per chunk (NDT_DEBUG_CHUNK overrides)
 };
@@ -302,9 +303,20 @@ int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
 
 // Enqueue the Gauss-Newton loop.  check_every > 0: poll the done flag every that many
 // launches (synchronous early exit); 0: enqueue all launches, finished ones are no-ops.
+int32_t finish_chunk_run(ndt2d_handle* h) {
+  if (!h->chunk_run.active) return NDT_OK;
+  bool seen = false;
+  HIP_TRY(chunk_run_finish(h->chunk_run, h->stream, h->h_flag, &seen));
+  HIP_TRY(hipGetLastError());
+  h->pending = !seen;                                  // seen: the result is in h_state already
+  h->last_parity = 1;                                  // even chunk length: the last launch had parity 1
+  return NDT_OK;
+}
+
 int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n, const double pose[3],
-                  int fixed_override, int check_every) {
+                  int fixed_override, int check_every, bool wait = true) {
   if (!h->has_target) return NDT_ERR_NO_TARGET;
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }   // an unfinished asynchronous call
   if (n == 0 || n > 0x7fffffffull || !pose) return NDT_ERR_INVALID_ARG;
   if (h->n_valid < 1) {
     h->pending = false;
@@ -329,12 +341,9 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
       const int chunk = check_every + (check_every & 1);
       const int32_t gs = ensure_graph(h, chunk, blocks);
       if (gs != NDT_OK) return gs;
-      bool seen = false;
-      HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->h_flag, chunk, K + 1, &seen));
-      HIP_TRY(hipGetLastError());
-      h->pending = !seen;                              // seen: the result is in h_state already
-      h->last_parity = 1;                              // even chunk length: the last launch had parity 1
-      return NDT_OK;
+      HIP_TRY(chunk_run_begin(h->chunk_run, h->graph_exec, h->stream, chunk, K + 1));
+      h->pending = false;
+      return wait ? finish_chunk_run(h) : NDT_OK;
     } else {
       const int32_t gs = ensure_graph(h, K + 1, blocks);
       if (gs != NDT_OK) return gs;
@@ -361,6 +370,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
 }
 
 int32_t fetch_state(ndt2d_handle* h) {
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   if (h->pending) {
     HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[h->last_parity], sizeof(IterState),
                            hipMemcpyDeviceToHost, h->stream));
@@ -488,6 +498,7 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
 int32_t ndt2d_destroy(ndt2d_handle* h) {
   if (!h) return NDT_OK;
   (void)hipSetDevice(h->device);
+  (void)finish_chunk_run(h);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
   void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
@@ -505,6 +516,7 @@ void* ndt2d_stream(ndt2d_handle* h) { return h ? (void*)h->stream : nullptr; }
 int32_t ndt2d_set_target(ndt2d_handle* h, const float* x, const float* y, size_t n) {
   if (!h || !x || !y || n == 0) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   const int32_t st = ensure_points(&h->d_tx, &h->d_ty, &h->tcap, n);
   if (st != NDT_OK) return st;
   HIP_TRY(hipMemcpyAsync(h->d_tx, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -515,6 +527,7 @@ int32_t ndt2d_set_target(ndt2d_handle* h, const float* x, const float* y, size_t
 int32_t ndt2d_set_target_dev(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n, void* stream) {
   if (!h || !d_x || !d_y || n == 0) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // producer of d_x/d_y
   return set_target_impl(h, d_x, d_y, n);
 }
@@ -524,6 +537,7 @@ int32_t ndt2d_reserve_target(ndt2d_handle* h, double xmin, double ymin, double x
       !std::isfinite(ymax))
     return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   h->has_target = false;
   const int32_t gs = setup_geometry(h, (float)xmin, (float)xmax, (float)ymin, (float)ymax);
   if (gs != NDT_OK) return gs;
@@ -541,6 +555,7 @@ int32_t ndt2d_add_target_points_dev(ndt2d_handle* h, const float* d_x, const flo
   if (!h || !d_x || !d_y || n == 0) return NDT_ERR_INVALID_ARG;
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   // order after the caller's producer stream, as ndt2d_set_target_dev does
   if (stream && (hipStream_t)stream != h->stream) {
     hipEvent_t ev;
@@ -573,6 +588,7 @@ int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y,
   if (!h || !x || !y || n == 0) return NDT_ERR_INVALID_ARG;
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   const int32_t st = ensure_points(&h->d_tx, &h->d_ty, &h->tcap, n);
   if (st != NDT_OK) return st;
   HIP_TRY(hipMemcpyAsync(h->d_tx, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -668,7 +684,8 @@ int32_t ndt2d_align_dev_async(ndt2d_handle* h, const float* d_sx, const float* d
                               const double init_pose[3]) {
   if (!h || !d_sx || !d_sy || !init_pose) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  return run_align(h, d_sx, d_sy, n, init_pose, -1, 0);
+  // converged mode: the first two chunks are enqueued here, ndt2d_align_finish keeps the loop fed
+  return run_align(h, d_sx, d_sy, n, init_pose, -1, h->check_every, /*wait=*/false);
 }
 
 int32_t ndt2d_align_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,

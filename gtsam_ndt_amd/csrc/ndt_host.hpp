@@ -94,34 +94,55 @@ struct ChainGraphCache {
 // stream sync inside the loop; launches enqueued past the end exit on the `done` state (about
 // 1.7 us each).  Drains the stream before returning: the caller may release the source buffers.
 // *seen = false only if max_launches went by without the flag (callers then read the state back).
-inline hipError_t run_chunks_until_flag(hipGraphExec_t exec, hipStream_t stream, int* flag,
-                                        int chunk, int max_launches, bool* seen) {
-  // flag[0]: raised by the finishing launch; flag[1]: updates applied so far (= index of the last
-  // launch that ran its prologue), written by every launch - the host's only view of progress,
-  // so nothing but kernel launches goes into the stream
-  int launched = 0, waited = 0;
-  auto raised = [&]() { return __atomic_load_n(&flag[0], __ATOMIC_ACQUIRE) != 0; };
-  *seen = false;
+struct ChunkRun {          // a converged-mode loop in flight (begin ... finish)
+  hipGraphExec_t exec = nullptr;
+  int chunk = 0, max_launches = 0, launched = 0;
+  bool active = false;
+};
+
+// Enqueue the first two chunks and return: the asynchronous half.
+inline hipError_t chunk_run_begin(ChunkRun& r, hipGraphExec_t exec, hipStream_t stream, int chunk, int max_launches) {
+  r.exec = exec; r.chunk = chunk; r.max_launches = max_launches; r.launched = 0; r.active = true;
   hipError_t e = hipGraphLaunch(exec, stream);
-  ++launched;
-  if (e == hipSuccess) { e = hipGraphLaunch(exec, stream); ++launched; }
+  ++r.launched;
+  if (e == hipSuccess) { e = hipGraphLaunch(exec, stream); ++r.launched; }
+  return e;
+}
+
+// Keep one chunk ahead until the flag is raised, then drain the stream.
+// flag[0]: raised by the finishing launch; flag[1]: updates applied so far (= index of the last
+// launch that ran its prologue), written by every launch - the host's only view of progress, so
+// nothing but kernel launches goes into the stream.
+inline hipError_t chunk_run_finish(ChunkRun& r, hipStream_t stream, int* flag, bool* seen) {
+  auto raised = [&]() { return __atomic_load_n(&flag[0], __ATOMIC_ACQUIRE) != 0; };
+  int waited = 0;
   long spins = 0;
+  hipError_t e = hipSuccess;
   while (e == hipSuccess) {
-    const int need = (waited + 1) * chunk - 1;           // chunk `waited` is through when progress reaches this
+    const int need = (waited + 1) * r.chunk - 1;         // chunk `waited` is through when progress reaches this
     bool stuck = false;
     while (!raised() && __atomic_load_n(&flag[1], __ATOMIC_ACQUIRE) < need) {
       if ((++spins & 0xfffff) == 0 && hipStreamQuery(stream) == hipSuccess) { stuck = true; break; }   // stream drained
     }
     if (raised() || stuck) break;
     ++waited;
-    if ((launched - 1) * chunk > max_launches) break;   // not reached: the iteration cap sets done
-    e = hipGraphLaunch(exec, stream);
-    ++launched;
+    if ((r.launched - 1) * r.chunk > r.max_launches) break;   // not reached: the iteration cap sets done
+    e = hipGraphLaunch(r.exec, stream);
+    ++r.launched;
   }
   const hipError_t es = hipStreamSynchronize(stream);
   if (e == hipSuccess) e = es;
   *seen = raised();
+  r.active = false;
   return e;
+}
+
+inline hipError_t run_chunks_until_flag(hipGraphExec_t exec, hipStream_t stream, int* flag, int chunk, int max_launches,
+                                        bool* seen) {
+  ChunkRun r;
+  const hipError_t e = chunk_run_begin(r, exec, stream, chunk, max_launches);
+  if (e != hipSuccess) { *seen = false; (void)hipStreamSynchronize(stream); return e; }
+  return chunk_run_finish(r, stream, flag, seen);
 }
 
 }  // namespace ndt

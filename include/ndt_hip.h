@@ -167,8 +167,11 @@ int32_t ndt2d_align(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
 /* Source already on the device.  Synchronous in the result (out is host memory). */
 int32_t ndt2d_align_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
                         const double init_pose[3], ndt2d_result* out);
-/* Fully asynchronous form for timing and pipelining: enqueues the whole Gauss-Newton
- * loop on the handle's stream and returns; ndt2d_align_finish() waits and fetches. */
+/* Asynchronous form for timing and pipelining: returns as soon as the loop is under way on the
+ * handle's stream; ndt2d_align_finish() waits and fetches.  With fixed_iterations > 0 the whole
+ * loop is enqueued here; in converged mode the first launches are enqueued here and
+ * ndt2d_align_finish() keeps the loop fed until it converges, so the d_sx / d_sy buffers must
+ * stay valid until it returns (any other call on the handle finishes a loop in flight first). */
 int32_t ndt2d_align_dev_async(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
                               const double init_pose[3]);
 int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out);

@@ -89,3 +89,36 @@ def test_pyramid_widens_the_basin(gpu_lib):
     ref = o.align(o.build_grid(xt, yt, prm), xs, ys, cur, prm)
     assert ref["status"] == 0
     assert np.abs(np.array(r.pose) - np.array(ref["pose"])).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_async_converged_mode(gpu_lib):
+    """ndt2d_align_dev_async in converged mode: begun here, finished (kept fed) by align_finish;
+    any other call on the handle finishes a loop in flight first."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(2, n_tgt=30000, n_src=30000)
+    sx, sy = torch.from_numpy(d["sx"]).cuda(), torch.from_numpy(d["sy"]).cuda()
+    d2 = synth.make_pair(4, pair_index=3, n_tgt=20000, n_src=20000)
+    with NdtMatcher2D() as m:
+        m.set_target(d["tx"], d["ty"])
+        ref = m.align(sx, sy, d["init"])
+        assert ref.status == 0 and ref.iterations > 16                 # longer than the two chunks begun by async
+        m.align_async(sx, sy, d["init"])
+        got = m.finish()
+        assert got.pose == ref.pose and got.iterations == ref.iterations and np.array_equal(got.H, ref.H)
+        # two asynchronous calls back to back: the second finishes the first, then runs
+        m.align_async(sx, sy, d["init"])
+        m.align_async(sx, sy, (0.05, 0.02, 0.0))
+        second = m.finish()
+        assert second.status == 0 and np.abs(np.array(second.pose) - np.array(ref.pose)).max() < 5e-4
+        # a target change with a loop in flight: the loop is finished against the old target first
+        m.align_async(sx, sy, d["init"])
+        m.set_target(d2["tx"], d2["ty"])
+        late = m.finish()
+        assert late.pose == ref.pose and late.iterations == ref.iterations
+        # evaluation with a loop in flight
+        m.set_target(d["tx"], d["ty"])
+        m.align_async(sx, sy, d["init"])
+        H, g, s, nh = m.evaluate(d["sx"], d["sy"], ref.pose)
+        assert nh > 0 and s > 0
