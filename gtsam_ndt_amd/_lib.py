@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libndt_hip.so")
+# NDT_HIP_LIB: an instrumented build of the same library (tools/ only)
+LIB_PATH = os.environ.get("NDT_HIP_LIB") or os.path.join(_HERE, "lib", "libndt_hip.so")
 
 NDT_OK = 0
 NDT_NOT_CONVERGED = 1

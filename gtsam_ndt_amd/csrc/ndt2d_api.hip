@@ -12,6 +12,7 @@
 
 #include "../../include/ndt_hip.h"
 #include "ndt2d_kernels.hpp"
+#include "ndt2d_small.hpp"
 #include "ndt2d_build.hpp"
 #include "ndt_host.hpp"
 
@@ -51,6 +52,8 @@ struct ndt2d_handle {
   ChainGraphCache graphs;
   hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
   ChunkRun chunk_run;                      // converged-mode loop begun by ndt2d_align_dev_async
+  bool small_run = false;                  // a k_align_small launch whose flag has not been waited for
+  bool use_small = true;                   // NDT_DEBUG_NO_SMALL=1: short scans go through k_iterate too
   bool use_graph = true;
   int check_every = 8;                     // converged mode: launches per chunk (NDT_DEBUG_CHUNK overrides)
 };
@@ -303,7 +306,25 @@ int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
 
 // Enqueue the Gauss-Newton loop.  check_every > 0: poll the done flag every that many
 // launches (synchronous early exit); 0: enqueue all launches, finished ones are no-ops.
+// Wait for a single-workgroup alignment: its last thread raises the flag in pinned host memory
+// after writing the state there, so the result is on the host the moment the spin ends.
+int32_t finish_small_run(ndt2d_handle* h) {
+  if (!h->small_run) return NDT_OK;
+  h->small_run = false;
+  long spins = 0;
+  while (!__atomic_load_n(&h->h_flag[0], __ATOMIC_ACQUIRE)) {
+    if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess) break;   // drained without a flag: error below
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));              // the caller may release the source buffers on return
+  HIP_TRY(hipGetLastError());
+  const bool seen = __atomic_load_n(&h->h_flag[0], __ATOMIC_ACQUIRE) != 0;
+  h->pending = !seen;                                    // not seen: fetch_state copies dyn->state[0]
+  h->last_parity = 0;
+  return NDT_OK;
+}
+
 int32_t finish_chunk_run(ndt2d_handle* h) {
+  { const int32_t fs = finish_small_run(h); if (fs != NDT_OK) return fs; }
   if (!h->chunk_run.active) return NDT_OK;
   bool seen = false;
   HIP_TRY(chunk_run_finish(h->chunk_run, h->stream, h->h_flag, &seen));
@@ -332,6 +353,28 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
   const bool chunked = h->use_graph && check_every > 0 && fixed == 0;
   __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
   __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
+  if (h->use_small && h->use_graph && n <= (size_t)kSmallMaxPoints) {
+    // short scan: the whole loop in one launch of one workgroup (ndt2d_small.hpp)
+    const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON, four = h->prm.overlap_grids == 4;
+#define NDT_LAUNCH_SMALL(MODE, NG)                                                                                       \
+  do {                                                                                                                   \
+    if (n <= (size_t)kSmallLoPoints)                                                                                     \
+      hipLaunchKernelGGL((k_align_small<MODE, NG, kSmallThreadsLo>), dim3(1), dim3(kSmallThreadsLo), 0, h->stream,       \
+                         h->d_static, d_sx, d_sy, (int)n, pose[0], pose[1], pose[2], fixed, &h->d_dyn->state[0],         \
+                         h->h_state, h->h_flag);                                                                         \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k_align_small<MODE, NG, kSmallThreadsHi>), dim3(1), dim3(kSmallThreadsHi), 0, h->stream,       \
+                         h->d_static, d_sx, d_sy, (int)n, pose[0], pose[1], pose[2], fixed, &h->d_dyn->state[0],         \
+                         h->h_state, h->h_flag);                                                                         \
+  } while (0)
+    if (newton) { if (four) NDT_LAUNCH_SMALL(1, 4); else NDT_LAUNCH_SMALL(1, 1); }
+    else        { if (four) NDT_LAUNCH_SMALL(0, 4); else NDT_LAUNCH_SMALL(0, 1); }
+#undef NDT_LAUNCH_SMALL
+    HIP_TRY(hipGetLastError());
+    h->small_run = true;
+    h->pending = false;
+    return wait ? finish_small_run(h) : NDT_OK;
+  }
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, d_sx, d_sy, (int)n, pose[0], pose[1],
                      pose[2], fixed, chunked ? h->h_state : (IterState*)nullptr, chunked ? h->h_flag : (int*)nullptr);
   int k = 0;
@@ -489,6 +532,7 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
   { const char* e = std::getenv("NDT_DEBUG_NO_GRAPH"); h->use_graph = !(e && e[0] == '1'); }
+  { const char* e = std::getenv("NDT_DEBUG_NO_SMALL"); h->use_small = !(e && e[0] == '1'); }
   { const char* e = std::getenv("NDT_DEBUG_CHUNK"); const int v = e ? std::atoi(e) : 0; if (v >= 2 && v <= 128) h->check_every = v; }
   { const char* e = std::getenv("NDT_DEBUG_ATOMIC_BUILD"); h->use_binned_build = !(e && e[0] == '1'); }
   *out = h;

@@ -122,3 +122,51 @@ def test_async_converged_mode(gpu_lib):
         m.align_async(sx, sy, d["init"])
         H, g, s, nh = m.evaluate(d["sx"], d["sy"], ref.pose)
         assert nh > 0 and s > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_src,kw", [(360, {}), (1000, {}), (2048, {}), (2049, {}), (4096, {}), (1000, dict(hessian_mode=1)),
+                                      (1500, dict(overlap_grids=4)), (777, dict(line_search=3)), (900, dict(step_scale=2.5)),
+                                      (1000, dict(fixed_iterations=7))])
+def test_short_scan_kernel_equals_launch_per_iteration_path(gpu_lib, monkeypatch, n_src, kw):
+    """Scans of up to 4096 points run the whole loop in one workgroup (k_align_small); the result
+    must be what the general path (one launch per iteration, NDT_DEBUG_NO_SMALL=1) returns, up to
+    the float32 summation order, and what the oracle returns."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    from oracle import ndt2d as o
+    d = synth.make_pair(2, n_tgt=50000, n_src=n_src)
+    sx, sy = torch.from_numpy(d["sx"]).cuda(), torch.from_numpy(d["sy"]).cuda()
+    res = {}
+    for no_small in ("0", "1"):
+        monkeypatch.setenv("NDT_DEBUG_NO_SMALL", no_small)
+        with NdtMatcher2D(**kw) as m:
+            m.set_target(d["tx"], d["ty"])
+            res[no_small] = (m.align(sx, sy, d["init"]), m.align(d["sx"], d["sy"], d["init"]),
+                             m.evaluate(d["sx"], d["sy"], d["pose"]))
+            m.align_async(sx, sy, d["init"])
+            res[no_small] += (m.finish(),)
+    small, general = res["0"], res["1"]
+    assert small[0].pose == small[1].pose == small[3].pose            # device / host / async entry points
+    a, b = small[0], general[0]
+    if kw.get("hessian_mode", 0) == 0:        # Newton trajectories on sparse scans amplify rounding (DESIGN.md section 2.5)
+        assert a.status == b.status and abs(a.iterations - b.iterations) <= 1
+        assert np.abs(np.array(a.pose) - np.array(b.pose)).max() < 2e-6
+        assert a.n_hit == b.n_hit
+    Hs, gs, ss, ns_ = small[2]
+    Hg, gg, sg, ng = general[2]
+    assert ns_ == ng and abs(ss - sg) <= 2e-6 * sg and np.abs(Hs - Hg).max() <= 2e-6 * np.abs(Hg).max()
+    okw = dict(kw)
+    if "overlap_grids" in okw:
+        okw["overlap"] = okw.pop("overlap_grids")
+    prm = o.NdtParams(**okw)
+    grid = o.build_grids(d["tx"], d["ty"], prm) if prm.overlap == 4 else o.build_grid(d["tx"], d["ty"], prm)
+    if kw.get("hessian_mode", 0) == 0:
+        # the float32-mirror oracle follows the device evaluation point for point: tight; the float64
+        # oracle may settle a few cell flips away on these mid-density scans (its own float32 mirror
+        # does too): loose
+        r32 = o.align(grid, d["sx"], d["sy"], d["init"], prm, mirror32=True)
+        r64 = o.align(grid, d["sx"], d["sy"], d["init"], prm)
+        assert a.status == r32["status"] == r64["status"]
+        assert np.abs(np.array(a.pose) - np.array(r32["pose"])).max() < 1e-6
+        assert np.abs(np.array(a.pose) - np.array(r64["pose"])).max() < 5e-4
