@@ -567,6 +567,31 @@ __device__ __forceinline__ void copy_state(IterState* dst, const IterState* src,
   if (have_partials >= 0) dst->have_partials = have_partials;
 }
 
+// The 11 sums of a wave through LDS instead of 11 DPP trees (66 dependent steps): every lane
+// parks its 11 values ([j][lane], row stride 68 floats: at most 2-way bank conflicts on the way
+// back), then lane 4j+q adds the 16 values of accumulator j whose lane index is q mod 4 (two
+// independent chains), and the quad folds with two DPP steps.  Same wave throughout: LDS runs a
+// wave's operations in order, so no barrier.  Returns accumulator (lane >> 2)'s total, valid in
+// lanes < 44; a fixed order, so sums stay reproducible.
+constexpr int kSumRowStride = 68;
+__device__ __forceinline__ float wave_reduce11_lds(const float* acc, float* s_t, int lane) {
+#pragma unroll
+  for (int j = 0; j < kNumAcc - 1; ++j) s_t[j * kSumRowStride + lane] = acc[j];
+  __builtin_amdgcn_wave_barrier();
+  const int j = lane >> 2, q = lane & 3;
+  float a = 0.f, b = 0.f;
+  if (lane < 4 * (kNumAcc - 1)) {
+    const float* row = s_t + j * kSumRowStride + q;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) { a += row[4 * k]; b += row[4 * k + 4]; }
+  }
+  float v = a + b;
+  v += dpp_mov<0xB1, 0xf>(v);
+  v += dpp_mov<0x4E, 0xf>(v);
+  __builtin_amdgcn_wave_barrier();                     // s_t is rewritten by this wave next iteration
+  return v;
+}
+
 // ---------------------------------------------------------------- a4-a8 iterate kernel
 // Launch k (parity = k & 1) consumes state[parity^1] and partials[parity^1] written by
 // launch k-1 and produces state[parity], partials[parity].  Always kMaxBlocks workgroups
@@ -584,6 +609,7 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
                                                     AlignDyn* __restrict__ dyn, int parity) {
   __shared__ double s_red[kNumAcc];
   __shared__ float s_wave[THREADS / 64][kNumAcc];
+  __shared__ float s_t[THREADS / 64][(kNumAcc - 1) * kSumRowStride];
   if (EXP & 8) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const IterState* prev = &dyn->state[parity ^ 1];
@@ -632,14 +658,27 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
     int n_hit = 0, status = 0;
     bool done = false;
     if (!(EXP & 1)) {
-      // ---- prologue: fixed-order reduction (wave w owns sums 3w..3w+2), then the solve
+      // ---- prologue: fixed-order reduction (wave w owns sums 3w..3w+2), then the solve.
+      // Each lane folds its 4 blocks per row in float64 and parks the 3 values in LDS ([row][lane]);
+      // lane 16v+q adds the 4 values of row v whose lane index is q mod 16, four DPP steps fold the
+      // 16 lanes - instead of three 6-step float64 DPP trees on the critical path.
       if (wave < 4) {
+        double* t = reinterpret_cast<double*>(s_t[wave]);     // 3 x 66 doubles fit in the epilogue's buffer
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-          double a = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
-          a = wave_sum_lane63(a);
-          if (lane == 63) s_red[wave * 3 + v] = a;
+        for (int v = 0; v < 3; ++v)
+          t[v * 66 + lane] = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
+        __builtin_amdgcn_wave_barrier();
+        double a = 0.0;
+        if (lane < 48) {
+          const double* row = t + (lane >> 4) * 66 + (lane & 15);
+          a = (row[0] + row[16]) + (row[32] + row[48]);
         }
+        a += dpp_mov<0xB1, 0xf>(a);
+        a += dpp_mov<0x4E, 0xf>(a);
+        a += dpp_mov<0x124, 0xf>(a);
+        a += dpp_mov<0x128, 0xf>(a);                           // every lane of the 16-lane row holds its total
+        if ((lane & 15) == 0 && lane < 48) s_red[wave * 3 + (lane >> 4)] = a;
+        __builtin_amdgcn_wave_barrier();
       }
       __syncthreads();
 #pragma unroll
@@ -735,10 +774,9 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
     if (tid < kNumAcc) dyn->partials[parity][tid][blockIdx.x] = acc[tid & 1];
     return;
   }
-#pragma unroll
-  for (int j = 0; j < kNumAcc - 1; ++j) {
-    const float r = wave_sum_lane63(acc[j]);
-    if (lane == 63) s_wave[wave][j] = r;
+  {
+    const float r = wave_reduce11_lds(acc, s_t[wave], lane);
+    if ((lane & 3) == 0 && lane < 4 * (kNumAcc - 1)) s_wave[wave][lane >> 2] = r;
   }
   __syncthreads();
   if (tid < kNumAcc) {

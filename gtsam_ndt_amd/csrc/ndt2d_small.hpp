@@ -24,31 +24,6 @@ constexpr int kSmallThreadsLo = 256, kSmallThreadsHi = 1024;
 constexpr int kSmallLoPoints = kSmallThreadsLo * kSmallPts;    // 2048
 constexpr int kSmallMaxPoints = 4096;
 
-// The 11 sums of a wave through LDS instead of 11 DPP trees (66 dependent steps): every lane
-// parks its 11 values ([j][lane], row stride 68 floats: at most 2-way bank conflicts on the way
-// back), then lane 4j+q adds the 16 values of accumulator j whose lane index is q mod 4 (two
-// independent chains), and the quad folds with two DPP steps.  Same wave throughout: LDS runs a
-// wave's operations in order, so no barrier.  Returns accumulator (lane >> 2)'s total, valid in
-// lanes < 44; a fixed order, so sums stay reproducible.
-constexpr int kSmallRowStride = 68;
-__device__ __forceinline__ float wave_reduce11_lds(const float* acc, float* s_t, int lane) {
-#pragma unroll
-  for (int j = 0; j < kNumAcc - 1; ++j) s_t[j * kSmallRowStride + lane] = acc[j];
-  __builtin_amdgcn_wave_barrier();
-  const int j = lane >> 2, q = lane & 3;
-  float a = 0.f, b = 0.f;
-  if (lane < 4 * (kNumAcc - 1)) {
-    const float* row = s_t + j * kSmallRowStride + q;
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) { a += row[4 * k]; b += row[4 * k + 4]; }
-  }
-  float v = a + b;
-  v += dpp_mov<0xB1, 0xf>(v);
-  v += dpp_mov<0x4E, 0xf>(v);
-  __builtin_amdgcn_wave_barrier();                     // s_t is rewritten by this wave next iteration
-  return v;
-}
-
 template <int MODE, int NG, int kSmallThreads>
 __global__ __launch_bounds__(kSmallThreads) void k_align_small(const AlignStatic* __restrict__ st,
                                                                const float* __restrict__ sx,
@@ -59,7 +34,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_align_small(const AlignStatic
                                                                int* __restrict__ host_flag) {
   constexpr int kSmallWaves = kSmallThreads / 64;
   __shared__ float s_red[kSmallWaves][kNumAcc];
-  __shared__ float s_t[kSmallWaves][(kNumAcc - 1) * kSmallRowStride];
+  __shared__ float s_t[kSmallWaves][(kNumAcc - 1) * kSumRowStride];
   __shared__ double s_bc[16];       // pose(3) | H(6) g(3) score n_hit of the last evaluation
   __shared__ int s_misc[4];         // done, iter, status
   __shared__ LineSearch s_ls;

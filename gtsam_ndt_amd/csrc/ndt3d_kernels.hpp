@@ -8,6 +8,7 @@
 
 namespace ndt {
 
+constexpr int kSum3RowStride = 66;
 constexpr int kNumAcc3 = 32;   // 29 used: Htt(6) Htr(9) Hrr(6) g(6) score nhit
 
 struct CellAcc3 {   // 88 B
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
                                                       AlignDyn3* __restrict__ dyn, int parity) {
   __shared__ double s_red[kNumAcc3];
   __shared__ float s_wave[kBlock / 64][kNumAcc3];
+  __shared__ float s_t[kBlock / 64][29 * kSum3RowStride];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const IterState3* prev = &dyn->state[parity ^ 1];
   IterState3* cur = &dyn->state[parity];
@@ -371,11 +373,23 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
   }
   int iter = ps_iter;
   if (ps_have) {
+    // this wave's 8 rows of 256 block partials -> 8 totals.  Each lane folds its 4 blocks per row in
+    // float64 and parks the 8 values in LDS ([row][lane], stride 66); lane 8v+q then adds the 8
+    // values of row v whose lane index is q mod 8 and three DPP steps fold the 8 lanes - instead of
+    // 8 float64 DPP trees (each 6 steps x 3 instructions) on the iteration's critical path.
+    {
+      double* t = reinterpret_cast<double*>(s_t[wave]);       // 8 x 66 doubles fit in the epilogue's buffer
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      double a = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
-      a = wave_sum_lane63(a);
-      if (lane == 63) s_red[wave * 8 + v] = a;
+      for (int v = 0; v < 8; ++v)
+        t[v * kSum3RowStride + lane] = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
+      __builtin_amdgcn_wave_barrier();
+      const double* row = t + (lane >> 3) * kSum3RowStride + (lane & 7);
+      double a = ((row[0] + row[8]) + (row[16] + row[24])) + ((row[32] + row[40]) + (row[48] + row[56]));
+      a += dpp_mov<0xB1, 0xf>(a);
+      a += dpp_mov<0x4E, 0xf>(a);
+      a += dpp_mov<0x124, 0xf>(a);                               // row_ror:4 moves data up: lane 8v+4 gets lane 8v
+      if ((lane & 7) == 4) s_red[wave * 8 + (lane >> 3)] = a;
+      __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // 6x6 from the 21 packed sums: Htt(6) Htr(9) Hrr(6)
@@ -518,10 +532,23 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     x = xn; y = yn; z = zn; i = inext;
   }
 
+  // the wave's 29 sums through LDS instead of 29 DPP trees (wave_reduce11_lds of the 2D path):
+  // park [j][lane] (row stride 66 floats), lane 2j+q adds the 32 values of accumulator j whose
+  // lane index is q mod 2 in two chains, one quad DPP step folds the pair
+  {
+    float* t = s_t[wave];
 #pragma unroll
-  for (int j = 0; j < 29; ++j) {
-    const float r = wave_sum_lane63(acc[j]);
-    if (lane == 63) s_wave[wave][j] = r;
+    for (int j = 0; j < 29; ++j) t[j * kSum3RowStride + lane] = acc[j];
+    __builtin_amdgcn_wave_barrier();
+    float a = 0.f, b = 0.f;
+    if (lane < 58) {
+      const float* row = t + (lane >> 1) * kSum3RowStride + (lane & 1);
+#pragma unroll
+      for (int k = 0; k < 32; k += 2) { a += row[2 * k]; b += row[2 * k + 2]; }
+    }
+    float v = a + b;
+    v += dpp_mov<0xB1, 0xf>(v);
+    if ((lane & 1) == 0 && lane < 58) s_wave[wave][lane >> 1] = v;
   }
   __syncthreads();
   if (tid < kNumAcc3) {
