@@ -259,6 +259,13 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   return NDT_OK;
 }
 
+int32_t ndt3d_set_target_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n, void* stream) {
+  if (!h || !d_x || !d_y || !d_z || n == 0) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // producer of the device arrays
+  return set_target3_impl(h, d_x, d_y, d_z, n);
+}
+
 int32_t ndt3d_set_target(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n) {
   if (!h || !x || !y || !z || n == 0) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));

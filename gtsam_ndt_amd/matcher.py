@@ -432,6 +432,13 @@ class NdtMatcher3D:
         self.close()
 
     def set_target(self, x, y, z):
+        if _is_dev(x):
+            import torch
+            n = x.numel()
+            L.check(self._lib.ndt3d_set_target_dev(self._h, _dev_ptr(x, n), _dev_ptr(y, n), _dev_ptr(z, n), n,
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "ndt3d_set_target_dev")
+            return self.grid_info()
         x, y, z = _host_f32(x), _host_f32(y), _host_f32(z)
         L.check(self._lib.ndt3d_set_target(self._h, x.ctypes.data, y.ctypes.data, z.ctypes.data, x.size),
                 "ndt3d_set_target")

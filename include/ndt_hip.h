@@ -276,6 +276,9 @@ void ndt3d_default_params(ndt3d_params* p);   /* cell 1.0 m, min_points 5, step_
 int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** out);
 int32_t ndt3d_destroy(ndt3d_handle* h);
 int32_t ndt3d_set_target(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n);
+/* device arrays; `stream` = the stream that produced them (NULL: already complete) */
+int32_t ndt3d_set_target_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n,
+                             void* stream);
 int32_t ndt3d_get_grid_info(ndt3d_handle* h, ndt3d_grid_info* info);
 /* count [cells], mean [cells][3], icov [cells][6] (xx xy xz yy yz zz); any pointer may be NULL */
 int32_t ndt3d_get_grid(ndt3d_handle* h, int32_t* count, float* mean_xyz, float* icov6);

@@ -85,3 +85,15 @@ def test_align3d_full_config5(gpu_lib):
     assert r.status == 0
     e = np.abs(np.array(r.pose) - np.array(d["pose"]))
     assert e[:3].max() < 5e-3 and e[3:].max() < 1e-3             # recovers the generating pose
+
+
+def test_set_target3d_from_device_arrays(gpu_lib, small):
+    import torch
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    d, prm, g = small
+    with NdtMatcher3D() as a, NdtMatcher3D() as b:
+        ia = a.set_target(d["tx"], d["ty"], d["tz"])
+        ib = b.set_target(*(torch.from_numpy(d[k]).cuda() for k in ("tx", "ty", "tz")))
+        assert (ia.width, ia.height, ia.depth, ia.n_valid) == (ib.width, ib.height, ib.depth, ib.n_valid)
+        for u, v in zip(a.grid(), b.grid()):
+            np.testing.assert_array_equal(u, v)
