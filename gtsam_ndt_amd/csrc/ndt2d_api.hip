@@ -95,6 +95,11 @@ int32_t ensure_points(float** dx, float** dy, size_t* cap, size_t n) {
 
 int blocks_for(size_t) { return kMaxBlocks; }   // one workgroup per CU, always (see k_iterate)
 
+// k_bounds ends in four same-address atomics per block (about 10 ns each, serialised): few blocks
+#ifndef NDT_BOUNDS_BLOCKS
+#define NDT_BOUNDS_BLOCKS 128
+#endif
+constexpr int kBoundsBlocks = NDT_BOUNDS_BLOCKS;
 int stream_blocks(size_t n) {   // streaming kernels: up to 8 blocks per CU
   size_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -236,7 +241,7 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
   unsigned int* hb = (unsigned int*)h->h_small;
   std::memcpy(hb, init, sizeof(init));
   HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, sizeof(init), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > 512 ? 512 : stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
+  hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > kBoundsBlocks ? kBoundsBlocks : stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, sizeof(init), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
