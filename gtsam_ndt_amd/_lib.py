@@ -130,6 +130,7 @@ SIGNATURES = {
     "ndt2d_batch_align": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ndt2d_batch_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "ndt2d_batch_stream": (_vp, [_vp]),
+    "ndt2d_batch_last_large_count": (C.c_int64, [_vp]),
     "ndt2d_default_pyramid": (C.c_int32, [C.POINTER(Params2D), C.POINTER(Params2D)]),
     "ndt2d_batch_create_pyramid": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "ndt2d_multi_create_pyramid": (C.c_int32, [C.POINTER(Params2D), C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),

@@ -20,13 +20,7 @@ namespace ndt {
 #ifndef NDT_BATCH_UNROLL
 #define NDT_BATCH_UNROLL 2
 #endif
-constexpr int kBatchThreads = NDT_BATCH_THREADS;
-constexpr int kBatchWaves = kBatchThreads / 64;
-constexpr int kBatchMaxCells = 16384;   // dense index table: e.g. 128 x 128 cells
-constexpr int kBatchMaxSlots = 2304;    // records: slot 0 is a dummy invalid record, so 2303 cells
-                                        // with n >= min_points fit
 constexpr int kBatchUnroll = NDT_BATCH_UNROLL;   // source points per thread and register set
-constexpr int kBatchSlotsPerThread = (kBatchMaxSlots + kBatchThreads - 1) / kBatchThreads;
 
 struct ResultDev {   // layout of ndt2d_result (include/ndt_hip.h); static_assert in the API file
   double pose[3];
@@ -42,6 +36,9 @@ struct BatchArgs {
   const double* init;        // [n_pairs][3]
   ResultDev* out;            // [n_pairs]
   unsigned int* queue;       // zeroed before the launch
+  int* marks;                // [n_pairs], written by the small variant for every pair: 1 = exceeds its limits,
+                             // left alone; the large variant then processes exactly the marked pairs
+                             // (null: every pair)
   int n_pairs;
   int min_points;
   int fixed_iterations;
@@ -52,26 +49,58 @@ struct BatchArgs {
   SolveParams prm;
 };
 
-// LDS carve (bytes); everything in one dynamic array, every offset a multiple of 16
-constexpr int kLdsIdx = 0;                                            // u16 [MaxCells]
-constexpr int kLdsSlotN = kLdsIdx + kBatchMaxCells * 2;               // u32 [MaxSlots]
-constexpr int kLdsSlotKey = kLdsSlotN + kBatchMaxSlots * 4;           // u16 [MaxSlots]
-constexpr int kLdsSums = kLdsSlotKey + kBatchMaxSlots * 2;            // u64 [5][MaxSlots]; aliases:
-                                                                      //   u32 cnt[MaxCells] (build)
-                                                                      //   float4 recA[MaxSlots], float4 recB[MaxSlots]
-constexpr int kLdsRed = kLdsSums + 5 * kBatchMaxSlots * 8;            // float [Waves][kNumAcc]
-constexpr int kLdsBc = kLdsRed + kBatchWaves * kNumAcc * 4;           // double [16] broadcast
-constexpr int kLdsMisc = kLdsBc + 16 * 8;                             // int [16]
-constexpr int kLdsScan = kLdsMisc + 16 * 4;                           // int [Waves]
-constexpr int kLdsLs = kLdsScan + kBatchWaves * 4;                    // LineSearch (line-search state)
-constexpr int kBatchLdsBytes = kLdsLs + (int)sizeof(LineSearch);
-static_assert(kBatchMaxCells * 4 <= 5 * kBatchMaxSlots * 8, "cnt must fit in the sums region");
-static_assert(kBatchMaxSlots * 32 <= 5 * kBatchMaxSlots * 8, "records must fit in the sums region");
-static_assert(kBatchLdsBytes <= 160 * 1024, "CDNA4 LDS is 160 KiB per CU");
-static_assert((kLdsSlotN % 16) == 0 && (kLdsSlotKey % 16) == 0 && (kLdsSums % 16) == 0 && (kLdsRed % 16) == 0 &&
-              (kLdsBc % 16) == 0 && (kLdsMisc % 16) == 0, "16-byte aligned carve");
+// Workgroup shape and on-chip capacities of one kernel variant.  LDS carve in bytes: everything in
+// one dynamic array, every offset a multiple of 16.
+//   Large  1024 threads, one workgroup per CU: 128 x 128 cells, 2303 occupied - the BASELINE config-4
+//          pairs (100k-point submap scans); sums reduced by DPP (no LDS left for anything else)
+//   Small   256 threads, two workgroups per CU: 128 x 128 cells, 511 occupied, clouds of up to 8192
+//          points - single lidar scans; the per-iteration fixed costs of a 16-wave workgroup (DPP
+//          trees on four waves per SIMD) are what bounds those, so this variant keeps one wave
+//          per SIMD per pair and sums through LDS (wave_reduce11_lds)
+template <int THREADS, int MAXCELLS, int MAXSLOTS, int MAXPOINTS, bool LDSSUMS, bool PACKEDCOUNT>
+struct BatchCfg {
+  static constexpr int kThreads = THREADS;
+  static constexpr int kWaves = THREADS / 64;
+  static constexpr int kMaxCells = MAXCELLS;      // dense index table
+  static constexpr int kMaxSlots = MAXSLOTS;      // records: slot 0 is a dummy invalid record
+  static constexpr int kMaxPoints = MAXPOINTS;    // per cloud; 0 = no limit
+  static constexpr bool kSumsViaLds = LDSSUMS;
+  // per-cell point counts of the build as u16 pairs in the index table itself (clouds of fewer
+  // than 65536 points; the slot index then overwrites each count in place) instead of a u32
+  // table aliased onto the sums region - what lets a 128 x 128-cell grid fit a small workgroup
+  static constexpr bool kPackedCount = PACKEDCOUNT;
+  static constexpr int kSlotsPerThread = (MAXSLOTS + THREADS - 1) / THREADS;
+  static constexpr int kLdsIdx = 0;                                        // u16 [MaxCells]
+  static constexpr int kLdsSlotN = kLdsIdx + MAXCELLS * 2;                 // u32 [MaxSlots]
+  static constexpr int kLdsSlotKey = kLdsSlotN + MAXSLOTS * 4;             // u16 [MaxSlots]
+  static constexpr int kLdsSums = kLdsSlotKey + MAXSLOTS * 2;              // u64 [5][MaxSlots]; aliases:
+                                                                           //   u32 cnt[MaxCells] (build)
+                                                                           //   float4 recA[MaxSlots], recB[MaxSlots]
+  static constexpr int kLdsRed = kLdsSums + 5 * MAXSLOTS * 8;              // float [Waves][kNumAcc]
+  static constexpr int kLdsBc = kLdsRed + kWaves * kNumAcc * 4;            // double [16] broadcast
+  static constexpr int kLdsMisc = kLdsBc + 16 * 8;                         // int [16]
+  static constexpr int kLdsScan = kLdsMisc + 16 * 4;                       // int [16]
+  static constexpr int kLdsLs = kLdsScan + 16 * 4;                         // LineSearch (line-search state)
+  static constexpr int kLdsT = kLdsLs + 80;                                // float [Waves][11 * 68] if kSumsViaLds
+  static_assert(sizeof(LineSearch) <= 80, "LineSearch slot");
+  static constexpr int kLdsBytes = kLdsT + (LDSSUMS ? kWaves * (kNumAcc - 1) * kSumRowStride * 4 : 0);
+  static_assert(PACKEDCOUNT || MAXCELLS * 4 <= 5 * MAXSLOTS * 8, "cnt must fit in the sums region");
+  static_assert(!PACKEDCOUNT || (MAXPOINTS > 0 && MAXPOINTS < 65536), "packed counts are 16-bit");
+  static_assert(MAXSLOTS * 32 <= 5 * MAXSLOTS * 8, "records must fit in the sums region");
+  static_assert(kLdsBytes <= 160 * 1024, "CDNA4 LDS is 160 KiB per CU");
+  static_assert((kLdsSlotN % 16) == 0 && (kLdsSlotKey % 16) == 0 && (kLdsSums % 16) == 0 && (kLdsRed % 16) == 0 &&
+                (kLdsBc % 16) == 0 && (kLdsMisc % 16) == 0 && (kLdsLs % 16) == 0 && (kLdsT % 16) == 0, "16-byte aligned carve");
+  static_assert(MAXSLOTS - 1 <= 0xffff && MAXCELLS <= 0x10000, "u16 slot indices and cell keys");
+};
+using BatchLarge = BatchCfg<NDT_BATCH_THREADS, 16384, 2304, 0, false, false>;
+using BatchSmall = BatchCfg<256, 16384, 512, 8192, true, true>;
+constexpr int kBatchThreads = BatchLarge::kThreads;       // names the host code and tools/ use
+constexpr int kBatchMaxCells = BatchLarge::kMaxCells;
+constexpr int kBatchMaxSlots = BatchLarge::kMaxSlots;
+constexpr int kBatchLdsBytes = BatchLarge::kLdsBytes;
 
 // exclusive scan of one int per thread over the 1024-thread workgroup; *total = sum
+template <class Cfg>
 __device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
@@ -84,7 +113,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* total) {
   __syncthreads();
   int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kBatchWaves; ++w) {
+  for (int w = 0; w < Cfg::kWaves; ++w) {
     const int t = s_scan[w];
     if (w < wave) base += t;
     tot += t;
@@ -134,21 +163,21 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
 // loop pays the full memory latency per trip: 98 dependent round trips per pass).  Loads go
 // through a buffer descriptor of the pair's slice: lanes past the end read 0 and are skipped.
 constexpr int kTgtUnroll = 8;
-template <typename F>
+template <class Cfg, typename F>
 __device__ __forceinline__ void for_each_target_point(const float* tx, const float* ty, int nt, F&& body) {
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)tx, 0, nt * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)ty, 0, nt * 4, 0x00020000);
-  for (int i = threadIdx.x; i < nt; i += kTgtUnroll * kBatchThreads) {
+  for (int i = threadIdx.x; i < nt; i += kTgtUnroll * Cfg::kThreads) {
     float x[kTgtUnroll], y[kTgtUnroll];
 #pragma unroll
     for (int u = 0; u < kTgtUnroll; ++u) {
-      const int off = (i + u * kBatchThreads) * 4;
+      const int off = (i + u * Cfg::kThreads) * 4;
       x[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
       y[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
     }
 #pragma unroll
     for (int u = 0; u < kTgtUnroll; ++u)
-      if (i + u * kBatchThreads < nt) body(x[u], y[u]);
+      if (i + u * Cfg::kThreads < nt) body(x[u], y[u]);
   }
 }
 
@@ -157,19 +186,19 @@ constexpr int kStatusCapacity = -5;   // NDT_ERR_CAPACITY: pair needs the global
 // One pair, start to finish, on the calling workgroup.  Early outs are plain returns: the
 // caller's queue loop then has a single back edge (with `continue`s inside the loop body
 // hipcc's loop restructuring produced a kernel that re-read the same queue slot forever).
-template <int MODE>
+template <int MODE, class Cfg>
 __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair, unsigned char* smem) {
-  unsigned short* idx = reinterpret_cast<unsigned short*>(smem + kLdsIdx);
-  unsigned int* slot_n = reinterpret_cast<unsigned int*>(smem + kLdsSlotN);
-  unsigned short* slot_key = reinterpret_cast<unsigned short*>(smem + kLdsSlotKey);
-  unsigned long long* sums = reinterpret_cast<unsigned long long*>(smem + kLdsSums);
-  unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + kLdsSums);
-  float4* recA = reinterpret_cast<float4*>(smem + kLdsSums);
-  float4* recB = reinterpret_cast<float4*>(smem + kLdsSums + kBatchMaxSlots * 16);
-  float* red = reinterpret_cast<float*>(smem + kLdsRed);
-  double* bc = reinterpret_cast<double*>(smem + kLdsBc);
-  int* misc = reinterpret_cast<int*>(smem + kLdsMisc);
-  int* s_scan = reinterpret_cast<int*>(smem + kLdsScan);
+  unsigned short* idx = reinterpret_cast<unsigned short*>(smem + Cfg::kLdsIdx);
+  unsigned int* slot_n = reinterpret_cast<unsigned int*>(smem + Cfg::kLdsSlotN);
+  unsigned short* slot_key = reinterpret_cast<unsigned short*>(smem + Cfg::kLdsSlotKey);
+  unsigned long long* sums = reinterpret_cast<unsigned long long*>(smem + Cfg::kLdsSums);
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + Cfg::kLdsSums);
+  float4* recA = reinterpret_cast<float4*>(smem + Cfg::kLdsSums);
+  float4* recB = reinterpret_cast<float4*>(smem + Cfg::kLdsSums + Cfg::kMaxSlots * 16);
+  float* red = reinterpret_cast<float*>(smem + Cfg::kLdsRed);
+  double* bc = reinterpret_cast<double*>(smem + Cfg::kLdsBc);
+  int* misc = reinterpret_cast<int*>(smem + Cfg::kLdsMisc);
+  int* s_scan = reinterpret_cast<int*>(smem + Cfg::kLdsScan);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int minpts = a.min_points < 2 ? 2 : a.min_points;
   const double zero6[6] = {0, 0, 0, 0, 0, 0};
@@ -183,6 +212,13 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     const float* __restrict__ ty = a.ty + t0;
     const float* __restrict__ sx = a.sx + s0;
     const float* __restrict__ sy = a.sy + s0;
+    if (Cfg::kMaxPoints > 0) {                       // the small variant leaves big pairs to the large one
+      const bool over = nt > Cfg::kMaxPoints || ns > Cfg::kMaxPoints;     // uniform
+      if (tid == 0) a.marks[pair] = over ? 1 : 0;    // every pair passes here once: no memset of the marks
+      if (over) return;
+    } else if (a.marks) {                            // the large variant after a small pass: marked pairs only
+      if (__builtin_amdgcn_readfirstlane(a.marks[pair]) == 0) return;
+    }
     double pose[3] = {a.init[3 * pair], a.init[3 * pair + 1], wrap_angle(a.init[3 * pair + 2])};
     ResultDev* out = a.out + pair;
     int iter_base = 0;
@@ -197,7 +233,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     // ---- a1: bounding box of the target and grid geometry (oracle/ndt2d.py grid_geometry)
     {
       float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-      for_each_target_point(tx, ty, nt, [&](float u, float v) {
+      for_each_target_point<Cfg>(tx, ty, nt, [&](float u, float v) {
         if (isfinite(u) && isfinite(v)) {
           xmin = fminf(xmin, u); xmax = fmaxf(xmax, u);
           ymin = fminf(ymin, v); ymax = fmaxf(ymax, v);
@@ -208,7 +244,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       if (lane == 0) { red[wave * 4 + 0] = xmin; red[wave * 4 + 1] = xmax; red[wave * 4 + 2] = ymin; red[wave * 4 + 3] = ymax; }
       __syncthreads();
       if (tid == 0) {
-        for (int w = 1; w < kBatchWaves; ++w) {
+        for (int w = 1; w < Cfg::kWaves; ++w) {
           xmin = fminf(xmin, red[w * 4 + 0]); xmax = fmaxf(xmax, red[w * 4 + 1]);
           ymin = fminf(ymin, red[w * 4 + 2]); ymax = fmaxf(ymax, red[w * 4 + 3]);
         }
@@ -221,7 +257,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
           ox = (float)((floor((double)xmin / a.cell) - 1.0) * a.cell);
           oy = (float)((floor((double)ymin / a.cell) - 1.0) * a.cell);
           const float kx = floorf((xmax - ox) * inv_c), ky = floorf((ymax - oy) * inv_c);
-          if (!(kx >= 0.f) || !(ky >= 0.f) || (double)(kx + 2.f) * (double)(ky + 2.f) > (double)kBatchMaxCells) {
+          if (!(kx >= 0.f) || !(ky >= 0.f) || (double)(kx + 2.f) * (double)(ky + 2.f) > (double)Cfg::kMaxCells) {
             st = kStatusCapacity;
           } else {
             W = (int)kx + 2; H = (int)ky + 2;
@@ -243,34 +279,51 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     static_assert(kFixShift == 22, "fix_scale literal");
     __syncthreads();                                 // misc is rewritten below
     if (status != 0) {                               // uniform
-      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, iter_base, 0, status);
+      if (tid == 0) {
+        if (Cfg::kMaxPoints > 0 && status == kStatusCapacity) a.marks[pair] = 1;   // too many cells for this variant
+        else write_result(out, pose, zero6, zero6, 0.0, iter_base, 0, status);
+      }
       return;
     }
 
     // ---- a2 (1/2): per-cell counts
-    for (int k = tid; k < ncell; k += kBatchThreads) cnt[k] = 0u;
+    unsigned int* cnt_pairs = reinterpret_cast<unsigned int*>(idx);      // kPackedCount: two u16 counters per word
+    if (Cfg::kPackedCount) {
+      for (int k = tid; k < (ncell + 1) / 2; k += Cfg::kThreads) cnt_pairs[k] = 0u;
+    } else {
+      for (int k = tid; k < ncell; k += Cfg::kThreads) cnt[k] = 0u;
+    }
     __syncthreads();
-    for_each_target_point(tx, ty, nt, [&](float px, float py) {
+    for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
       const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
-      if ((fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH)) atomicAdd(&cnt[(int)fy * W + (int)fx], 1u);
+      if ((fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH)) {
+        const int key = (int)fy * W + (int)fx;
+        if (Cfg::kPackedCount) atomicAdd(&cnt_pairs[key >> 1], (key & 1) ? 0x10000u : 1u);   // nt < 65536: no carry
+        else atomicAdd(&cnt[key], 1u);
+      }
     });
     __syncthreads();
+    // the count of cell k, whichever table holds it (the u16 view of the packed words is idx itself)
+    auto cell_count = [&](int k) -> unsigned int { return Cfg::kPackedCount ? (unsigned int)idx[k] : cnt[k]; };
 
     // ---- compaction: cells with n >= min_points get a slot, in cell order (deterministic)
-    const int chunk = (ncell + kBatchThreads - 1) / kBatchThreads;
+    const int chunk = (ncell + Cfg::kThreads - 1) / Cfg::kThreads;
     const int c0 = tid * chunk < ncell ? tid * chunk : ncell;
     const int c1 = c0 + chunk < ncell ? c0 + chunk : ncell;
     int local = 0;
-    for (int k = c0; k < c1; ++k) local += (cnt[k] >= (unsigned)minpts) ? 1 : 0;
+    for (int k = c0; k < c1; ++k) local += (cell_count(k) >= (unsigned)minpts) ? 1 : 0;
     int nslot = 0;
-    int s = block_excl_scan(local, s_scan, &nslot);
+    int s = block_excl_scan<Cfg>(local, s_scan, &nslot);
     nslot = __builtin_amdgcn_readfirstlane(nslot);
-    if (nslot > kBatchMaxSlots - 1 || nslot < 1) {   // uniform (record 0 is the dummy)
-      if (tid == 0) write_result(out, pose, zero6, zero6, 0.0, iter_base, 0, nslot < 1 ? 4 : kStatusCapacity);
+    if (nslot > Cfg::kMaxSlots - 1 || nslot < 1) {   // uniform (record 0 is the dummy)
+      if (tid == 0) {
+        if (Cfg::kMaxPoints > 0 && nslot >= 1) a.marks[pair] = 1;                    // too many occupied cells for this variant
+        else write_result(out, pose, zero6, zero6, 0.0, iter_base, 0, nslot < 1 ? 4 : kStatusCapacity);
+      }
       return;
     }
     for (int k = c0; k < c1; ++k) {
-      const unsigned int n = cnt[k];
+      const unsigned int n = cell_count(k);              // read before idx[k] is overwritten (same thread, same k)
       if (n >= (unsigned)minpts) {
         idx[k] = (unsigned short)(s + 1);
         slot_n[s] = n;
@@ -281,12 +334,12 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       }
     }
     __syncthreads();                                 // cnt is dead; its bytes become the sums
-    for (int j = tid; j < 5 * kBatchMaxSlots; j += kBatchThreads)
-      if ((j % kBatchMaxSlots) < nslot) sums[j] = 0ull;
+    for (int j = tid; j < 5 * Cfg::kMaxSlots; j += Cfg::kThreads)
+      if ((j % Cfg::kMaxSlots) < nslot) sums[j] = 0ull;
     __syncthreads();
 
     // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics)
-    for_each_target_point(tx, ty, nt, [&](float px, float py) {
+    for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
       const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
       if ((fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH)) {
         const int ix = (int)fx, iy = (int)fy;
@@ -296,10 +349,10 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
           const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
           unsigned long long* q = sums + (slot - 1);
           atomicAdd(q, (unsigned long long)(long long)ux);
-          atomicAdd(q + kBatchMaxSlots, (unsigned long long)(long long)uy);
-          atomicAdd(q + 2 * kBatchMaxSlots, prod64(ux, ux));
-          atomicAdd(q + 3 * kBatchMaxSlots, prod64(ux, uy));
-          atomicAdd(q + 4 * kBatchMaxSlots, prod64(uy, uy));
+          atomicAdd(q + Cfg::kMaxSlots, (unsigned long long)(long long)uy);
+          atomicAdd(q + 2 * Cfg::kMaxSlots, prod64(ux, ux));
+          atomicAdd(q + 3 * Cfg::kMaxSlots, prod64(ux, uy));
+          atomicAdd(q + 4 * Cfg::kMaxSlots, prod64(uy, uy));
         }
       }
     });
@@ -308,21 +361,21 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
 
     // ---- a3: finalise (<= 3 slots per thread held in registers, then overwrite the sums)
     {
-      float4 ra[kBatchSlotsPerThread], rb[kBatchSlotsPerThread];
+      float4 ra[Cfg::kSlotsPerThread], rb[Cfg::kSlotsPerThread];
       int nvalid = 0;
 #pragma unroll
-      for (int j = 0; j < kBatchSlotsPerThread; ++j) {
-        const int sl = tid + j * kBatchThreads;
+      for (int j = 0; j < Cfg::kSlotsPerThread; ++j) {
+        const int sl = tid + j * Cfg::kThreads;
         ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (sl < nslot) {
           const int key = slot_key[sl];
           const int n = (int)slot_n[sl];
           const bool ok = n <= (int)kMaxCellCount &&
-                          finalise_sums(n, (long long)sums[sl], (long long)sums[sl + kBatchMaxSlots],
-                                        (long long)sums[sl + 2 * kBatchMaxSlots],
-                                        (long long)sums[sl + 3 * kBatchMaxSlots],
-                                        (long long)sums[sl + 4 * kBatchMaxSlots],
+                          finalise_sums(n, (long long)sums[sl], (long long)sums[sl + Cfg::kMaxSlots],
+                                        (long long)sums[sl + 2 * Cfg::kMaxSlots],
+                                        (long long)sums[sl + 3 * Cfg::kMaxSlots],
+                                        (long long)sums[sl + 4 * Cfg::kMaxSlots],
                                         cell_centre(ox, key % W, a.cell), cell_centre(oy, key / W, a.cell),
                                         fix_scale, a.min_points, a.eig_ratio, ra[j], rb[j]);
           nvalid += ok ? 1 : 0;
@@ -330,8 +383,8 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       }
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < kBatchSlotsPerThread; ++j) {
-        const int sl = tid + j * kBatchThreads;
+      for (int j = 0; j < Cfg::kSlotsPerThread; ++j) {
+        const int sl = tid + j * Cfg::kThreads;
         if (sl < nslot) { recA[sl + 1] = ra[j]; recB[sl + 1] = rb[j]; }   // record index = idx value
       }
       if (tid == 0) { recA[0] = make_float4(0.f, 0.f, 0.f, 0.f); recB[0] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -351,7 +404,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     if (tid == 0) { misc[9] = 0; misc[10] = 0; }     // iter, status
     __syncthreads();
     // line-search state lives in LDS so that it is not held in registers across the point loop
-    LineSearch* ls_lds = reinterpret_cast<LineSearch*>(smem + kLdsLs);
+    LineSearch* ls_lds = reinterpret_cast<LineSearch*>(smem + Cfg::kLdsLs);
     if (tid == 0) { ls_lds->valid = 0; ls_lds->trials = 0; }
     for (;;) {
       float acc[kNumAcc];
@@ -368,7 +421,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
         // between trips (a copy is a use and would put the wait right behind the loads).
         // Every load of a wave is 256 contiguous bytes; lanes past the end re-read the last
         // point and are masked by `live`.
-        constexpr int kTrip = kBatchUnroll * kBatchThreads;
+        constexpr int kTrip = kBatchUnroll * Cfg::kThreads;
         float xa[kBatchUnroll], ya[kBatchUnroll], xb[kBatchUnroll], yb[kBatchUnroll];
         // Source points come through buffer descriptors: 32-bit byte offsets instead of 64-bit
         // address arithmetic, and the hardware range check returns 0 past the end of the pair's
@@ -378,7 +431,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
         auto load_set = [&](int base, float* xs, float* ys) {
 #pragma unroll
           for (int u = 0; u < kBatchUnroll; ++u) {
-            const int off = (base + u * kBatchThreads) * 4;
+            const int off = (base + u * Cfg::kThreads) * 4;
 #if defined(NDT_BATCH_ABLATE) && (NDT_BATCH_ABLATE & 2)      // tools only: no global point loads
             xs[u] = (float)((off >> 2) & 1023) * 0.04f - 20.f;
             ys[u] = (float)(off >> 12) * 0.4f - 20.f;
@@ -392,7 +445,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
           PointRec r[kBatchUnroll];
 #pragma unroll
           for (int u = 0; u < kBatchUnroll; ++u)
-            lookup_point_lds(P, idx, recA, recB, xs[u], ys[u], (base + u * kBatchThreads) < ns, r[u]);
+            lookup_point_lds(P, idx, recA, recB, xs[u], ys[u], (base + u * Cfg::kThreads) < ns, r[u]);
 #pragma unroll
           for (int u = 0; u < kBatchUnroll; ++u) accumulate_point<MODE>(P, r[u], A);
         };
@@ -408,29 +461,38 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
         acc_store(A, a.prm.d2, acc);
         acc[11] = 0.f;
       }
+      if (Cfg::kSumsViaLds) {
+        float* s_t = reinterpret_cast<float*>(smem + Cfg::kLdsT) + wave * ((kNumAcc - 1) * kSumRowStride);
+        const float rsum = wave_reduce11_lds(acc, s_t, lane);
+        if ((lane & 3) == 0 && lane < 4 * (kNumAcc - 1)) red[wave * kNumAcc + (lane >> 2)] = rsum;
+      } else {
 #pragma unroll
-      for (int j = 0; j < kNumAcc - 1; ++j) {
-        const float rsum = wave_sum_lane63(acc[j]);
-        if (lane == 63) red[wave * kNumAcc + j] = rsum;
+        for (int j = 0; j < kNumAcc - 1; ++j) {
+          const float rsum = wave_sum_lane63(acc[j]);
+          if (lane == 63) red[wave * kNumAcc + j] = rsum;
+        }
       }
       __syncthreads();
       if (wave == 0) {
-        // lane j < 11 sums column j over the 16 waves in a fixed order, in float64
-        double tot = 0.0;
+        // lane j < 11 sums column j over the waves in a fixed order, in float64, and parks it in
+        // LDS; every lane reads the totals back (broadcast reads, one wait) - H(6) g(3) score n_hit
+        // of this evaluation stay there for the result
         if (lane < kNumAcc - 1) {
+          double tot = 0.0;
 #pragma unroll
-          for (int w = 0; w < kBatchWaves; ++w) tot += (double)red[w * kNumAcc + lane];
+          for (int w = 0; w < Cfg::kWaves; ++w) tot += (double)red[w * kNumAcc + lane];
+          bc[3 + lane] = tot;
         }
+        __builtin_amdgcn_wave_barrier();               // same wave: LDS executes its operations in order
         double H[6], g[3];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) H[j] = __shfl(tot, j, 64);
+        for (int j = 0; j < 6; ++j) H[j] = bc[3 + j];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) g[j] = __shfl(tot, 6 + j, 64);
-        const int n_hit = (int)(__shfl(tot, 10, 64) + 0.5);
+        for (int j = 0; j < 3; ++j) g[j] = bc[9 + j];
+        const int n_hit = (int)(bc[13] + 0.5);
         int iter = misc[9], st = 0;
-        const bool done = gn_update(pose, H, g, n_hit, iter, st, a.prm, a.fixed_iterations, __shfl(tot, 9, 64),
-                                    ls_lds, ls_lds, lane == 0);
-        if (lane < kNumAcc - 1) bc[3 + lane] = tot;          // H(6) g(3) score n_hit of this evaluation
+        const bool done = gn_update(pose, H, g, n_hit, iter, st, a.prm, a.fixed_iterations, bc[12], ls_lds, ls_lds,
+                                    lane == 0);
         if (lane == 0) {
           bc[0] = pose[0]; bc[1] = pose[1]; bc[2] = pose[2];
           misc[8] = done ? 1 : 0;
@@ -449,10 +511,10 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
   }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBatchThreads) void k_batch(BatchArgs a) {
+template <int MODE, class Cfg = BatchLarge>
+__global__ __launch_bounds__(Cfg::kThreads) void k_batch(BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* misc = reinterpret_cast<int*>(smem + kLdsMisc);
+  int* misc = reinterpret_cast<int*>(smem + Cfg::kLdsMisc);
   for (;;) {
     // dequeue one pair (every wave reaches this; the loop ends for all of them together)
     if (threadIdx.x == 0) misc[0] = (int)atomicAdd(a.queue, 1u);
@@ -460,7 +522,7 @@ __global__ __launch_bounds__(kBatchThreads) void k_batch(BatchArgs a) {
     const int pair = __builtin_amdgcn_readfirstlane(misc[0]);   // wave-uniform by construction
     __syncthreads();
     if (pair >= a.n_pairs) break;
-    process_pair<MODE>(a, pair, smem);
+    process_pair<MODE, Cfg>(a, pair, smem);
     __syncthreads();                                 // LDS is rewritten by the next pair
   }
 }

@@ -20,6 +20,10 @@ struct ndt2d_batch {
   ndt2d_result* d_out = nullptr;
   size_t pcap = 0;
   std::vector<ndt2d_handle*> fallback;   // global-memory path (one handle per level) for pairs over the LDS capacity
+  int* d_marks = nullptr;                // [n_pairs]: pairs the small variant left to the large one
+  size_t marks_cap = 0;
+  bool use_small = true;                 // NDT_DEBUG_NO_BATCH_SMALL=1: every pair through the large variant
+  int64_t last_large = -1;               // pairs the last host-pointer call's final level ran on the large variant
 };
 
 static_assert(sizeof(ndt::ResultDev) == sizeof(ndt2d_result), "ResultDev mirrors ndt2d_result");
@@ -39,8 +43,20 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
   a.queue = b->d_queue;
   a.n_pairs = (int)n_pairs;
   const int blocks = (int)(n_pairs < (size_t)b->n_cu ? n_pairs : (size_t)b->n_cu);
-  // one launch per resolution level; a later level starts every pair from the pose the
-  // previous one left in d_out (stream order is the only synchronisation between levels)
+  // the small variant keeps two workgroups resident per CU
+  const size_t small_max = 2 * (size_t)b->n_cu;
+  const int blocks_small = (int)(n_pairs < small_max ? n_pairs : small_max);
+  if (b->use_small && n_pairs > b->marks_cap) {
+    if (b->d_marks) (void)hipFree(b->d_marks);
+    b->d_marks = nullptr; b->marks_cap = 0;
+    const size_t want = n_pairs + n_pairs / 4 + 64;
+    HIP_TRY(hipMalloc((void**)&b->d_marks, want * sizeof(int)));
+    b->marks_cap = want;
+  }
+  // Per resolution level: the small variant takes every pair it can hold (lidar-sized scans) and
+  // marks the rest, the large variant then takes exactly the marked ones.  A later level starts
+  // every pair from the pose the previous one left in d_out; stream order is the only
+  // synchronisation between launches.
   for (size_t lv = 0; lv < b->levels.size(); ++lv) {
     const ndt2d_params& p = b->levels[lv];
     a.chain = lv > 0 ? 1 : 0;
@@ -56,11 +72,25 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
     a.prm.eps_trans = p.eps_trans; a.prm.eps_rot = p.eps_rot;
     a.prm.step_max_trans = p.step_max_trans; a.prm.step_max_rot = p.step_max_rot;
     a.prm.step_scale = p.step_scale > 0.0 ? p.step_scale : 1.0;
+    const bool newton = p.hessian_mode == NDT_HESSIAN_NEWTON;
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 16, st));
-    if (p.hessian_mode == NDT_HESSIAN_NEWTON)
-      hipLaunchKernelGGL(ndt::k_batch<1>, dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
+    a.marks = nullptr;
+    if (b->use_small) {
+      a.marks = b->d_marks;
+      a.queue = b->d_queue;
+      if (newton)
+        hipLaunchKernelGGL((ndt::k_batch<1, ndt::BatchSmall>), dim3(blocks_small), dim3(ndt::BatchSmall::kThreads),
+                           ndt::BatchSmall::kLdsBytes, st, a);
+      else
+        hipLaunchKernelGGL((ndt::k_batch<0, ndt::BatchSmall>), dim3(blocks_small), dim3(ndt::BatchSmall::kThreads),
+                           ndt::BatchSmall::kLdsBytes, st, a);
+      HIP_TRY(hipGetLastError());
+    }
+    a.queue = b->d_queue + 1;                        // its own dequeue counter
+    if (newton)
+      hipLaunchKernelGGL((ndt::k_batch<1, ndt::BatchLarge>), dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
     else
-      hipLaunchKernelGGL(ndt::k_batch<0>, dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
+      hipLaunchKernelGGL((ndt::k_batch<0, ndt::BatchLarge>), dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
     HIP_TRY(hipGetLastError());
   }
   return NDT_OK;
@@ -124,10 +154,15 @@ int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels,
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipMalloc((void**)&b->d_queue, 16) != hipSuccess) return fail(NDT_ERR_ALLOC);
   // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<0, ndt::BatchSmall>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::BatchSmall::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<1, ndt::BatchSmall>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::BatchSmall::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::kBatchLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::kBatchLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  { const char* e = std::getenv("NDT_DEBUG_NO_BATCH_SMALL"); b->use_small = !(e && e[0] == '1'); }
   *out = b;
   return NDT_OK;
 }
@@ -141,13 +176,15 @@ int32_t ndt2d_batch_destroy(ndt2d_batch* b) {
   if (!b) return NDT_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* dev[] = {b->d_queue, b->d_tx, b->d_ty, b->d_sx, b->d_sy, b->d_toff, b->d_soff, b->d_init, b->d_out};
+  void* dev[] = {b->d_queue, b->d_tx, b->d_ty, b->d_sx, b->d_sy, b->d_toff, b->d_soff, b->d_init, b->d_out, b->d_marks};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (ndt2d_handle* f : b->fallback) ndt2d_destroy(f);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return NDT_OK;
 }
+
+int64_t ndt2d_batch_last_large_count(const ndt2d_batch* b) { return b ? b->last_large : -1; }
 
 void* ndt2d_batch_stream(ndt2d_batch* b) { return b ? (void*)b->stream : nullptr; }
 
@@ -195,7 +232,14 @@ int32_t ndt2d_batch_align(ndt2d_batch* b, const float* tx, const float* ty, cons
   st = batch_launch(b, b->d_tx, b->d_ty, b->d_toff, b->d_sx, b->d_sy, b->d_soff, b->d_init, n_pairs, b->d_out, s);
   if (st != NDT_OK) return st;
   HIP_TRY(hipMemcpyAsync(results, b->d_out, n_pairs * sizeof(ndt2d_result), hipMemcpyDeviceToHost, s));
+  std::vector<int> marks;
+  if (b->use_small) {
+    marks.resize(n_pairs);
+    HIP_TRY(hipMemcpyAsync(marks.data(), b->d_marks, n_pairs * sizeof(int), hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(hipStreamSynchronize(s));
+  b->last_large = b->use_small ? 0 : (int64_t)n_pairs;
+  for (int m : marks) b->last_large += m != 0;
   // pairs whose grid does not fit the on-chip capacity go through the global-memory path
   for (size_t k = 0; k < n_pairs; ++k) {
     if (results[k].status != NDT_ERR_CAPACITY) continue;

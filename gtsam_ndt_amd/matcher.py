@@ -346,6 +346,11 @@ class NdtBatch2D:
     def stream(self) -> int:
         return int(self._lib.ndt2d_batch_stream(self._h) or 0)
 
+    @property
+    def last_large_count(self) -> int:
+        """Pairs of the last align() call that needed the 1024-thread kernel variant (diagnostic)."""
+        return int(self._lib.ndt2d_batch_last_large_count(self._h))
+
     def align(self, targets, sources, inits):
         """targets / sources: lists of (x, y) numpy pairs; inits: [n][3].  Returns a list of
         AlignResult.  Pairs over the on-chip capacity are re-run through the general path."""

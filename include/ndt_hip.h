@@ -220,6 +220,10 @@ int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_
                               const float* d_sx, const float* d_sy, const uint64_t* d_soff,
                               const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream);
 void* ndt2d_batch_stream(ndt2d_batch* b);
+/* Of the pairs of the last ndt2d_batch_align() call, how many ran on the 1024-thread variant of
+ * the kernel (the rest fitted the 256-thread variant for lidar-sized scans: clouds of at most 8192
+ * points, at most 511 occupied cells); -1 before the first call.  Diagnostic. */
+int64_t ndt2d_batch_last_large_count(const ndt2d_batch* b);
 
 /* The same batch over several devices from ONE host process (a C++ SLAM back end that owns the
  * node's GPUs itself): one batch context and one host thread per device, pairs split into

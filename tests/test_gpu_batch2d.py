@@ -210,3 +210,59 @@ def test_batch_pyramid_matches_oracle_composition_and_widens_the_basin(gpu_lib, 
         bad = b.align([(sub[0]["tx"][:3], sub[0]["ty"][:3]), T[1]], [S[0], S[1]], inits[:2])
     assert bad[0].status == 4 and bad[0].iterations == 0
     assert bad[1].pose == res[1].pose
+
+
+def test_small_pair_variant_equals_large_variant_and_oracle(gpu_lib, monkeypatch):
+    """Lidar-sized pairs run on the 256-thread variant of the batch kernel (three pairs per CU);
+    pairs over its limits (points, cells, occupied cells) are left to the 1024-thread variant in
+    the same call.  Same results as with the small variant switched off, and as the oracle."""
+    from gtsam_ndt_amd import matcher as M
+    from oracle import ndt2d as o
+    sizes = [(1000, 1000), (360, 360), (4000, 3000), (8192, 8192), (8193, 500), (500, 8193), (20000, 20000), (2000, 2000),
+             (3, 50), (1500, 0)]
+    pairs = []
+    for k, (nt, ns) in enumerate(sizes):
+        p = synth.make_pair(4, pair_index=40 + k, n_tgt=max(nt, 1), n_src=max(ns, 1))
+        if ns == 0:
+            p["sx"], p["sy"] = p["sx"][:0], p["sy"][:0]
+        pairs.append(p)
+    T = [(p["tx"], p["ty"]) for p in pairs]
+    S = [(p["sx"], p["sy"]) for p in pairs]
+    I = [p["init"] for p in pairs]
+    res = {}
+    for off in ("0", "1"):
+        monkeypatch.setenv("NDT_DEBUG_NO_BATCH_SMALL", off)
+        with M.NdtBatch2D() as b:
+            res[off] = b.align(T, S, I)
+            # (8193, 500), (500, 8193), (20000, 20000) exceed the point limit; (8192, 8192) and (4000, 3000)
+            # occupy more than 511 cells; the others fit the small variant
+            assert b.last_large_count == (len(T) if off == "1" else 5), b.last_large_count
+            again = b.align(T, S, I)
+            assert [r.pose for r in again] == [r.pose for r in res[off]]          # deterministic, marks reset
+    prm = o.NdtParams()
+    for k, (p, a, b) in enumerate(zip(pairs, res["0"], res["1"])):
+        assert a.status == b.status, (k, a.status, b.status)
+        if a.status in (0, 1):
+            # float32 summation order differs between the variants; sparse scans stop a step apart
+            assert abs(a.iterations - b.iterations) <= 2 and abs(a.n_hit - b.n_hit) <= 1, k
+            assert np.abs(np.array(a.pose) - np.array(b.pose)).max() < 2e-5, k
+            if len(p["tx"]) >= 1000:
+                ref = o.align(o.build_grid(p["tx"], p["ty"], prm), p["sx"], p["sy"], p["init"], prm, mirror32=True)
+                assert np.abs(np.array(a.pose) - np.array(ref["pose"])).max() < 1e-5, k
+    # a cell size that needs more than 64 x 64 cells: the small variant hands the pair over
+    for off in ("0", "1"):
+        monkeypatch.setenv("NDT_DEBUG_NO_BATCH_SMALL", off)
+        with M.NdtBatch2D(cell_size=0.2) as b:
+            res[off] = b.align(T[:3], S[:3], I[:3])
+    for a, b in zip(res["0"], res["1"]):
+        assert a.status == b.status and np.abs(np.array(a.pose) - np.array(b.pose)).max() < 2e-5
+    # coarse-to-fine over a mixed batch
+    monkeypatch.setenv("NDT_DEBUG_NO_BATCH_SMALL", "0")
+    with M.NdtBatch2D(levels=M.pyramid_params()) as b:
+        pyr = b.align(T[:8], S[:8], I[:8])
+    monkeypatch.setenv("NDT_DEBUG_NO_BATCH_SMALL", "1")
+    with M.NdtBatch2D(levels=M.pyramid_params()) as b:
+        pyr_l = b.align(T[:8], S[:8], I[:8])
+    for a, b in zip(pyr, pyr_l):
+        assert a.status == b.status and abs(a.iterations - b.iterations) <= 3
+        assert np.abs(np.array(a.pose) - np.array(b.pose)).max() < 2e-5
