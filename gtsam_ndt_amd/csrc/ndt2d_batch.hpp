@@ -53,7 +53,7 @@ struct BatchArgs {
 // one dynamic array, every offset a multiple of 16.
 //   Large  1024 threads, one workgroup per CU: 128 x 128 cells, 2303 occupied - the BASELINE config-4
 //          pairs (100k-point submap scans); sums reduced by DPP (no LDS left for anything else)
-//   Small   256 threads, two workgroups per CU: 128 x 128 cells, 511 occupied, clouds of up to 8192
+//   Small   256 threads, two workgroups per CU (2 x 78.7 KB of LDS): 128 x 128 cells, 767 occupied, clouds of up to 8192
 //          points - single lidar scans; the per-iteration fixed costs of a 16-wave workgroup (DPP
 //          trees on four waves per SIMD) are what bounds those, so this variant keeps one wave
 //          per SIMD per pair and sums through LDS (wave_reduce11_lds)
@@ -93,7 +93,7 @@ struct BatchCfg {
   static_assert(MAXSLOTS - 1 <= 0xffff && MAXCELLS <= 0x10000, "u16 slot indices and cell keys");
 };
 using BatchLarge = BatchCfg<NDT_BATCH_THREADS, 16384, 2304, 0, false, false>;
-using BatchSmall = BatchCfg<256, 16384, 512, 8192, true, true>;
+using BatchSmall = BatchCfg<256, 16384, 768, 8192, true, true>;
 constexpr int kBatchThreads = BatchLarge::kThreads;       // names the host code and tools/ use
 constexpr int kBatchMaxCells = BatchLarge::kMaxCells;
 constexpr int kBatchMaxSlots = BatchLarge::kMaxSlots;

@@ -222,7 +222,7 @@ int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_
 void* ndt2d_batch_stream(ndt2d_batch* b);
 /* Of the pairs of the last ndt2d_batch_align() call, how many ran on the 1024-thread variant of
  * the kernel (the rest fitted the 256-thread variant for lidar-sized scans: clouds of at most 8192
- * points, at most 511 occupied cells); -1 before the first call.  Diagnostic. */
+ * points, at most 767 occupied cells); -1 before the first call.  Diagnostic. */
 int64_t ndt2d_batch_last_large_count(const ndt2d_batch* b);
 
 /* The same batch over several devices from ONE host process (a C++ SLAM back end that owns the

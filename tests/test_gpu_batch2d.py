@@ -234,9 +234,9 @@ def test_small_pair_variant_equals_large_variant_and_oracle(gpu_lib, monkeypatch
         monkeypatch.setenv("NDT_DEBUG_NO_BATCH_SMALL", off)
         with M.NdtBatch2D() as b:
             res[off] = b.align(T, S, I)
-            # (8193, 500), (500, 8193), (20000, 20000) exceed the point limit; (8192, 8192) and (4000, 3000)
-            # occupy more than 511 cells; the others fit the small variant
-            assert b.last_large_count == (len(T) if off == "1" else 5), b.last_large_count
+            # (8193, 500), (500, 8193), (20000, 20000) exceed the point limit; (8192, 8192) occupies more
+            # than 767 cells; the others fit the small variant
+            assert b.last_large_count == (len(T) if off == "1" else 4), b.last_large_count
             again = b.align(T, S, I)
             assert [r.pose for r in again] == [r.pose for r in res[off]]          # deterministic, marks reset
     prm = o.NdtParams()
