@@ -74,6 +74,53 @@ def main3d():
     print(path, os.path.getsize(path), "bytes;", r["iterations"], "iterations; pose", r["pose"])
 
 
+OPTION_CASES = {
+    # name: (NdtParams keyword arguments, offset added to the config-1 initial guess)
+    "step_scale_3": (dict(step_scale=3.0), (0.0, 0.0, 0.0)),
+    "line_search_4": (dict(line_search=4), (0.05, -0.04, 0.01)),
+    "overlap_4": (dict(overlap=4), (0.0, 0.0, 0.0)),
+    "cell_1m_eig_0p03": (dict(cell_size=1.0, eig_ratio=0.03), (0.1, 0.1, -0.02)),
+    "magnusson_0p3": (dict(), (0.0, 0.0, 0.0)),          # d1, d2 filled in from the mixture constants below
+    "fixed_12_scale_2": (dict(fixed_iterations=12, step_scale=2.0), (0.0, 0.0, 0.0)),
+}
+
+
+def magnusson(outlier_ratio: float, cell: float, dim: int):
+    """Magnusson 2009 eq. 6.8-6.10 as include/ndt_hip.h states them (d1 returned positive)."""
+    import math
+    c1 = 10.0 * (1.0 - outlier_ratio)
+    c2 = outlier_ratio / cell ** dim
+    d3 = -math.log(c2)
+    d1 = -math.log(c1 + c2) - d3
+    d2 = -2.0 * math.log((-math.log(c1 * math.exp(-0.5) + c2) - d3) / d1)
+    return -d1, d2
+
+
+def main_options():
+    """tests/golden/ndt2d_options.npz: what the optional parts of the contract (over-relaxation,
+    line search, overlapping grids, other cell sizes, mixture score constants) return on the
+    config-1 pair.  Inputs are those of ndt2d_config1.npz; only results are stored."""
+    d = synth.make_pair(1)
+    out = {}
+    for name, (kw, off) in OPTION_CASES.items():
+        kw = dict(kw)
+        if name.startswith("magnusson"):
+            kw["d1"], kw["d2"] = magnusson(0.3, 0.5, 2)
+            out[name + "_d1d2"] = np.array([kw["d1"], kw["d2"]])
+        prm = o.NdtParams(**kw)
+        grid = o.build_grids(d["tx"], d["ty"], prm) if prm.overlap == 4 else o.build_grid(d["tx"], d["ty"], prm)
+        init = tuple(a + b for a, b in zip(d["init"], off))
+        r = o.align(grid, d["sx"], d["sy"], init, prm)
+        out[name + "_pose"] = np.array(r["pose"])
+        out[name + "_meta"] = np.array([r["iterations"], r["status"], r["n_hit"]], dtype=np.int64)
+        out[name + "_score"] = np.float64(r["score"])
+        print(name, r["iterations"], r["status"], r["pose"])
+    path = os.path.join(ROOT, "tests", "golden", "ndt2d_options.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     main()
     main3d()
+    main_options()

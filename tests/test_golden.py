@@ -111,3 +111,57 @@ def test_hip_3d_matches_golden(gpu_lib):
         m.set_target(g3["tx"], g3["ty"], g3["tz"])
         r = m.align(g3["sx"], g3["sy"], g3["sz"], tuple(g3["init"]))
     assert r.iterations == 5 and np.abs(np.array(r.pose) - g3["fixed5_pose"]).max() < 1e-4
+
+
+GOLD_OPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ndt2d_options.npz")
+
+
+def _option_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(GOLD), "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.OPTION_CASES, mod.magnusson
+
+
+def test_oracle_reproduces_option_golden(gold):
+    """The optional parts of the contract (over-relaxation, line search, overlapping grids, other
+    cell sizes, mixture constants) still give the committed results on the config-1 pair."""
+    from oracle import ndt2d as o
+    cases, magnusson = _option_cases()
+    opt = np.load(GOLD_OPT)
+    for name, (kw, off) in cases.items():
+        kw = dict(kw)
+        if name.startswith("magnusson"):
+            kw["d1"], kw["d2"] = magnusson(0.3, 0.5, 2)
+            np.testing.assert_allclose(opt[name + "_d1d2"], [kw["d1"], kw["d2"]], rtol=1e-15)
+        prm = o.NdtParams(**kw)
+        grid = o.build_grids(gold["tx"], gold["ty"], prm) if prm.overlap == 4 else o.build_grid(gold["tx"], gold["ty"], prm)
+        init = tuple(a + b for a, b in zip(gold["init"], off))
+        r = o.align(grid, gold["sx"], gold["sy"], init, prm)
+        assert [r["iterations"], r["status"], r["n_hit"]] == list(opt[name + "_meta"]), name
+        np.testing.assert_allclose(np.array(r["pose"]), opt[name + "_pose"], rtol=0, atol=1e-12, err_msg=name)
+        assert abs(r["score"] - float(opt[name + "_score"])) <= 1e-9 * float(opt[name + "_score"]), name
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_option_golden(gold, gpu_lib):
+    from gtsam_ndt_amd.matcher import NdtMatcher2D, magnusson_constants
+    cases, _ = _option_cases()
+    opt = np.load(GOLD_OPT)
+    for name, (kw, off) in cases.items():
+        kw = dict(kw)
+        if "overlap" in kw:
+            kw["overlap_grids"] = kw.pop("overlap")
+        if name.startswith("magnusson"):
+            kw["d1"], kw["d2"] = magnusson_constants(0.3, 0.5, 2)          # the library's own constants
+            np.testing.assert_allclose([kw["d1"], kw["d2"]], opt[name + "_d1d2"], rtol=1e-12)
+        init = tuple(a + b for a, b in zip(gold["init"], off))
+        with NdtMatcher2D(**kw) as m:
+            m.set_target(gold["tx"], gold["ty"])
+            r = m.align(gold["sx"], gold["sy"], init)
+        its, status, n_hit = (int(v) for v in opt[name + "_meta"])
+        assert r.status == status, name
+        e = np.abs(np.array(r.pose) - opt[name + "_pose"])
+        assert e.max() < 1e-4, (name, r.pose, opt[name + "_pose"])              # 1e-4 m / 1e-4 rad
+        assert abs(r.iterations - its) <= 3, (name, r.iterations, its)
