@@ -630,7 +630,7 @@ int32_t ndt2d_add_target_points_dev(ndt2d_handle* h, const float* d_x, const flo
   if (n_outside) *n_outside = (size_t)outside;
   if (fs != NDT_OK) { h->has_target = false; return fs; }
   h->n_points += n - (size_t)outside;
-  return upload_static(h);
+  return NDT_OK;          // geometry, storage and parameters are unchanged: the device context stays as it is
 }
 
 int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y, size_t n, size_t* n_outside) {
@@ -646,9 +646,8 @@ int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y,
   const int32_t fs = accumulate_and_finalise(h, h->d_tx, h->d_ty, n, /*merge=*/true, &outside);
   if (n_outside) *n_outside = (size_t)outside;
   if (fs != NDT_OK) { h->has_target = false; return fs; }
-  unsigned long long* ho = &outside;
-  h->n_points += n - (size_t)*ho;
-  return upload_static(h);
+  h->n_points += n - (size_t)outside;
+  return NDT_OK;          // as above: nothing in the device context changes
 }
 
 int32_t ndt2d_get_grid_info(ndt2d_handle* h, ndt2d_grid_info* info) {

@@ -12,3 +12,13 @@ with NdtMatcher2D() as m:
     for _ in range(12):
         t0 = time.perf_counter(); m.set_target(tx, ty); ts.append(time.perf_counter() - t0)
     print(os.environ.get("NDT_HIP_LIB", "default"), "set_target 1M points: median %.1f us" % (1e6 * np.median(ts[2:])))
+
+# incremental update: a 7200-point scan merged into the 1M-point submap
+from gtsam_ndt_amd.synth import make_pair
+with NdtMatcher2D() as m:
+    m.set_target(tx, ty)
+    sx = tx[:7200].contiguous(); sy = ty[:7200].contiguous()
+    ts = []
+    for _ in range(12):
+        t0 = time.perf_counter(); m.add_target_points(sx, sy, pose=(0.01, 0.0, 0.0)); ts.append(time.perf_counter() - t0)
+    print("add_target_points_dev 7200 points into the 1M-point grid: median %.1f us" % (1e6 * np.median(ts[2:])))
