@@ -40,6 +40,7 @@ struct ndt2d_handle {
   AlignCall* d_call = nullptr;
   AlignDyn* d_dyn = nullptr;
   AlignStatic* h_static = nullptr;         // pinned
+  hipEvent_t upload_ev = nullptr;          // recorded after the last upload from h_static
   IterState* h_state = nullptr;            // pinned
   int* h_flag = nullptr;                   // pinned: [0] raised by the launch that ends a converged-mode loop, [1] progress
   int last_parity = 0;
@@ -261,6 +262,9 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
 // whenever the target changes; the per-call part is written by k_begin from kernel arguments,
 // so no host buffer has to outlive an asynchronous call.
 int32_t upload_static(ndt2d_handle* h) {
+  // The copy is left in flight (everything that reads d_static is ordered behind it on the same
+  // stream); the pinned source is only rewritten once the previous copy has left it.
+  HIP_TRY(hipEventSynchronize(h->upload_ev));
   AlignStatic* c = h->h_static;
   c->grid = h->grid;
   SolveParams& p = c->prm;
@@ -276,7 +280,7 @@ int32_t upload_static(ndt2d_handle* h) {
   p.step_max_rot = h->prm.step_max_rot;
   p.step_scale = h->prm.step_scale > 0.0 ? h->prm.step_scale : 1.0;
   HIP_TRY(hipMemcpyAsync(h->d_static, c, sizeof(AlignStatic), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipEventRecord(h->upload_ev, h->stream));
   return NDT_OK;
 }
 
@@ -533,6 +537,7 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipHostMalloc((void**)&h->h_static, sizeof(AlignStatic), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_state, sizeof(IterState), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipEventCreateWithFlags(&h->upload_ev, hipEventDisableTiming) != hipSuccess) return fail(NDT_ERR_HIP);
   *h->h_flag = 0;
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
@@ -555,6 +560,7 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag};
   for (void* p : host) if (p) (void)hipHostFree(p);
+  if (h->upload_ev) (void)hipEventDestroy(h->upload_ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return NDT_OK;
