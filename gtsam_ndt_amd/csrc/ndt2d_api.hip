@@ -321,12 +321,19 @@ int32_t finish_small_run(ndt2d_handle* h) {
   if (!h->small_run) return NDT_OK;
   h->small_run = false;
   long spins = 0;
+  bool seen = true;
   while (!__atomic_load_n(&h->h_flag[0], __ATOMIC_ACQUIRE)) {
-    if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess) break;   // drained without a flag: error below
+    if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess) {   // drained without a flag
+      seen = __atomic_load_n(&h->h_flag[0], __ATOMIC_ACQUIRE) != 0;
+      break;
+    }
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));              // the caller may release the source buffers on return
-  HIP_TRY(hipGetLastError());
-  const bool seen = __atomic_load_n(&h->h_flag[0], __ATOMIC_ACQUIRE) != 0;
+  // No stream sync once the flag is up: the kernel read the scan into registers at its start and
+  // raises the flag as its last action, so the caller's source buffers are already free.
+  if (!seen) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipGetLastError());
+  }
   h->pending = !seen;                                    // not seen: fetch_state copies dyn->state[0]
   h->last_parity = 0;
   return NDT_OK;
