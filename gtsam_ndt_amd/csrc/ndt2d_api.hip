@@ -351,7 +351,7 @@ int32_t finish_chunk_run(ndt2d_handle* h) {
 }
 
 int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n, const double pose[3],
-                  int fixed_override, int check_every, bool wait = true) {
+                  int fixed_override, int check_every, bool wait = true, bool own_source = false) {
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }   // an unfinished asynchronous call
   if (n == 0 || n > 0x7fffffffull || !pose) return NDT_ERR_INVALID_ARG;
@@ -400,6 +400,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
       const int chunk = check_every + (check_every & 1);
       const int32_t gs = ensure_graph(h, chunk, blocks);
       if (gs != NDT_OK) return gs;
+      h->chunk_run.drain = !own_source;                // the handle's own staging arrays outlive the call
       HIP_TRY(chunk_run_begin(h->chunk_run, h->graph_exec, h->stream, chunk, K + 1));
       h->pending = false;
       return wait ? finish_chunk_run(h) : NDT_OK;
@@ -767,7 +768,9 @@ int32_t ndt2d_align(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
   if (st != NDT_OK) return st;
   HIP_TRY(hipMemcpyAsync(h->d_sx, sx, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_sy, sy, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  return ndt2d_align_dev(h, h->d_sx, h->d_sy, n, init_pose, out);
+  const int32_t rs = run_align(h, h->d_sx, h->d_sy, n, init_pose, -1, h->check_every, /*wait=*/true, /*own_source=*/true);
+  if (rs != NDT_OK) return rs;
+  return ndt2d_align_finish(h, out);
 }
 
 }  // extern "C"

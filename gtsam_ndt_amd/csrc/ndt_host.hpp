@@ -98,6 +98,8 @@ struct ChunkRun {          // a converged-mode loop in flight (begin ... finish)
   hipGraphExec_t exec = nullptr;
   int chunk = 0, max_launches = 0, launched = 0;
   bool active = false;
+  bool drain = true;       // wait for the launches enqueued past the end before returning: they still read
+                           // the source arrays, so only a caller that owns those arrays may skip it
 };
 
 // Enqueue the first two chunks and return: the asynchronous half.
@@ -130,8 +132,10 @@ inline hipError_t chunk_run_finish(ChunkRun& r, hipStream_t stream, int* flag, b
     e = hipGraphLaunch(r.exec, stream);
     ++r.launched;
   }
-  const hipError_t es = hipStreamSynchronize(stream);
-  if (e == hipSuccess) e = es;
+  if (r.drain || e != hipSuccess || !raised()) {
+    const hipError_t es = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = es;
+  }
   *seen = raised();
   r.active = false;
   return e;
