@@ -53,6 +53,7 @@ struct ndt2d_handle {
   ChainGraphCache graphs;
   hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
   ChunkRun chunk_run;                      // converged-mode loop begun by ndt2d_align_dev_async
+  int call_seq = 0;                        // alignments enqueued so far (never 0 once one has run)
   bool small_run = false;                  // a k_align_small launch whose flag has not been waited for
   bool use_small = true;                   // NDT_DEBUG_NO_SMALL=1: short scans go through k_iterate too
   bool use_graph = true;
@@ -369,6 +370,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
   const bool chunked = h->use_graph && check_every > 0 && fixed == 0;
   __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
   __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
+  h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
   if (h->use_small && h->use_graph && n <= (size_t)kSmallMaxPoints) {
     // short scan: the whole loop in one launch of one workgroup (ndt2d_small.hpp)
     const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON, four = h->prm.overlap_grids == 4;
@@ -392,7 +394,8 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
     return wait ? finish_small_run(h) : NDT_OK;
   }
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, d_sx, d_sy, (int)n, pose[0], pose[1],
-                     pose[2], fixed, chunked ? h->h_state : (IterState*)nullptr, chunked ? h->h_flag : (int*)nullptr);
+                     pose[2], fixed, chunked ? h->h_state : (IterState*)nullptr, chunked ? h->h_flag : (int*)nullptr,
+                     h->call_seq);
   int k = 0;
   if (h->use_graph) {
     if (chunked) {
@@ -401,6 +404,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
       const int32_t gs = ensure_graph(h, chunk, blocks);
       if (gs != NDT_OK) return gs;
       h->chunk_run.drain = !own_source;                // the handle's own staging arrays outlive the call
+      h->chunk_run.seq = h->call_seq;
       HIP_TRY(chunk_run_begin(h->chunk_run, h->graph_exec, h->stream, chunk, K + 1));
       h->pending = false;
       return wait ? finish_chunk_run(h) : NDT_OK;

@@ -98,6 +98,8 @@ struct AlignCall {
   // into, so the host sees the end of the loop without a copy or a stream sync (null = off)
   IterState* host_state;
   int* host_flag;
+  int seq;                   // this call's number: what the first launch past the end reports in host_flag[2]
+  int pad;
 };
 struct AlignDyn {
   IterState state[2];
@@ -415,8 +417,10 @@ __device__ __forceinline__ bool gn_update(double* pose, const double* H, const d
 // Per-call part of the context, written from kernel arguments (no host buffer lifetime).
 __global__ void k_begin(AlignCall* __restrict__ call, AlignDyn* __restrict__ dyn, const float* sx,
                         const float* sy, int n, double p0, double p1, double p2, int fixed_iterations,
-                        IterState* host_state, int* host_flag) {
+                        IterState* host_state, int* host_flag, int seq) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  call->seq = seq;
+  call->pad = 0;
   call->sx = sx;
   call->sy = sy;
   call->n = n;
@@ -648,7 +652,12 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
   if (i + stride < n) { x1 = sx[i + stride]; y1 = sy[i + stride]; }
 
   if (ps_done) {                         // uniform: a finished alignment just carries its state
-    if (writer) copy_state(cur, prev, -1);
+    if (writer) {
+      copy_state(cur, prev, -1);
+      // the launch that finished the loop is complete (this one started after it) and left n = 0
+      // behind: nothing reads the source arrays any more - tell the host it may hand them back
+      if (host_flag) __hip_atomic_store(host_flag + 2, call->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;
   }
   double pose[3] = {ps_pose0, ps_pose1, ps_pose2};
@@ -714,6 +723,7 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
       if (host_flag) {                   // tell the host directly
         if (done) {                      // state first, then the flag
           *host_state = o;
+          const_cast<AlignCall*>(call)->n = 0;     // the launches enqueued past the end load no points
           __threadfence_system();
           __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {                         // progress: which launch this is

@@ -24,6 +24,7 @@ struct ndt3d_handle {
   ndt::AlignStatic3* h_static = nullptr;
   ndt::IterState3* h_state = nullptr;
   int* h_flag = nullptr;              // pinned: raised by the launch that ends a converged-mode loop
+  int call_seq = 0;                   // alignments enqueued so far
   ndt::ChainGraphCache graphs;
   hipGraphExec_t graph_exec = nullptr;   // selected by ensure_graph3, owned by `graphs`
   bool host_result = false;           // result already in h_state (no device work was enqueued)
@@ -166,9 +167,10 @@ int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const floa
   const int fixed = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
   __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
   __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
+  h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
   hipLaunchKernelGGL(k_begin3, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, dx, dy, dz, (int)n, pose[0], pose[1],
                      pose[2], pose[3], pose[4], pose[5], fixed, fixed > 0 ? (IterState3*)nullptr : h->h_state,
-                     fixed > 0 ? (int*)nullptr : h->h_flag);
+                     fixed > 0 ? (int*)nullptr : h->h_flag, h->call_seq);
   const int K = fixed > 0 ? fixed : h->prm.max_iterations;
   int last_parity;
   if (fixed > 0) {
@@ -181,7 +183,7 @@ int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const floa
     const int32_t gs = ensure_graph3(h, chunk);
     if (gs != NDT_OK) return gs;
     bool seen = false;
-    HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->h_flag, chunk, K + 1, &seen));
+    HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->h_flag, chunk, K + 1, h->call_seq, &seen));
     HIP_TRY(hipGetLastError());
     if (seen) return NDT_OK;                           // the finishing launch wrote h_state itself
     last_parity = 1;

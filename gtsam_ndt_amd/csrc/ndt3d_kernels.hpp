@@ -47,6 +47,8 @@ struct AlignCall3 {
   int fixed_iterations;
   IterState3* host_state;    // as AlignCall: pinned host memory for the finishing launch, or null
   int* host_flag;
+  int seq;                   // as AlignCall
+  int pad;
 };
 struct LineSearch3 {      // LineSearch of ndt2d_kernels.hpp for a 6-vector pose
   double base[6];
@@ -302,8 +304,10 @@ __device__ __forceinline__ bool gn_update3(double* pose, const double* A, const 
 // Per-call part of the context (k_begin of the 2D path).
 __global__ void k_begin3(AlignCall3* __restrict__ call, AlignDyn3* __restrict__ dyn, const float* sx,
                          const float* sy, const float* sz, int n, double p0, double p1, double p2, double p3,
-                         double p4, double p5, int fixed_iterations, IterState3* host_state, int* host_flag) {
+                         double p4, double p5, int fixed_iterations, IterState3* host_state, int* host_flag, int seq) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  call->seq = seq;
+  call->pad = 0;
   call->sx = sx; call->sy = sy; call->sz = sz;
   call->n = n;
   call->fixed_iterations = fixed_iterations;
@@ -368,7 +372,10 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
   if (i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
 
   if (ps_done) {
-    if (writer) copy_state3(cur, prev, -1);
+    if (writer) {
+      copy_state3(cur, prev, -1);
+      if (host_flag) __hip_atomic_store(host_flag + 2, call->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // as k_iterate
+    }
     return;
   }
   int iter = ps_iter;
@@ -425,6 +432,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
       if (host_flag) {                   // tell the host directly
         if (done) {                      // state first, then the flag
           store(host_state);
+          const_cast<AlignCall3*>(call)->n = 0;    // the launches enqueued past the end load no points
           __threadfence_system();
           __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {                         // progress: which launch this is

@@ -98,8 +98,9 @@ struct ChunkRun {          // a converged-mode loop in flight (begin ... finish)
   hipGraphExec_t exec = nullptr;
   int chunk = 0, max_launches = 0, launched = 0;
   bool active = false;
-  bool drain = true;       // wait for the launches enqueued past the end before returning: they still read
-                           // the source arrays, so only a caller that owns those arrays may skip it
+  int seq = 0;             // number of this call: flag[2] == seq means "nothing reads the sources any more"
+  bool drain = true;       // before returning, wait until nothing reads the source arrays any more (the
+                           // first launch past the end says so); a caller that owns those arrays may skip it
 };
 
 // Enqueue the first two chunks and return: the asynchronous half.
@@ -132,9 +133,17 @@ inline hipError_t chunk_run_finish(ChunkRun& r, hipStream_t stream, int* flag, b
     e = hipGraphLaunch(r.exec, stream);
     ++r.launched;
   }
-  if (r.drain || e != hipSuccess || !raised()) {
+  if (e != hipSuccess || !raised()) {
     const hipError_t es = hipStreamSynchronize(stream);
     if (e == hipSuccess) e = es;
+  } else if (r.drain) {
+    // flag[2]: raised by the first launch past the end - the finishing launch (whose other workgroups
+    // may still have had point loads in flight when the flag went up) is complete by then, and it left
+    // n = 0 behind, so no later launch touches the source arrays.  Falls back to the stream's end.
+    spins = 0;
+    while (__atomic_load_n(&flag[2], __ATOMIC_ACQUIRE) != r.seq) {
+      if ((++spins & 0xffff) == 0 && hipStreamQuery(stream) == hipSuccess) break;
+    }
   }
   *seen = raised();
   r.active = false;
@@ -142,8 +151,9 @@ inline hipError_t chunk_run_finish(ChunkRun& r, hipStream_t stream, int* flag, b
 }
 
 inline hipError_t run_chunks_until_flag(hipGraphExec_t exec, hipStream_t stream, int* flag, int chunk, int max_launches,
-                                        bool* seen) {
+                                        int seq, bool* seen) {
   ChunkRun r;
+  r.seq = seq;
   const hipError_t e = chunk_run_begin(r, exec, stream, chunk, max_launches);
   if (e != hipSuccess) { *seen = false; (void)hipStreamSynchronize(stream); return e; }
   return chunk_run_finish(r, stream, flag, seen);

@@ -25,13 +25,13 @@ float time_chain(hipStream_t st, AlignStatic* d_st, AlignCall* d_call, AlignDyn*
   CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int w = 0; w < 20; ++w) {
-    hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, st, d_call, d_dyn, sx, sy, n, 0.1, -0.08, 0.01, K, (IterState*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, st, d_call, d_dyn, sx, sy, n, 0.1, -0.08, 0.01, K, (IterState*)nullptr, (int*)nullptr, 0);
     CK(hipGraphLaunch(ge, st));
   }
   CK(hipStreamSynchronize(st));
   CK(hipEventRecord(e0, st));
   for (int r = 0; r < reps; ++r) {
-    hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, st, d_call, d_dyn, sx, sy, n, 0.1, -0.08, 0.01, K, (IterState*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, st, d_call, d_dyn, sx, sy, n, 0.1, -0.08, 0.01, K, (IterState*)nullptr, (int*)nullptr, 0);
     CK(hipGraphLaunch(ge, st));
   }
   CK(hipEventRecord(e1, st));
