@@ -69,7 +69,7 @@ def traffic(kernel_prefix):
 
 
 it = traffic("k_iterate<")
-ba = traffic("k_batch<")
+ba = traffic("BatchCfg<1024")          # the 1024-thread variant does the config-4 pairs; the 256-thread pre-pass only marks them
 i3 = traffic("k_iterate3")
 summary = {
     "source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes "
