@@ -215,7 +215,9 @@ int32_t ndt2d_batch_align(ndt2d_batch* b, const float* tx, const float* ty, cons
                           const float* sx, const float* sy, const uint64_t* soff, const double* init,
                           size_t n_pairs, ndt2d_result* results);
 /* All pointers are device pointers (results too).  Asynchronous on `stream` (NULL = the
- * context's own stream): the results are valid once that stream is synchronised. */
+ * context's own stream): the results are valid once that stream is synchronised.  Calls on one
+ * context share its dequeue counters and pair marks, so they must be ordered with respect to each
+ * other (the same stream, or synchronised streams); use one context per concurrent stream. */
 int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_ty, const uint64_t* d_toff,
                               const float* d_sx, const float* d_sy, const uint64_t* d_soff,
                               const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream);
