@@ -321,21 +321,12 @@ int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
 int32_t finish_small_run(ndt2d_handle* h) {
   if (!h->small_run) return NDT_OK;
   h->small_run = false;
-  long spins = 0;
-  bool seen = true;
-  while (!__atomic_load_n(&h->h_flag[0], __ATOMIC_ACQUIRE)) {
-    if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess) {   // drained without a flag
-      seen = __atomic_load_n(&h->h_flag[0], __ATOMIC_ACQUIRE) != 0;
-      break;
-    }
-  }
   // No stream sync once the flag is up: the kernel read the scan into registers at its start and
   // raises the flag as its last action, so the caller's source buffers are already free.
-  if (!seen) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipGetLastError());
-  }
-  h->pending = !seen;                                    // not seen: fetch_state copies dyn->state[0]
+  bool seen = false;
+  HIP_TRY(spin_until(h->stream, [&]() { return __atomic_load_n(&h->h_flag[0], __ATOMIC_ACQUIRE) != 0; }, &seen));
+  HIP_TRY(hipGetLastError());
+  h->pending = !seen;            // not seen after real syncs: the kernel has ended anyway, fetch_state copies dyn->state[0]
   h->last_parity = 0;
   return NDT_OK;
 }
@@ -346,8 +337,8 @@ int32_t finish_chunk_run(ndt2d_handle* h) {
   bool seen = false;
   HIP_TRY(chunk_run_finish(h->chunk_run, h->stream, h->h_flag, &seen));
   HIP_TRY(hipGetLastError());
-  h->pending = !seen;                                  // seen: the result is in h_state already
-  h->last_parity = 1;                                  // even chunk length: the last launch had parity 1
+  if (!seen) { set_error("the Gauss-Newton loop did not report its end"); return NDT_ERR_HIP; }
+  h->pending = false;                                  // the finishing launch wrote the result into h_state
   return NDT_OK;
 }
 

@@ -185,8 +185,8 @@ int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const floa
     bool seen = false;
     HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->h_flag, chunk, K + 1, h->call_seq, &seen));
     HIP_TRY(hipGetLastError());
-    if (seen) return NDT_OK;                           // the finishing launch wrote h_state itself
-    last_parity = 1;
+    if (!seen) { ndt::set_error("the Gauss-Newton loop did not report its end"); return NDT_ERR_HIP; }
+    return NDT_OK;                                     // the finishing launch wrote h_state itself
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[last_parity], sizeof(IterState3), hipMemcpyDeviceToHost, h->stream));

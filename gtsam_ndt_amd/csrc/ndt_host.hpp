@@ -116,36 +116,58 @@ inline hipError_t chunk_run_begin(ChunkRun& r, hipGraphExec_t exec, hipStream_t 
 // flag[0]: raised by the finishing launch; flag[1]: updates applied so far (= index of the last
 // launch that ran its prologue), written by every launch - the host's only view of progress, so
 // nothing but kernel launches goes into the stream.
+// Spin on pinned host memory until `ready()`; the stream is only consulted for errors and, after a
+// long time without progress, for a real synchronisation.  (hipStreamQuery is NOT used to decide
+// that the stream has drained: with graph replays in flight it was seen to report hipSuccess in
+// the middle of an alignment, which made an earlier version of this loop return a state a few
+// chunks short of convergence - about one alignment in a hundred with eight busy host threads,
+// tools/soak_threads.py.)  Returns hipSuccess with *ok = ready(), or the stream's error.
+template <class Ready>
+inline hipError_t spin_until(hipStream_t stream, Ready&& ready, bool* ok) {
+  unsigned long spins = 0;
+  int syncs = 0;
+  for (;;) {
+    if (ready()) { *ok = true; return hipSuccess; }
+    if ((++spins & 0xfffff) != 0) continue;
+    const hipError_t q = hipStreamQuery(stream);
+    if (q != hipSuccess && q != hipErrorNotReady) { *ok = false; return q; }
+    if ((spins >> 20) % 512 == 0) {                     // roughly every second of spinning: a real sync
+      const hipError_t es = hipStreamSynchronize(stream);
+      if (es != hipSuccess) { *ok = false; return es; }
+      if (ready()) { *ok = true; return hipSuccess; }
+      if (++syncs >= 2) { *ok = false; return hipSuccess; }   // everything enqueued has run and it is still not ready
+    }
+  }
+}
+
 inline hipError_t chunk_run_finish(ChunkRun& r, hipStream_t stream, int* flag, bool* seen) {
   auto raised = [&]() { return __atomic_load_n(&flag[0], __ATOMIC_ACQUIRE) != 0; };
   int waited = 0;
-  long spins = 0;
   hipError_t e = hipSuccess;
+  *seen = false;
   while (e == hipSuccess) {
     const int need = (waited + 1) * r.chunk - 1;         // chunk `waited` is through when progress reaches this
-    bool stuck = false;
-    while (!raised() && __atomic_load_n(&flag[1], __ATOMIC_ACQUIRE) < need) {
-      if ((++spins & 0xfffff) == 0 && hipStreamQuery(stream) == hipSuccess) { stuck = true; break; }   // stream drained
-    }
-    if (raised() || stuck) break;
+    bool ok = false;
+    e = spin_until(stream, [&]() { return raised() || __atomic_load_n(&flag[1], __ATOMIC_ACQUIRE) >= need; }, &ok);
+    if (e != hipSuccess || raised()) break;
+    // ok == false: the stream is idle and the progress counter did not move - feed it anyway; the
+    // launch cap below ends a loop that can never finish
     ++waited;
-    if ((r.launched - 1) * r.chunk > r.max_launches) break;   // not reached: the iteration cap sets done
+    if ((r.launched - 1) * r.chunk > r.max_launches + 2 * r.chunk) { e = hipErrorLaunchFailure; break; }
     e = hipGraphLaunch(r.exec, stream);
     ++r.launched;
   }
-  if (e != hipSuccess || !raised()) {
-    const hipError_t es = hipStreamSynchronize(stream);
-    if (e == hipSuccess) e = es;
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(stream);
   } else if (r.drain) {
     // flag[2]: raised by the first launch past the end - the finishing launch (whose other workgroups
     // may still have had point loads in flight when the flag went up) is complete by then, and it left
-    // n = 0 behind, so no later launch touches the source arrays.  Falls back to the stream's end.
-    spins = 0;
-    while (__atomic_load_n(&flag[2], __ATOMIC_ACQUIRE) != r.seq) {
-      if ((++spins & 0xffff) == 0 && hipStreamQuery(stream) == hipSuccess) break;
-    }
+    // n = 0 behind, so no later launch touches the source arrays.
+    bool ok = false;
+    e = spin_until(stream, [&]() { return __atomic_load_n(&flag[2], __ATOMIC_ACQUIRE) == r.seq; }, &ok);
+    if (e == hipSuccess && !ok) e = hipStreamSynchronize(stream);   // no launch past the end was enqueued
   }
-  *seen = raised();
+  *seen = e == hipSuccess && raised();
   r.active = false;
   return e;
 }
