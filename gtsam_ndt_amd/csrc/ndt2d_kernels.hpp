@@ -77,7 +77,7 @@ struct IterState {
   int status;
   int done;
   int have_partials;
-  int pad;
+  int pad;           // index of the launch that wrote this state (what the host sees as progress)
 };
 
 // Device context, split by who writes it so that the read-only parts can be fetched with
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
 
   // ---- batch 1 of loads: previous state (scalar), partial rows (vector), first point
   const double ps_pose0 = prev->pose[0], ps_pose1 = prev->pose[1], ps_pose2 = prev->pose[2];
-  const int ps_iter = prev->iter, ps_done = prev->done, ps_have = prev->have_partials;
+  const int ps_iter = prev->iter, ps_done = prev->done, ps_have = prev->have_partials, ps_launch = prev->pad;
   const SolveParams prm = st->prm;       // read-only: scalar loads, all in this first batch
   const GridDev G = st->grid;
   const int n = call->n;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
   asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.rec),
                "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations), "s"(prm.eps_trans),
                "s"(prm.eps_rot), "s"(prm.step_max_trans), "s"(prm.step_max_rot), "s"(prm.step_scale), "s"(ps_pose0), "s"(ps_pose1),
-               "s"(ps_pose2), "s"(ps_iter), "s"(ps_done), "s"(ps_have), "s"(fixed_iterations), "s"(host_state),
+               "s"(ps_pose2), "s"(ps_iter), "s"(ps_done), "s"(ps_have), "s"(ps_launch), "s"(fixed_iterations), "s"(host_state),
                "s"(host_flag));
   const int stride = kMaxBlocks * THREADS;
   int i = blockIdx.x * THREADS + tid;
@@ -718,16 +718,17 @@ __global__ __launch_bounds__(THREADS) void k_iterate(const AlignStatic* __restri
       o.status = status;
       o.done = done ? 1 : 0;
       o.have_partials = 1;
-      o.pad = 0;
+      o.pad = ps_launch + 1;
       *cur = o;
       if (host_flag) {                   // tell the host directly
-        if (done) {                      // state first, then the flag
+        if (done) {                      // state and this launch's number first, then the flag
           *host_state = o;
+          __hip_atomic_store(host_flag + 1, ps_launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           const_cast<AlignCall*>(call)->n = 0;     // the launches enqueued past the end load no points
           __threadfence_system();
           __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {                         // progress: which launch this is
-          __hip_atomic_store(host_flag + 1, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(host_flag + 1, ps_launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }

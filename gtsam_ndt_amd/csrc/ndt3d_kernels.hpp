@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
   double pose[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) pose[j] = prev->pose[j];
-  const int ps_iter = prev->iter, ps_done = prev->done, ps_have = prev->have_partials;
+  const int ps_iter = prev->iter, ps_done = prev->done, ps_have = prev->have_partials, ps_launch = prev->pad;
   const SolveParams prm = st->prm;
   const Grid3Dev G = st->grid;
   const int n = call->n;
@@ -426,17 +426,18 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
         for (int j = 0; j < 21; ++j) o->H[j] = s_red[j];
         o->score = score;
         o->n_hit = n_hit; o->iter = iter; o->status = status;
-        o->done = done ? 1 : 0; o->have_partials = 1; o->pad = 0;
+        o->done = done ? 1 : 0; o->have_partials = 1; o->pad = ps_launch + 1;   // index of this launch
       };
       store(cur);
       if (host_flag) {                   // tell the host directly
-        if (done) {                      // state first, then the flag
+        if (done) {                      // state and this launch's number first, then the flag
           store(host_state);
+          __hip_atomic_store(host_flag + 1, ps_launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           const_cast<AlignCall3*>(call)->n = 0;    // the launches enqueued past the end load no points
           __threadfence_system();
           __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {                         // progress: which launch this is
-          __hip_atomic_store(host_flag + 1, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(host_flag + 1, ps_launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }

@@ -163,9 +163,16 @@ inline hipError_t chunk_run_finish(ChunkRun& r, hipStream_t stream, int* flag, b
     // flag[2]: raised by the first launch past the end - the finishing launch (whose other workgroups
     // may still have had point loads in flight when the flag went up) is complete by then, and it left
     // n = 0 behind, so no later launch touches the source arrays.
-    bool ok = false;
-    e = spin_until(stream, [&]() { return __atomic_load_n(&flag[2], __ATOMIC_ACQUIRE) == r.seq; }, &ok);
-    if (e == hipSuccess && !ok) e = hipStreamSynchronize(stream);   // no launch past the end was enqueued
+    // flag[1] now holds the finishing launch's index: if it was the last launch enqueued there is
+    // nothing behind it to raise flag[2], and the stream's end is what to wait for.
+    const int last = __atomic_load_n(&flag[1], __ATOMIC_ACQUIRE);
+    if (r.launched * r.chunk - 1 > last) {
+      bool ok = false;
+      e = spin_until(stream, [&]() { return __atomic_load_n(&flag[2], __ATOMIC_ACQUIRE) == r.seq; }, &ok);
+      if (e == hipSuccess && !ok) e = hipStreamSynchronize(stream);
+    } else {
+      e = hipStreamSynchronize(stream);
+    }
   }
   *seen = e == hipSuccess && raised();
   r.active = false;
