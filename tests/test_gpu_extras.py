@@ -170,3 +170,29 @@ def test_short_scan_kernel_equals_launch_per_iteration_path(gpu_lib, monkeypatch
         assert a.status == r32["status"] == r64["status"]
         assert np.abs(np.array(a.pose) - np.array(r32["pose"])).max() < 1e-6
         assert np.abs(np.array(a.pose) - np.array(r64["pose"])).max() < 5e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"NDT_DEBUG_NO_GRAPH": "1"}, {"NDT_DEBUG_CHUNK": "2"}, {"NDT_DEBUG_CHUNK": "64"}])
+def test_launch_chain_drivers_agree(gpu_lib, monkeypatch, env):
+    """The converged-mode loop gives the same result however the host feeds it: plain stream
+    launches with a poll per chunk, or graph replays of 2, 8 (default) or 64 launches."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(2, n_tgt=30000, n_src=30000)
+    sx, sy = torch.from_numpy(d["sx"]).cuda(), torch.from_numpy(d["sy"]).cuda()
+    with NdtMatcher2D() as m:
+        m.set_target(d["tx"], d["ty"])
+        ref = m.align(sx, sy, d["init"])
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with NdtMatcher2D() as m:
+        m.set_target(d["tx"], d["ty"])
+        for src in ((sx, sy), (d["sx"], d["sy"])):
+            for _ in range(3):
+                r = m.align(*src, d["init"])
+                assert r.status == ref.status and r.iterations == ref.iterations
+                assert r.pose == ref.pose and np.array_equal(r.H, ref.H)
+        m.align_async(sx, sy, d["init"])
+        r = m.finish()
+        assert r.pose == ref.pose and r.iterations == ref.iterations
