@@ -95,3 +95,44 @@ def test_gpu_incremental_submap_full_size(gpu_lib):
         inc = m.grid()
     for u, v in zip(full, inc):
         np.testing.assert_array_equal(u, v)
+
+
+def test_oracle_is_invariant_under_whole_cell_translations():
+    """Moving the target and the pose by whole cells moves the grid with them: the cell statistics,
+    score, gradient and Hessian are unchanged (the origin is snapped to multiples of the cell size,
+    so nothing depends on where the map sits).  Exact multiples of 0.5 m in float32 keep the points
+    exactly representable."""
+    from oracle import ndt2d as o
+    d = synth.make_pair(2, n_tgt=8000, n_src=4000)
+    prm = o.NdtParams()
+    g0 = o.build_grid(d["tx"], d["ty"], prm)
+    H0, gr0, s0, n0 = o.evaluate(g0, d["sx"], d["sy"], d["pose"], prm)
+    for kx, ky in ((8, -6), (-40, 64), (1, 1)):
+        dx, dy = np.float32(0.5 * kx), np.float32(0.5 * ky)
+        tx, ty = d["tx"] + dx, d["ty"] + dy
+        exact = np.all((tx - dx) == d["tx"]) and np.all((ty - dy) == d["ty"])          # the shift was lossless
+        g1 = o.build_grid(tx, ty, prm)
+        assert (g1.W, g1.H, g1.n_valid) == (g0.W, g0.H, g0.n_valid)
+        np.testing.assert_array_equal(g1.count, g0.count)
+        pose = (d["pose"][0] + float(dx), d["pose"][1] + float(dy), d["pose"][2])
+        H1, gr1, s1, n1 = o.evaluate(g1, d["sx"], d["sy"], pose, prm)
+        assert n1 == n0
+        tol = 1e-9 if exact else 1e-4
+        assert abs(s1 - s0) <= tol * s0 and np.abs(H1 - H0).max() <= tol * np.abs(H0).max()
+        assert np.abs(gr1 - gr0).max() <= tol * np.sqrt(np.abs(np.diag(H0)).max() * s0)
+
+
+def test_oracle_rotation_of_both_clouds_by_a_quarter_turn():
+    """A quarter turn maps the cell lattice onto itself: aligning the rotated pair from the rotated
+    initial guess ends at the rotated pose (to the convergence wobble)."""
+    from oracle import ndt2d as o
+    d = synth.make_pair(2, n_tgt=8000, n_src=8000)
+    prm = o.NdtParams()
+    r0 = o.align(o.build_grid(d["tx"], d["ty"], prm), d["sx"], d["sy"], d["init"], prm)
+    # world frame rotated by +90 degrees: (x, y) -> (-y, x); the source frame is left alone
+    tx, ty = (-d["ty"]).astype(np.float32), d["tx"].copy()
+    init = (-d["init"][1], d["init"][0], d["init"][2] + np.pi / 2)
+    r1 = o.align(o.build_grid(tx, ty, prm), d["sx"], d["sy"], init, prm)
+    assert r0["status"] == r1["status"] == o.NDT_OK
+    want = np.array([-r0["pose"][1], r0["pose"][0], o.wrap_angle(r0["pose"][2] + np.pi / 2)])
+    assert np.abs(np.array(r1["pose"]) - want).max() < 5e-4
