@@ -136,3 +136,31 @@ def test_oracle_rotation_of_both_clouds_by_a_quarter_turn():
     assert r0["status"] == r1["status"] == o.NDT_OK
     want = np.array([-r0["pose"][1], r0["pose"][0], o.wrap_angle(r0["pose"][2] + np.pi / 2)])
     assert np.abs(np.array(r1["pose"]) - want).max() < 5e-4
+
+
+@pytest.mark.gpu
+def test_gpu_whole_cell_translation_full_size(gpu_lib):
+    """Config 3 (1M-point submap) moved by whole cells: identical cell counts, the converged pose
+    moves by exactly the shift (to the float32 resolution of the larger coordinates)."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(3)
+    dx, dy = np.float32(64.0), np.float32(-32.0)                 # 128 and -64 cells of 0.5 m
+    with NdtMatcher2D() as m:
+        m.set_target(d["tx"], d["ty"])
+        c0 = m.grid()[0]
+        info0 = m.grid_info()
+        a = m.align(d["sx"], d["sy"], d["init"])
+        m.set_target(d["tx"] + dx, d["ty"] + dy)
+        c1 = m.grid()[0]
+        info1 = m.grid_info()
+        b = m.align(d["sx"], d["sy"], (d["init"][0] + 64.0, d["init"][1] - 32.0, d["init"][2]))
+    assert (info0.width, info0.height, info0.n_valid) == (info1.width, info1.height, info1.n_valid)
+    assert info1.ox - info0.ox == 64.0 and info1.oy - info0.oy == -32.0
+    lossless = np.all((d["tx"] + dx) - dx == d["tx"]) and np.all((d["ty"] + dy) - dy == d["ty"])
+    if lossless:
+        np.testing.assert_array_equal(c0, c1)
+    else:                                                        # a few points round across a cell edge
+        assert np.abs(c0.astype(np.int64) - c1.astype(np.int64)).sum() <= 2e-4 * c0.sum()
+    assert a.status == 0 == b.status
+    e = np.abs(np.array(b.pose) - (np.array(a.pose) + np.array([64.0, -32.0, 0.0])))
+    assert e[0] < 2e-4 and e[1] < 2e-4 and e[2] < 2e-5
