@@ -1,5 +1,6 @@
-// Host-side helpers shared by the C-ABI translation units: per-thread error text and the
-// HIP_TRY macro that turns a hipError_t into NDT_ERR_HIP without throwing.
+// Host-side helpers shared by the C-ABI translation units: per-thread error text, the HIP_TRY
+// macro that turns a hipError_t into NDT_ERR_HIP without throwing, launch-chain graphs and their
+// cache, and the host half of the converged-mode protocol (flags in pinned host memory).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -89,11 +90,13 @@ struct ChainGraphCache {
 };
 
 // Converged mode of the launch-chain paths: replay `exec` (an even-length chunk of launches),
-// always one chunk ahead of the one being waited for, until the finishing launch raises *flag
-// in pinned host memory (it has written its state next to it first).  No copy, no event and no
-// stream sync inside the loop; launches enqueued past the end exit on the `done` state (about
-// 1.7 us each).  Drains the stream before returning: the caller may release the source buffers.
-// *seen = false only if max_launches went by without the flag (callers then read the state back).
+// always one chunk ahead of the one being waited for, until the finishing launch raises flag[0]
+// in pinned host memory (it has written its state next to it first).  Nothing but kernel
+// launches goes into the stream: no copy, no event, no sync inside the loop; launches enqueued
+// past the end exit on the `done` state (about 1.7 us each).
+//   flag[0]  raised by the finishing launch
+//   flag[1]  index of the last launch that ran its prologue (the host's view of progress)
+//   flag[2]  call number, written by the first launch past the end: the source arrays are free
 struct ChunkRun {          // a converged-mode loop in flight (begin ... finish)
   hipGraphExec_t exec = nullptr;
   int chunk = 0, max_launches = 0, launched = 0;
@@ -112,10 +115,6 @@ inline hipError_t chunk_run_begin(ChunkRun& r, hipGraphExec_t exec, hipStream_t 
   return e;
 }
 
-// Keep one chunk ahead until the flag is raised, then drain the stream.
-// flag[0]: raised by the finishing launch; flag[1]: updates applied so far (= index of the last
-// launch that ran its prologue), written by every launch - the host's only view of progress, so
-// nothing but kernel launches goes into the stream.
 // Spin on pinned host memory until `ready()`; the stream is only consulted for errors and, after a
 // long time without progress, for a real synchronisation.  (hipStreamQuery is NOT used to decide
 // that the stream has drained: with graph replays in flight it was seen to report hipSuccess in
@@ -140,6 +139,8 @@ inline hipError_t spin_until(hipStream_t stream, Ready&& ready, bool* ok) {
   }
 }
 
+// Keep one chunk ahead until the flag is raised, then wait until the source arrays are free.
+// *seen = true on success; a loop that does not report its end is an error, never a result.
 inline hipError_t chunk_run_finish(ChunkRun& r, hipStream_t stream, int* flag, bool* seen) {
   auto raised = [&]() { return __atomic_load_n(&flag[0], __ATOMIC_ACQUIRE) != 0; };
   int waited = 0;
