@@ -2,12 +2,12 @@
 //
 // A planar lidar delivers 360 - 4000 returns per scan (BASELINE config 1: 1000).  At that size
 // one launch per iteration (k_iterate) is all launch boundary: 4.5 us per iteration of which the
-// points are 0.1 us.  With <= 8192 source points the loop fits one workgroup of 1024 threads:
-// the points stay in registers, records come from the cached global-memory grid (L1/L2 hits
-// after the first iteration), the reduction is DPP -> LDS -> wave 0 in float64 exactly as in the
-// loop-closure kernel (ndt2d_batch.hpp), and convergence is decided on the device - no launch
-// boundary, no host polling.  The finishing thread writes the state to device memory and to
-// pinned host memory, then raises the host flag.  Same per-point code and the same update rule
+// points are 0.1 us.  With <= 4096 source points the loop fits one workgroup of 256 or 1024
+// threads: the points stay in registers, records come from the cached global-memory grid (L1/L2
+// hits after the first iteration), the reduction is per-wave LDS sums -> wave 0 in float64 (the
+// loop-closure kernel's scheme, ndt2d_batch.hpp), and convergence is decided on the device - no
+// launch boundary, no host polling.  The finishing thread writes the state to device memory and
+// to pinned host memory, then raises the host flag.  Same per-point code and the same update rule
 // (gn_update) as the other two kernels.
 #pragma once
 #include "ndt2d_kernels.hpp"
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_align_small(const AlignStatic
   const GridDev G = st->grid;
   const float4* __restrict__ rec = G.rec;
 
-  // the scan, once: point u of this thread is tid + u * 1024
+  // the scan, once: point u of this thread is tid + u * kSmallThreads
   float px[kSmallPts], py[kSmallPts];
 #pragma unroll
   for (int u = 0; u < kSmallPts; ++u) {
