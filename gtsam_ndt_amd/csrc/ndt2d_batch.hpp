@@ -1,12 +1,13 @@
-// Loop-closure candidate batch (BASELINE config 4): one persistent 1024-thread workgroup per
-// CU pulls scan pairs from a queue and runs the WHOLE alignment of a pair on chip:
+// Loop-closure candidate batch (BASELINE config 4): persistent workgroups (one of 1024 threads per
+// CU for submap-sized pairs, two of 256 threads for lidar-sized ones: BatchCfg below) pull scan
+// pairs from a queue and run the WHOLE alignment of a pair on chip:
 //   - the target's NDT grid is built and kept in LDS (dense cell -> slot index table plus
 //     compact per-slot records), so the per-point cell lookup of every Gauss-Newton
 //     iteration is an LDS read ("LDS-staged cell stats", BASELINE.json north_star);
 //   - source points are streamed from HBM/L2 with coalesced SoA loads, once per iteration;
-//   - the 11 sums are reduced wave (DPP) -> LDS -> one wave, which also does the 3x3 solve,
-//     so an iteration costs three workgroup barriers and no kernel boundary, no grid
-//     barrier, no atomics on floats.
+//   - the 11 sums are reduced per wave (DPP, or through LDS in the small variant) -> LDS -> one
+//     wave, which also does the 3x3 solve, so an iteration costs three workgroup barriers and no
+//     kernel boundary, no grid barrier, no atomics on floats.
 // Same arithmetic as the single-pair path (shared device functions of ndt2d_kernels.hpp):
 // the LDS grid holds bit-identical records to k_accumulate/k_finalise.
 #pragma once
