@@ -6,7 +6,7 @@
 //     iteration is an LDS read ("LDS-staged cell stats", BASELINE.json north_star);
 //   - source points are streamed from HBM/L2 with coalesced SoA loads, once per iteration;
 //   - the 11 sums are reduced per wave (DPP, or through LDS in the small variant) -> LDS -> one
-//     wave, which also does the 3x3 solve, so an iteration costs three workgroup barriers and no
+//     wave, which also does the 3x3 solve, so an iteration costs two workgroup barriers and no
 //     kernel boundary, no grid barrier, no atomics on floats.
 // Same arithmetic as the single-pair path (shared device functions of ndt2d_kernels.hpp):
 // the LDS grid holds bit-identical records to k_accumulate/k_finalise.
@@ -505,7 +505,9 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       pose[0] = bc[0]; pose[1] = bc[1]; pose[2] = bc[2];
       const int done = __builtin_amdgcn_readfirstlane(misc[8]);
       if (done) break;
-      __syncthreads();
+      // No third barrier: the next iteration writes `red` (every wave) and bc/misc (wave 0) only
+      // after its own first barrier, which no wave passes before all have finished the reads above;
+      // wave 0 read `red` before the second barrier.
     }
     if (tid == 0)
       write_result(out, pose, &bc[3], &bc[9], bc[12], misc[9] + iter_base, (int)(bc[13] + 0.5), misc[10]);
