@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--no-latency", action="store_true",
                     help="N=1: skip the converged-mode call latency (keeps a profile's k_iterate population to the timed steps)")
     ap.add_argument("--all-configs", action="store_true",
-                    help="N=1: also time BASELINE configs 1 and 2 (single pair) and config 5 (3D) for the per-config table")
+                    help="N=1: also time config 5 (3D) and a lidar-sized loop-closure batch for the per-config table")
     ap.add_argument("--host-path", action="store_true",
                     help="N=1: also time the host-pointer entry points (PCIe-inclusive; reported beside value)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -497,8 +497,9 @@ def main():
             out["batch"] = run_batch(a, dev, dev_index, 0, 1, None, barrier)
         if a.with_3d or a.all_configs:
             out["3d"] = run_3d(a, dev, dev_index)
+        # the other single-pair configs of BASELINE.json beside the headline (parity-test cases; cheap to time)
+        out["configs_1_2"] = [single_pair_rate(dev, dev_index, c, a.steps, a.warmup) for c in (1, 2)]
         if a.all_configs:
-            out["configs_1_2"] = [single_pair_rate(dev, dev_index, c, a.steps, a.warmup) for c in (1, 2)]
             out["batch_lidar_sized"] = lidar_batch_rate(dev, dev_index)
         copy_peak = stream_copy_GBps(dev)
         out["roofline"]["stream_copy_GBps"] = round(copy_peak, 1)
