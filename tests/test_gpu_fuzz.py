@@ -136,3 +136,40 @@ def test_random_clouds_3d(gpu_lib):
                 assert abs(s - sm) <= 2e-3 * max(sm, 1e-6)
             checked += 1
     assert checked >= 12
+
+
+def test_random_clouds_three_iterations_batch_vs_single_pair(gpu_lib):
+    """Three fixed iterations with random options (Hessian form, over-relaxation, line search, step
+    limits) on random clouds: the four loop drivers - k_align_small / k_iterate behind the single-pair
+    handle, the 256- and 1024-thread variants of k_batch - must land on the same pose."""
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMatcher2D
+    rng = np.random.default_rng(424242)
+    compared = 0
+    for i, tx, ty, sx, sy, pose, kw in _cases(120, seed=777):
+        # a source that overlaps the target: a noisy subset of it, a pose near the identity
+        fin = np.flatnonzero(np.isfinite(tx) & np.isfinite(ty))
+        if fin.size < 20:
+            continue
+        pick = rng.choice(fin, size=min(len(sx), fin.size), replace=False)
+        sx = (tx[pick] + rng.normal(0, 0.02, pick.size)).astype(np.float32)
+        sy = (ty[pick] + rng.normal(0, 0.02, pick.size)).astype(np.float32)
+        pose = (float(rng.normal(0, 0.05)), float(rng.normal(0, 0.05)), float(rng.normal(0, 0.005)))
+        kw = dict(kw, fixed_iterations=3, step_scale=float(rng.choice([1.0, 2.0, 3.0])),
+                  line_search=int(rng.choice([0, 0, 2])), step_max_trans=float(rng.choice([0.5, 0.05])))
+        with NdtMatcher2D(**kw) as m:
+            info = m.set_target(tx, ty)
+            if info.n_valid == 0:
+                continue
+            a = m.align(sx, sy, pose)
+        with NdtBatch2D(**kw) as b:
+            c = b.align([(tx, ty)], [(sx, sy)], [pose])[0]
+        if c.status == L.NDT_ERR_CAPACITY:
+            continue
+        assert a.status == c.status, (i, kw, a.status, c.status)
+        if a.status in (L.NDT_OK, L.NDT_NOT_CONVERGED) and a.n_hit > 10:
+            assert a.iterations == c.iterations == 3
+            scale = max(1.0, np.abs(np.array(a.pose[:2])).max())
+            assert np.abs(np.array(a.pose) - np.array(c.pose)).max() < 2e-4 * scale, (i, kw, a.pose, c.pose)
+            compared += 1
+    assert compared >= 40
