@@ -23,6 +23,7 @@ struct ndt3d_handle {
   ndt::AlignDyn3* d_dyn = nullptr;
   ndt::AlignStatic3* h_static = nullptr;
   ndt::IterState3* h_state = nullptr;
+  unsigned long long* d_outside = nullptr;   // [1] points of the last build / update outside the extent
   int* h_flag = nullptr;              // pinned: raised by the launch that ends a converged-mode loop
   int call_seq = 0;                   // alignments enqueued so far
   ndt::ChainGraphCache graphs;
@@ -53,6 +54,64 @@ int32_t upload_static3(ndt3d_handle* h) {
   p.step_scale = h->prm.step_scale > 0.0 ? h->prm.step_scale : 1.0;
   HIP_TRY(hipMemcpyAsync(h->d_static, c, sizeof(ndt::AlignStatic3), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return NDT_OK;
+}
+
+// a2 + a3 for n points into the grid whose geometry and storage are set: binned LDS build, or
+// scattered global atomics for maps beyond the tile histogram.  merge = add to the cached sums
+// (incremental submap update) instead of starting from zero.
+int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n, bool merge,
+                    unsigned long long* h_outside) {
+  using namespace ndt;
+  Grid3Dev& g = h->grid;
+  const size_t ncell = (size_t)g.W * g.H * g.D;
+  HIP_TRY(hipMemsetAsync(h->d_outside, 0, sizeof(unsigned long long), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
+  const int ntx = (g.W + (1 << kT3x) - 1) >> kT3x, nty = (g.H + (1 << kT3y) - 1) >> kT3y, ntz = (g.D + (1 << kT3z) - 1) >> kT3z;
+  const long long ntile_ll = (long long)ntx * nty * ntz;
+  if (ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull) {
+    // binned build (ndt3d_build.hpp)
+    const int ntile = (int)ntile_ll;
+    int32_t st = ensure3(h->d_b, &h->bcap, n);
+    if (st != NDT_OK) return st;
+    const size_t tneed = 3 * (size_t)ntile + 4;
+    if (tneed > h->tile_cap) {
+      if (h->d_tiles) (void)hipFree(h->d_tiles);
+      h->d_tiles = nullptr; h->tile_cap = 0;
+      HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
+      h->tile_cap = tneed;
+    }
+    unsigned int* d_total = h->d_tiles;
+    unsigned int* d_start = h->d_tiles + ntile;
+    unsigned int* d_cursor = h->d_tiles + 2 * ntile + 1;
+    const BinGeom3 bg{g.ox, g.oy, g.oz, g.inv_c, g.W, g.H, g.D, ntx, nty, ntile};
+    size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
+    if (nb > 1024) nb = 1024;
+    HIP_TRY(hipMemsetAsync(d_total, 0, ntile * sizeof(unsigned int), h->stream));
+    hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
+                       dz, n, bg, d_total, h->d_outside);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile);
+    hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
+                       dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2]);
+    hipLaunchKernelGGL(k_tile_accumulate3, dim3(ntile), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1], h->d_b[2],
+                       d_start, g, ntx, nty, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+    HIP_TRY(hipGetLastError());
+  } else {
+    if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));
+    hipLaunchKernelGGL(k_accumulate3, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, g, h->d_outside);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_finalise3, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, g,
+                       h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+    HIP_TRY(hipGetLastError());
+  }
+  int* hc = (int*)h->h_small;
+  unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 32);
+  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h_outside) *h_outside = *ho;
+  h->n_valid = hc[0];
+  if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
   return NDT_OK;
 }
 
@@ -98,49 +157,8 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
     HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc3)));
     h->cell_capacity = want;
   }
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
-  const int ntx = (g.W + (1 << kT3x) - 1) >> kT3x, nty = (g.H + (1 << kT3y) - 1) >> kT3y, ntz = (g.D + (1 << kT3z) - 1) >> kT3z;
-  const long long ntile_ll = (long long)ntx * nty * ntz;
-  if (ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull) {
-    // binned build (ndt3d_build.hpp)
-    const int ntile = (int)ntile_ll;
-    int32_t st = ensure3(h->d_b, &h->bcap, n);
-    if (st != NDT_OK) return st;
-    const size_t tneed = 3 * (size_t)ntile + 4;
-    if (tneed > h->tile_cap) {
-      if (h->d_tiles) (void)hipFree(h->d_tiles);
-      h->d_tiles = nullptr; h->tile_cap = 0;
-      HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
-      h->tile_cap = tneed;
-    }
-    unsigned int* d_total = h->d_tiles;
-    unsigned int* d_start = h->d_tiles + ntile;
-    unsigned int* d_cursor = h->d_tiles + 2 * ntile + 1;
-    const BinGeom3 bg{g.ox, g.oy, g.oz, g.inv_c, g.W, g.H, g.D, ntx, nty, ntile};
-    size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
-    if (nb > 1024) nb = 1024;
-    HIP_TRY(hipMemsetAsync(d_total, 0, ntile * sizeof(unsigned int), h->stream));
-    hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
-                       dz, n, bg, d_total);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile);
-    hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
-                       dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2]);
-    hipLaunchKernelGGL(k_tile_accumulate3, dim3(ntile), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1], h->d_b[2],
-                       d_start, g, ntx, nty, h->prm.min_points, h->prm.eig_ratio, h->d_counters);
-    HIP_TRY(hipGetLastError());
-  } else {
-    HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));
-    hipLaunchKernelGGL(k_accumulate3, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, g);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_finalise3, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, g,
-                       h->prm.min_points, h->prm.eig_ratio, h->d_counters);
-    HIP_TRY(hipGetLastError());
-  }
-  int* hc = (int*)h->h_small;
-  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  h->n_valid = hc[0];
-  if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+  const int32_t as = accumulate3(h, dx, dy, dz, n, /*merge=*/false, nullptr);
+  if (as != NDT_OK) return as;
   h->has_target = true;
   return upload_static3(h);
 }
@@ -233,6 +251,7 @@ int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** ou
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipMalloc((void**)&h->d_bounds, 32) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_counters, 2 * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_outside, sizeof(unsigned long long)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_static, sizeof(ndt::AlignStatic3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_call, sizeof(ndt::AlignCall3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_dyn, sizeof(ndt::AlignDyn3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
@@ -251,7 +270,7 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->graphs.clear();
-  void* dev[] = {h->d_bounds, h->d_counters, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
+  void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
                  h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag};
@@ -259,6 +278,21 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return NDT_OK;
+}
+
+int32_t ndt3d_add_target_points(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n, size_t* n_outside) {
+  if (!h || !x || !y || !z || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = ensure3(h->d_t, &h->tcap, n);
+  if (st != NDT_OK) return st;
+  const float* src[3] = {x, y, z};
+  for (int a = 0; a < 3; ++a) HIP_TRY(hipMemcpyAsync(h->d_t[a], src[a], n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  unsigned long long outside = 0;
+  const int32_t fs = accumulate3(h, h->d_t[0], h->d_t[1], h->d_t[2], n, /*merge=*/true, &outside);
+  if (n_outside) *n_outside = (size_t)outside;
+  if (fs != NDT_OK) { h->has_target = false; return fs; }
+  return NDT_OK;          // geometry, storage and parameters are unchanged: the device context stays as it is
 }
 
 int32_t ndt3d_set_target_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n, void* stream) {

@@ -28,19 +28,23 @@ __device__ __forceinline__ int tile_of3(const BinGeom3& g, float px, float py, f
 
 __global__ __launch_bounds__(kBinThreads) void k_tile_count3(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ z, size_t n, BinGeom3 g,
-                                                              unsigned int* __restrict__ tile_total) {
+                                                              unsigned int* __restrict__ tile_total,
+                                                              unsigned long long* __restrict__ n_outside) {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_hist[];
   for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) s_hist[t] = 0u;
   __syncthreads();
+  unsigned int outside = 0;
   for (size_t i = (size_t)blockIdx.x * kBinThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kBinThreads) {
     const int t = tile_of3(g, x[i], y[i], z[i]);
     if (t >= 0) atomicAdd(&s_hist[t], 1u);
+    else outside++;
   }
   __syncthreads();
   for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) {
     const unsigned int c = s_hist[t];
     if (c) atomicAdd(&tile_total[t], c);
   }
+  if (n_outside && outside) atomicAdd(n_outside, (unsigned long long)outside);
 }
 
 __global__ __launch_bounds__(kBinThreads) void k_tile_scatter3(const float* __restrict__ x, const float* __restrict__ y,
@@ -92,16 +96,22 @@ __device__ __forceinline__ bool finalise_sums3(const CellAcc3& c, double cx, dou
 __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* __restrict__ bx, const float* __restrict__ by,
                                                                    const float* __restrict__ bz,
                                                                    const unsigned int* __restrict__ tile_start, Grid3Dev g,
-                                                                   int ntx, int nty, int min_points, double eig_ratio,
-                                                                   int* __restrict__ counters) {
+                                                                   int ntx, int nty, int merge, int min_points,
+                                                                   double eig_ratio, int* __restrict__ counters) {
   __shared__ unsigned int s_n[kTile3Cells];
   __shared__ unsigned long long s_sum[9][kTile3Cells];
   const int tile = blockIdx.x;
   const int tx0 = (tile % ntx) << kT3x, ty0 = ((tile / ntx) % nty) << kT3y, tz0 = (tile / (ntx * nty)) << kT3z;
+  // init: zeros, or the cached sums of this tile's voxels (merge = incremental submap update)
   for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
-    s_n[c] = 0u;
+    const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
+    CellAcc3 a = {};
+    if (merge && ix < g.W && iy < g.H && iz < g.D) a = g.acc[((size_t)iz * g.H + iy) * g.W + ix];
+    s_n[c] = a.n;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) s_sum[j][c] = 0ull;
+    for (int j = 0; j < 3; ++j) s_sum[j][c] = (unsigned long long)a.s[j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s_sum[3 + j][c] = (unsigned long long)a.ss[j];
   }
   __syncthreads();
   const unsigned int p0 = tile_start[tile], p1 = tile_start[tile + 1];

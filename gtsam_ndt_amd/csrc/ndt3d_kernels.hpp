@@ -95,11 +95,13 @@ __global__ __launch_bounds__(kBlock) void k_bounds3(const float* __restrict__ x,
 
 // ---------------------------------------------------------------------------- accumulate
 __global__ __launch_bounds__(kBlock) void k_accumulate3(const float* __restrict__ x, const float* __restrict__ y,
-                                                         const float* __restrict__ z, size_t n, Grid3Dev g) {
+                                                         const float* __restrict__ z, size_t n, Grid3Dev g,
+                                                         unsigned long long* __restrict__ n_outside) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const float px = x[i], py = y[i], pz = z[i];
     const float fx = (px - g.ox) * g.inv_c, fy = (py - g.oy) * g.inv_c, fz = (pz - g.oz) * g.inv_c;
     const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H) & (fz >= 0.f) & (fz < (float)g.D);
+    if (!in && n_outside) atomicAdd(n_outside, 1ull);
     if (in) {
       const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
       const int ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);

@@ -449,6 +449,14 @@ class NdtMatcher3D:
                 "ndt3d_set_target")
         return self.grid_info()
 
+    def add_target_points(self, x, y, z) -> int:
+        """Merge more points into the cached voxel grid; returns how many fell outside its extent."""
+        x, y, z = _host_f32(x), _host_f32(y), _host_f32(z)
+        out = C.c_size_t(0)
+        L.check(self._lib.ndt3d_add_target_points(self._h, x.ctypes.data, y.ctypes.data, z.ctypes.data, x.size,
+                                                  C.byref(out)), "ndt3d_add_target_points")
+        return int(out.value)
+
     def grid_info(self) -> L.GridInfo3D:
         info = L.GridInfo3D()
         L.check(self._lib.ndt3d_get_grid_info(self._h, C.byref(info)), "ndt3d_get_grid_info")

@@ -282,6 +282,10 @@ void ndt3d_default_params(ndt3d_params* p);   /* cell 1.0 m, min_points 5, step_
 int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** out);
 int32_t ndt3d_destroy(ndt3d_handle* h);
 int32_t ndt3d_set_target(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n);
+/* Incremental submap update, as ndt2d_add_target_points: bins n more points into the cached voxel
+ * grid's exact sums and re-finalises; points outside the cached extent are counted and ignored. */
+int32_t ndt3d_add_target_points(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n,
+                                size_t* n_outside);
 /* device arrays; `stream` = the stream that produced them (NULL: already complete) */
 int32_t ndt3d_set_target_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n,
                              void* stream);

@@ -97,3 +97,27 @@ def test_set_target3d_from_device_arrays(gpu_lib, small):
         assert (ia.width, ia.height, ia.depth, ia.n_valid) == (ib.width, ib.height, ib.depth, ib.n_valid)
         for u, v in zip(a.grid(), b.grid()):
             np.testing.assert_array_equal(u, v)
+
+
+def test_incremental_target3d_equals_rebuild(gpu_lib, small):
+    """ndt3d_add_target_points: the voxel grid built in pieces is bit for bit the one-shot grid (exact
+    integer sums), points outside the cached extent are counted and ignored."""
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    d, prm, g = small
+    n = len(d["tx"])
+    ext = np.unique([f(d[k]) for k in ("tx", "ty", "tz") for f in (np.argmin, np.argmax)])
+    rest = np.setdiff1d(np.arange(n), ext)
+    with NdtMatcher3D() as m:
+        m.set_target(d["tx"], d["ty"], d["tz"])
+        full = m.grid()
+        info_full = m.grid_info()
+        m.set_target(d["tx"][ext], d["ty"][ext], d["tz"][ext])          # fixes the extent
+        for part in np.array_split(rest, 4):
+            assert m.add_target_points(d["tx"][part], d["ty"][part], d["tz"][part]) == 0
+        assert m.add_target_points(d["tx"][:7] + np.float32(1e4), d["ty"][:7], d["tz"][:7]) == 7
+        inc = m.grid()
+        assert m.grid_info().n_valid == info_full.n_valid == g.n_valid
+        r = m.align(d["sx"], d["sy"], d["sz"], d["init"])
+    for u, v in zip(full, inc):
+        np.testing.assert_array_equal(u, v)
+    assert r.status == 0
