@@ -11,7 +11,9 @@
 #ifndef NDT_MATCHER_HIP_HPP_
 #define NDT_MATCHER_HIP_HPP_
 
+#include <algorithm>
 #include <array>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -274,6 +276,81 @@ class NdtMultiHip {
 
  private:
   ndt2d_multi* m_ = nullptr;
+};
+
+// ---- 3D (SE(3), BASELINE config 5): the same shape over the ndt3d_* entry points ----------------
+struct Pose3 {           // translation and roll/pitch/yaw of R = Rz(yaw) Ry(pitch) Rx(roll)
+  double x = 0.0, y = 0.0, z = 0.0, roll = 0.0, pitch = 0.0, yaw = 0.0;
+};
+
+struct MatchResult3 {
+  Pose3 pose;
+  std::array<double, 36> information{};  // row-major 6x6 Gauss-Newton Hessian of -score (tx ty tz roll pitch yaw)
+  std::array<double, 36> covariance{};   // its inverse (zero if singular)
+  double score = 0.0;
+  int iterations = 0, n_hit = 0, status = NDT_OK;
+  bool converged() const { return status == NDT_OK; }
+};
+
+// symmetric positive definite 6x6 inverse by Gauss-Jordan with partial pivoting; false if singular
+inline bool invert6(const double* H, double* C) {
+  double a[6][12];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) { a[i][j] = H[6 * i + j]; a[i][6 + j] = i == j ? 1.0 : 0.0; }
+  for (int c = 0; c < 6; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 6; ++r) if (std::abs(a[r][c]) > std::abs(a[p][c])) p = r;
+    if (!(std::abs(a[p][c]) > 0.0)) { for (int i = 0; i < 36; ++i) C[i] = 0.0; return false; }
+    if (p != c) for (int j = 0; j < 12; ++j) std::swap(a[p][j], a[c][j]);
+    const double inv = 1.0 / a[c][c];
+    for (int j = 0; j < 12; ++j) a[c][j] *= inv;
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      const double f = a[r][c];
+      if (f != 0.0) for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) C[6 * i + j] = a[i][6 + j];
+  return true;
+}
+
+class NdtMatcherHip3 {
+ public:
+  static ndt3d_params defaultParams() { ndt3d_params p; ndt3d_default_params(&p); return p; }
+
+  explicit NdtMatcherHip3(const ndt3d_params& params = defaultParams(), int device = 0) {
+    const int32_t st = ndt3d_create(&params, device, &h_);
+    if (st != NDT_OK) throw NdtError(st, "ndt3d_create");
+  }
+  ~NdtMatcherHip3() { ndt3d_destroy(h_); }
+  NdtMatcherHip3(const NdtMatcherHip3&) = delete;
+  NdtMatcherHip3& operator=(const NdtMatcherHip3&) = delete;
+
+  void setTarget(const float* x, const float* y, const float* z, size_t n) { check(ndt3d_set_target(h_, x, y, z, n), "ndt3d_set_target"); }
+  // incremental voxel-grid update: returns the number of points outside the cached extent
+  size_t addTargetPoints(const float* x, const float* y, const float* z, size_t n) {
+    size_t outside = 0;
+    check(ndt3d_add_target_points(h_, x, y, z, n, &outside), "ndt3d_add_target_points");
+    return outside;
+  }
+  ndt3d_grid_info gridInfo() const { ndt3d_grid_info g; check(ndt3d_get_grid_info(h_, &g), "ndt3d_get_grid_info"); return g; }
+
+  MatchResult3 align(const float* sx, const float* sy, const float* sz, size_t n, const Pose3& guess = Pose3()) {
+    const double init[6] = {guess.x, guess.y, guess.z, guess.roll, guess.pitch, guess.yaw};
+    ndt3d_result r;
+    check(ndt3d_align(h_, sx, sy, sz, n, init, &r), "ndt3d_align");
+    MatchResult3 m;
+    m.pose = {r.pose[0], r.pose[1], r.pose[2], r.pose[3], r.pose[4], r.pose[5]};
+    for (int i = 0; i < 36; ++i) m.information[i] = r.H[i];
+    invert6(r.H, m.covariance.data());
+    m.score = r.score; m.iterations = r.iterations; m.n_hit = r.n_hit; m.status = r.status;
+    return m;
+  }
+  ndt3d_handle* raw() { return h_; }
+
+ private:
+  static void check(int32_t st, const char* where) { if (st < 0) throw NdtError(st, where); }
+  ndt3d_handle* h_ = nullptr;
 };
 
 }  // namespace ndt

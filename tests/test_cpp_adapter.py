@@ -69,3 +69,8 @@ def test_adapter_matches_oracle(exe, tmp_path, gpu_lib):
     got = [float(v) for v in lines["pyramid"][:3]]
     assert got == list(rp.pose) and int(lines["pyramid"][3]) == rp.iterations and int(lines["pyramid"][4]) == rp.status
     assert abs(float(lines["infocov"][0]) - 1.0) < 1e-6
+    # the 3D adapter on a self-generated room: the known motion (0.20, -0.15, 0.05, yaw 0.02) comes back
+    p3 = np.array([float(v) for v in lines["three_d"][:6]])
+    assert int(lines["three_d"][7]) in (0, 1)
+    assert np.abs(p3 - np.array([0.20, -0.15, 0.05, 0.0, 0.0, 0.02])).max() < 2e-2, p3
+    assert abs(float(lines["three_d"][8]) - 1.0) < 1e-6
