@@ -561,3 +561,43 @@ class NdtPyramid2D:
             pose = r.pose
         r.iterations = total
         return r
+
+
+class NdtPyramid3D:
+    """Coarse-to-fine 3D alignment: one NdtMatcher3D per level (cells 4c and 2c with a stronger
+    eigenvalue clamp and loose stops, then the caller's parameters), each level started from the
+    previous level's pose - the 3D counterpart of NdtPyramid2D."""
+
+    def __init__(self, device: int = 0, levels=PYRAMID_LEVELS, **overrides):
+        fine = default_params3d(**overrides)
+        self.levels = []
+        for mult, er in levels:
+            kw = dict(overrides)
+            kw.update(cell_size=fine.cell_size * mult, eig_ratio=er, eps_trans=1e-3, eps_rot=1e-4,
+                      max_iterations=30, fixed_iterations=0, step_max_trans=fine.step_max_trans * mult)
+            self.levels.append(NdtMatcher3D(device, **kw))
+        self.levels.append(NdtMatcher3D(device, **overrides))
+
+    def close(self):
+        for m in self.levels:
+            m.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_target(self, x, y, z):
+        return [m.set_target(x, y, z) for m in self.levels][-1]
+
+    def align(self, sx, sy, sz, init_pose=(0.0,) * 6):
+        pose, total, r = tuple(init_pose), 0, None
+        for m in self.levels:
+            r = m.align(sx, sy, sz, pose)
+            total += r.iterations
+            if r.status not in (L.NDT_OK, L.NDT_NOT_CONVERGED):
+                break
+            pose = r.pose
+        r.iterations = total
+        return r

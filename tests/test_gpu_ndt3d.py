@@ -121,3 +121,21 @@ def test_incremental_target3d_equals_rebuild(gpu_lib, small):
     for u, v in zip(full, inc):
         np.testing.assert_array_equal(u, v)
     assert r.status == 0
+
+
+def test_pyramid3d_widens_the_basin(gpu_lib):
+    """From 1.2 m / 0.08 rad off, the 1 m grid alone ends elsewhere; 4 m -> 2 m -> 1 m recovers the pose."""
+    from gtsam_ndt_amd.matcher import NdtMatcher3D, NdtPyramid3D
+    d = synth3d.make_pair3d(n_elev=32, n_azim=1024)
+    true = np.array(d["pose"])
+    init = tuple(true + np.array([1.2, -0.9, 0.15, 0.0, 0.0, 0.08]))
+    with NdtPyramid3D() as p:
+        p.set_target(d["tx"], d["ty"], d["tz"])
+        r = p.align(d["sx"], d["sy"], d["sz"], init)
+    with NdtMatcher3D() as m:
+        m.set_target(d["tx"], d["ty"], d["tz"])
+        flat = m.align(d["sx"], d["sy"], d["sz"], init)
+    e = np.abs(np.array(r.pose) - true)
+    assert r.status == 0 and e[:3].max() < 0.03 and e[3:].max() < 5e-3, (r.pose, d["pose"])
+    ef = np.abs(np.array(flat.pose) - true)
+    assert ef[:3].max() > e[:3].max()
