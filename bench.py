@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--batch-points", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="N=1: skip the extra loop-closure batch figure")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="N=1: only the timed config-3 steps and the config-4 batch (a profile's kernel populations "
+                         "are then exactly the timed launches); implies --no-latency")
     ap.add_argument("--no-latency", action="store_true",
                     help="N=1: skip the converged-mode call latency (keeps a profile's k_iterate population to the timed steps)")
     ap.add_argument("--all-configs", action="store_true",
@@ -66,7 +69,10 @@ def parse():
                          "gather runs over gloo on host copies (RCCL refuses two ranks on one device)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N>1 code path (process group + all_gather) even with one rank")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.headline_only:
+        a.no_latency = True
+    return a
 
 
 def hip_events_ms(stream_ptr: int, fn):
@@ -498,7 +504,8 @@ def main():
         if a.with_3d or a.all_configs:
             out["3d"] = run_3d(a, dev, dev_index)
         # the other single-pair configs of BASELINE.json beside the headline (parity-test cases; cheap to time)
-        out["configs_1_2"] = [single_pair_rate(dev, dev_index, c, a.steps, a.warmup) for c in (1, 2)]
+        if not a.headline_only:
+            out["configs_1_2"] = [single_pair_rate(dev, dev_index, c, a.steps, a.warmup) for c in (1, 2)]
         if a.all_configs:
             out["batch_lidar_sized"] = lidar_batch_rate(dev, dev_index)
         copy_peak = stream_copy_GBps(dev)

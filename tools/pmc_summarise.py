@@ -73,7 +73,7 @@ ba = traffic("BatchCfg<1024")          # the 1024-thread variant does the config
 i3 = traffic("k_iterate3")
 summary = {
     "source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes "
-              "(--kernel-trace only) of `bench.py --no-cpu-baseline --no-latency --with-3d --steps 10 --warmup 2` on one MI355X",
+              "(--kernel-trace only) of `bench.py --no-cpu-baseline --headline-only --with-3d --steps 10 --warmup 2` on one MI355X",
     "units": "counter values are KiB; FETCH_SIZE scaled by the factor measured on the 1 GiB calibration reads "
              f"(tools/pmc_calib.hip): {fetch_scale:.4f} (MI355X_MICROARCH.md: gfx950 reports half of streamed "
              "reads); WRITE_SIZE taken as is (calibration: 1 GiB of stores reads 1048576 KiB)",

@@ -9,7 +9,7 @@ set -eo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/prof"
 rm -rf "$OUT"; mkdir -p "$OUT"
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-latency --with-3d --steps 10 --warmup 2"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --headline-only --with-3d --steps 10 --warmup 2"
 cd /tmp && export TMPDIR=/tmp
 hipcc --offload-arch=gfx950 -O3 -o "$OUT/pmc_calib" "$ROOT/tools/pmc_calib.hip"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- $BENCH > "$OUT/bench_stats.log" 2>&1
