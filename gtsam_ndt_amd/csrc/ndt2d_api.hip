@@ -54,8 +54,11 @@ struct ndt2d_handle {
   hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
   ChunkRun chunk_run;                      // converged-mode loop begun by ndt2d_align_dev_async
   int call_seq = 0;                        // alignments enqueued so far (never 0 once one has run)
+  bool wide = false;                       // this alignment's k_iterate launches use 1024-thread workgroups
   bool small_run = false;                  // a k_align_small launch whose flag has not been waited for
   bool use_small = true;                   // NDT_DEBUG_NO_SMALL=1: short scans go through k_iterate too
+  bool use_wide = true;                    // NDT_DEBUG_NO_WIDE=1: 256-thread workgroups whatever the scan size
+  size_t wide_threshold = 300000;          // scan size from which they are used (NDT_WIDE_THRESHOLD overrides)
   bool use_graph = true;
   int check_every = 8;                     // converged mode: launches per chunk (NDT_DEBUG_CHUNK overrides)
 };
@@ -67,6 +70,10 @@ constexpr size_t kMaxCells = (size_t)1 << 27;
 #define NDT_ITER_THREADS 256
 #endif
 constexpr int kIterThreads = NDT_ITER_THREADS;   // workgroup size of k_iterate (256 workgroups always)
+// Scans of a few hundred thousand points and more are no longer latency-bound per launch but short
+// of loads in flight (15+ dependent gather rounds per thread at 256 threads): 1024-thread
+// workgroups (four waves per SIMD) hide that latency.  Measured at 1M source points: see DESIGN 5.1.
+constexpr int kIterThreadsWide = 1024;
 
 int32_t check_params(const ndt2d_params* p) {
   if (!p) return NDT_ERR_INVALID_ARG;
@@ -287,9 +294,15 @@ int32_t upload_static(ndt2d_handle* h) {
 
 void launch_iter(ndt2d_handle* h, int blocks, int k) {
   const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON, four = h->prm.overlap_grids == 4;
-#define NDT_LAUNCH_ITER(MODE, NG) \
-  hipLaunchKernelGGL((k_iterate<MODE, 0, kIterThreads, NG>), dim3(blocks), dim3(kIterThreads), 0, h->stream, \
-                     h->d_static, h->d_call, h->d_dyn, k & 1)
+#define NDT_LAUNCH_ITER(MODE, NG)                                                                                       \
+  do {                                                                                                                  \
+    if (h->wide)                                                                                                        \
+      hipLaunchKernelGGL((k_iterate<MODE, 0, kIterThreadsWide, NG>), dim3(blocks), dim3(kIterThreadsWide), 0, h->stream, \
+                         h->d_static, h->d_call, h->d_dyn, k & 1);                                                      \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_iterate<MODE, 0, kIterThreads, NG>), dim3(blocks), dim3(kIterThreads), 0, h->stream,        \
+                         h->d_static, h->d_call, h->d_dyn, k & 1);                                                      \
+  } while (0)
   if (newton && four) NDT_LAUNCH_ITER(1, 4);
   else if (newton) NDT_LAUNCH_ITER(1, 1);
   else if (four) NDT_LAUNCH_ITER(0, 4);
@@ -307,10 +320,15 @@ void drop_graph(ndt2d_handle* h) {
 // serves every target and every source.
 int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
   const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON, four = h->prm.overlap_grids == 4;
-  const void* func = newton ? (four ? (const void*)&k_iterate<1, 0, kIterThreads, 4> : (const void*)&k_iterate<1, 0, kIterThreads, 1>)
-                            : (four ? (const void*)&k_iterate<0, 0, kIterThreads, 4> : (const void*)&k_iterate<0, 0, kIterThreads, 1>);
-  HIP_TRY(h->graphs.get(func, dim3(blocks), dim3(kIterThreads), (void*)h->d_static, (void*)h->d_call, (void*)h->d_dyn,
-                        launches, h->prm.hessian_mode, &h->graph_exec));
+  const void* func;
+  if (h->wide)
+    func = newton ? (four ? (const void*)&k_iterate<1, 0, kIterThreadsWide, 4> : (const void*)&k_iterate<1, 0, kIterThreadsWide, 1>)
+                  : (four ? (const void*)&k_iterate<0, 0, kIterThreadsWide, 4> : (const void*)&k_iterate<0, 0, kIterThreadsWide, 1>);
+  else
+    func = newton ? (four ? (const void*)&k_iterate<1, 0, kIterThreads, 4> : (const void*)&k_iterate<1, 0, kIterThreads, 1>)
+                  : (four ? (const void*)&k_iterate<0, 0, kIterThreads, 4> : (const void*)&k_iterate<0, 0, kIterThreads, 1>);
+  HIP_TRY(h->graphs.get(func, dim3(blocks), dim3(h->wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static, (void*)h->d_call,
+                        (void*)h->d_dyn, launches, h->prm.hessian_mode | (h->wide ? 16 : 0), &h->graph_exec));
   return NDT_OK;
 }
 
@@ -358,6 +376,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
   const int fixed = fixed_override >= 0 ? fixed_override : h->prm.fixed_iterations;
   const int K = fixed > 0 ? fixed : h->prm.max_iterations;
   const int blocks = blocks_for(n);
+  h->wide = h->use_wide && n >= h->wide_threshold;
   const bool chunked = h->use_graph && check_every > 0 && fixed == 0;
   __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
   __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
@@ -545,6 +564,8 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
   { const char* e = std::getenv("NDT_DEBUG_NO_GRAPH"); h->use_graph = !(e && e[0] == '1'); }
+  { const char* e = std::getenv("NDT_DEBUG_NO_WIDE"); h->use_wide = !(e && e[0] == '1'); }
+  { const char* e = std::getenv("NDT_WIDE_THRESHOLD"); const long v = e ? std::atol(e) : 0; if (v > 0) h->wide_threshold = (size_t)v; }
   { const char* e = std::getenv("NDT_DEBUG_NO_SMALL"); h->use_small = !(e && e[0] == '1'); }
   { const char* e = std::getenv("NDT_DEBUG_CHUNK"); const int v = e ? std::atoi(e) : 0; if (v >= 2 && v <= 128) h->check_every = v; }
   { const char* e = std::getenv("NDT_DEBUG_ATOMIC_BUILD"); h->use_binned_build = !(e && e[0] == '1'); }

@@ -196,3 +196,25 @@ def test_launch_chain_drivers_agree(gpu_lib, monkeypatch, env):
         m.align_async(sx, sy, d["init"])
         r = m.finish()
         assert r.pose == ref.pose and r.iterations == ref.iterations
+
+
+@pytest.mark.gpu
+def test_wide_workgroups_for_large_scans_equal_the_narrow_ones(gpu_lib, monkeypatch):
+    """Scans of >= 300k points run k_iterate with 1024-thread workgroups (loads in flight); the
+    result is the 256-thread one up to the float32 summation order."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(3, n_src=400_000)
+    tx, ty, sx, sy = (torch.from_numpy(d[k]).cuda() for k in ("tx", "ty", "sx", "sy"))
+    res = {}
+    for off in ("0", "1"):
+        monkeypatch.setenv("NDT_DEBUG_NO_WIDE", off)
+        with NdtMatcher2D() as m:
+            m.set_target(tx, ty)
+            res[off] = (m.align(sx, sy, d["init"]), m.align(sx, sy, d["init"]))
+    for off in ("0", "1"):
+        assert res[off][0].pose == res[off][1].pose                     # deterministic
+    a, b = res["0"][0], res["1"][0]
+    assert a.status == b.status == 0 and abs(a.iterations - b.iterations) <= 1 and a.n_hit == b.n_hit
+    assert np.abs(np.array(a.pose) - np.array(b.pose)).max() < 2e-6
+    assert np.abs(np.array(a.pose) - np.array(d["pose"])).max() < 2e-3
