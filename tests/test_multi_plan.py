@@ -63,3 +63,25 @@ def test_plan_rejects_bad_arguments(ndt_lib):
     bad = np.array([0, 10, 5], dtype=np.uint64)
     with pytest.raises(NdtError):
         M.multi_plan(2, bad, toff)
+
+
+def test_plan_properties_hold_for_random_inputs(ndt_lib):
+    """Property check (hypothesis): for any sizes and shard count the plan is a monotone cover of
+    the pairs and no shard exceeds the even share by more than one pair's work."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.tuples(st.integers(0, 20000), st.integers(0, 20000)), min_size=1, max_size=200),
+           st.integers(1, 16), st.integers(0, 60))
+    def check(sizes, shards, hint):
+        toff = _offsets([a for a, _ in sizes])
+        soff = _offsets([b for _, b in sizes])
+        b = M.multi_plan(shards, toff, soff, hint).astype(np.int64)
+        assert b[0] == 0 and b[-1] == len(sizes) and np.all(np.diff(b) >= 0) and len(b) == shards + 1
+        k = hint if hint > 0 else 30
+        work = np.array([3.0 * a + k * s + 1.0 for a, s in sizes])
+        share = work.sum() / shards
+        for d in range(shards):
+            assert work[b[d]: b[d + 1]].sum() <= share + work.max() + 1e-6
+
+    check()
