@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gtsam_ndt_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "gtsam_ndt_amd", "lib")
 LIB = os.path.join(LIBDIR, "libndt_hip.so")
+SYNTH_LIB = os.path.join(LIBDIR, "libndt_synth.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "libndt_oracle.so")
 
@@ -61,24 +62,57 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_oracle(force: bool = False, verbose: bool = False) -> str | None:
-    """gcc build of oracle/ndt_oracle.c (the C restatement used as the timed CPU baseline)."""
-    src = os.path.join(ORACLE_DIR, "ndt_oracle.c")
-    if not os.path.exists(src):
-        return None
-    if not force and _newer(ORACLE_LIB, [src]):
-        return ORACLE_LIB
-    os.makedirs(os.path.dirname(ORACLE_LIB), exist_ok=True)
-    cmd = ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-o", ORACLE_LIB,
-           src, "-lm"]
+def build_synth(force: bool = False, verbose: bool = False) -> str:
+    """The device-side workload generator (include/ndt_synth.h): its own library, so the matcher
+    library carries nothing of it.  -ffp-contract=off: it must reproduce synth.py bit for bit."""
+    src = os.path.join(CSRC, "ndt_synth.hip")
+    if not force and _newer(SYNTH_LIB, [src, os.path.join(ROOT, "include", "ndt_synth.h")]):
+        return SYNTH_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off",
+           "-I", os.path.join(ROOT, "include"), "-o", SYNTH_LIB, src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=ROOT)
-    return ORACLE_LIB
+    return SYNTH_LIB
+
+
+def _cpu_tag() -> str:
+    """Short hash of this host's CPU flags: a -march=native build must not travel to another CPU."""
+    import hashlib
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = line
+                    break
+    except OSError:
+        pass
+    return hashlib.sha1(flags.encode()).hexdigest()[:10]
+
+
+def build_oracle(force: bool = False, verbose: bool = False, native: bool = False) -> str | None:
+    """gcc build of oracle/ndt_oracle.c (the C restatement; checker and timed CPU baseline).
+    native=True: a second library built with -O3 -march=native for THIS host's CPU (file name
+    carries a hash of the CPU flags), used by bench.py's cpu_baseline leg on the box it runs on."""
+    src = os.path.join(ORACLE_DIR, "ndt_oracle.c")
+    if not os.path.exists(src):
+        return None
+    out = ORACLE_LIB if not native else os.path.join(ORACLE_DIR, "_build", f"libndt_oracle_native_{_cpu_tag()}.so")
+    if not force and _newer(out, [src]):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    opt = ["-O3", "-march=native"] if native else ["-O2"]
+    cmd = ["gcc", *opt, "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-o", out, src, "-lm"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return out
 
 
 def build_all(force: bool = False, verbose: bool = False):
-    return build_hip(force, verbose), build_oracle(force, verbose)
+    return build_hip(force, verbose), build_synth(force, verbose), build_oracle(force, verbose)
 
 
 if __name__ == "__main__":
