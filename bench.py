@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--batch-points", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="N=1: skip the extra loop-closure batch figure")
+    ap.add_argument("--no-batch-4096", action="store_true", help="N=1: skip the full 4096-pair single-GPU batch figure")
     ap.add_argument("--headline-only", action="store_true",
                     help="N=1: only the timed config-3 steps and the config-4 batch (a profile's kernel populations "
                          "are then exactly the timed launches); implies --no-latency")
@@ -168,28 +169,51 @@ def load_traffic():
         return None
 
 
+def cpu_share() -> int:
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box hands a one-GPU job 16 cores of a much larger host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(d, seconds: float):
-    """The C restatement of the oracle (kind "port"), timed on this host's cores on a bounded
-    sample of the same workload: fixed-K alignments of the config-3 pair until `seconds`."""
+    """The C restatement of the oracle (kind "port"), built here with -O3 -march=native and timed
+    on this host's cores on a bounded sample of the same workload: fixed-K alignments of the
+    config-3 pair until `seconds`, single-threaded and on every core this job may use."""
     from gtsam_ndt_amd import build
     from oracle import cport, ndt2d
-    build.build_oracle()
+    lib_path = build.build_oracle(native=True)
     prm = ndt2d.NdtParams(fixed_iterations=K_GN)
     t0 = time.perf_counter()
-    g = cport.CGrid(d["tx"], d["ty"], prm)
+    g = cport.CGrid(d["tx"], d["ty"], prm, lib_path=lib_path)
     grid_s = time.perf_counter() - t0
     best = None
     runs = []
-    nthr = int(cport.load().orc_max_threads())
-    try:
-        nthr = min(nthr, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
-    # a GPU box's CPU share is 16 cores whatever the host's thread count says
-    counts = sorted({1, min(nthr, 16), nthr})
+    share = cpu_share()
+    nthr = max(1, min(int(cport.load(lib_path).orc_max_threads()), share))
+    counts = sorted({1, nthr})
     for threads in counts:
         it = 0
         n_al = 0
+        g.align(d["sx"], d["sy"], d["init"], threads=threads)          # warm the thread pool and the caches
         t0 = time.perf_counter()
         while True:
             r = g.align(d["sx"], d["sy"], d["init"], threads=threads)
@@ -201,36 +225,62 @@ def cpu_baseline(d, seconds: float):
         rate = it / el
         runs.append({"cores": threads, "value": round(rate, 1)})
         if best is None or rate > best["value"]:
-            best = {"value": rate, "unit": "iters/s", "cores": threads, "kind": "port",
+            best = {"value": round(rate, 1), "unit": "iters/s", "cores": threads, "kind": "port",
                     "sample": f"{n_al} fixed-K={K_GN} alignments of the same config-3 pair "
-                              f"({el:.1f} s of CPU work), oracle/ndt_oracle.c with {threads} thread(s); "
+                              f"({el:.1f} s of CPU work), oracle/ndt_oracle.c (gcc -O3 -march=native -fopenmp, built on this "
+                              f"host) with {threads} thread(s) of the {share} cores this job may use; "
                               f"1M-point grid build {grid_s * 1e3:.0f} ms excluded, as on the GPU"}
     g.close()
     best["runs"] = runs
     return best
 
 
-def run_batch(a, dev, dev_index, rank, world, dist, barrier):
-    """BASELINE config 4, this rank's shard: pairs_per_rank candidate pairs x batch_points,
-    all resident in HBM; a step aligns every pair (LDS grid build + 30 GN iterations each) and
-    gathers the per-pair results of all ranks (RCCL all_gather; the path's only collective)."""
-    from gtsam_ndt_amd import dist as nd, synth
+def cross_check_batch_rows(dev_index, t, rows, ppr, every: int = 64):
+    """Parity inside the bench: every `every`-th pair of this rank's shard is aligned again through the
+    single-pair path (k_iterate, its own grid build in global memory) with the same fixed K, and the
+    batch kernel's row is compared with it.  Outside the timed region."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    worst = np.zeros(3)
+    checked = 0
+    toff, soff = t["toff"].cpu().numpy(), t["soff"].cpu().numpy()
+    init = t["init"].cpu().numpy()
+    with NdtMatcher2D(device=dev_index, fixed_iterations=K_GN) as m:
+        for k in range(0, ppr, every):
+            m.set_target(t["tx"][toff[k]:toff[k + 1]], t["ty"][toff[k]:toff[k + 1]])
+            r = m.align(t["sx"][soff[k]:soff[k + 1]], t["sy"][soff[k]:soff[k + 1]], init[k])
+            assert r.status == rows[k].status == 0 and r.iterations == rows[k].iterations == K_GN
+            worst = np.maximum(worst, np.abs(np.array(r.pose) - np.array(rows[k].pose)))
+            checked += 1
+    return {"dx_m": float(worst[0]), "dy_m": float(worst[1]), "dtheta_rad": float(worst[2]), "pairs_checked": checked,
+            "note": f"every {every}th pair re-aligned through the single-pair path (k_iterate), fixed {K_GN} iterations: "
+                    "max |pose difference| between the two kernels"}
+
+
+def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=None):
+    """BASELINE config 4, this rank's shard: `ppr` candidate pairs x batch_points, generated in HBM
+    by the device twin of synth.py (bit-identical to synth.make_pair(4, k)); a step aligns every
+    pair (LDS grid build + 30 GN iterations each) and gathers the per-pair results of all ranks
+    (RCCL all_gather; the path's only collective)."""
+    from gtsam_ndt_amd import dist as nd, synth_dev
     from gtsam_ndt_amd.matcher import NdtBatch2D
-    ppr, npts = a.pairs_per_rank, a.batch_points
+    ppr = ppr or a.pairs_per_rank
+    steps = steps or a.steps
+    npts = a.batch_points
     total = ppr * world
     mine = nd.shard_range(total, rank, world)
-    pairs = [synth.make_pair(4, pair_index=k, n_tgt=npts, n_src=npts) for k in mine]
-    h = nd.pack_pairs(pairs)
-    t = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
-    truth = np.array([p["pose"] for p in pairs])
-    del pairs
+    t0 = time.perf_counter()
+    t = synth_dev.config4_batch(mine.start, len(mine), npts, npts, device=dev)
+    torch.cuda.synchronize()
+    gen_ms = 1e3 * (time.perf_counter() - t0)
+    truth = t["pose"].cpu().numpy()
     b = NdtBatch2D(device=dev_index, fixed_iterations=K_GN)
     host_ms = None
-    if dist is None and a.host_path:
+    if dist is None and a.host_path and ppr <= 512:
         # the same batch through the host-pointer entry point (pageable host arrays -> upload ->
         # kernel -> results back): the PCIe-inclusive figure DESIGN.md section 7 quotes; never `value`
         from gtsam_ndt_amd import _lib as L
         from gtsam_ndt_amd.matcher import RESULT_DOUBLES
+        h = {k: np.ascontiguousarray(v.cpu().numpy()) for k, v in t.items()}
         outh = np.zeros(ppr * RESULT_DOUBLES, dtype=np.float64)
         lat = []
         for _ in range(3):
@@ -240,7 +290,7 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
                                              h["init"].ctypes.data, ppr, outh.ctypes.data), "ndt2d_batch_align")
             lat.append(time.perf_counter() - t0)
         host_ms = 1e3 * min(lat[1:])
-    del h
+        del h
     # one explicit (non-default) stream carries the kernel, the HIP events and - through
     # torch.distributed's stream ordering - the RCCL all_gather that consumes the results
     side = torch.cuda.Stream(device=dev)
@@ -257,7 +307,7 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
         for _ in range(max(1, a.warmup)):
             allr = step()
         barrier()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
         for e0, e1 in ev:
             e0.record(side)
@@ -273,8 +323,12 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
     assert len(rows) == total and all(r.iterations == K_GN and r.status == 0 for r in rows)
     local = rows[mine.start: mine.stop]
     err = np.abs(np.array([r.pose for r in local]) - truth)      # vs the generating pose (sampling noise)
-    iters = total * K_GN * a.steps
-    launch_ms = kern_ms / a.steps
+    cross = cross_check_batch_rows(dev_index, t, local, ppr)
+    if dist is not None:
+        for k in ("dx_m", "dy_m", "dtheta_rad"):
+            cross[k] = nd.max_over_ranks(cross[k], device=dev)
+    iters = total * K_GN * steps
+    launch_ms = kern_ms / steps
     # Algorithmic HBM bytes of one pair for THIS kernel: the target once
     # (8 B/pt) + the source once per iteration (8 B/pt; 0.8 MB per pair does not fit on chip)
     # + one result row.  SURVEY.md section 8d's figure of record, 32 B per point-iteration,
@@ -284,21 +338,25 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
     streamed_pair = 3 * 8 * npts + K_GN * 8 * npts + 144          # what the kernel reads: 3 target passes
     survey_pair = 8 * npts + 24 * 10816 + K_GN * BYTES_PER_POINT_ITER * npts
     achieved = ppr * alg_pair / (launch_ms * 1e-3) / 1e9
+    traffic = load_traffic() or {}
     out = {
         "metric": METRIC, "value": round(iters / elapsed, 1), "unit": "iters/s", "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
+        "steps": steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"config4: loop-closure batch, {ppr} candidate pairs x {npts} pts per GPU "
                                f"({total} pairs total), 0.5 m cells, grid build + fixed 30 GN iterations per pair",
                    "pairs_per_gpu": ppr, "pairs_total": total, "n_target": npts, "n_source": npts,
                    "cell_size": 0.5, "gn_iterations_per_pair": K_GN, "collective": "all_gather of 144 B/pair"
-                   if world > 1 else "none (1 GPU)"},
-        "pairs_per_s": round(total * a.steps / elapsed, 1),
+                   if world > 1 else "none (1 GPU)",
+                   "generator": f"device twin of synth.make_pair(4, k), k = {mine.start}..{mine.stop - 1} on this rank "
+                                f"({gen_ms:.0f} ms incl. first-use overheads; outside the timed region)"},
+        "pairs_per_s": round(total * steps / elapsed, 1),
         "scaling_note": "weak scaling of the loop-closure batch: compare with the N=1 line's batch.value "
                         "(the N=1 line's own value is the single-pair config 3)",
         "roofline": {"bound": "hbm", "kernel": "k_batch<GN>", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": (load_traffic() or {}).get("batch_bytes_per_launch"),
+                     "traffic": traffic.get("batch_bytes_per_launch") if ppr == 512 else None,
+                     "traffic_source": traffic.get("source", "profiles/ (rocprofv3 --pmc, separate run of this command)"),
                      "algorithmic_bytes_per_launch": ppr * alg_pair, "avg_launch_us": round(1e3 * launch_ms, 1),
                      "streamed_bytes_per_launch": ppr * streamed_pair,
                      "survey_8d_bytes_per_launch": ppr * survey_pair,
@@ -310,6 +368,7 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
         "pose_err_vs_truth_max": {"dx_m": float(err[:, 0].max()), "dy_m": float(err[:, 1].max()),
                                   "dtheta_rad": float(err[:, 2].max()),
                                   "note": "fixed 30 iterations vs the generating pose (sampling noise included)"},
+        "pose_err_vs_single_pair_max": cross,
     }
     if host_ms is not None:
         nbytes = ppr * npts * 16
@@ -319,6 +378,8 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier):
                             "note": "ndt2d_batch_align with pageable host arrays: upload + kernel + results; "
                                     "reported beside value, never as value"}
     b.close()
+    del t, res
+    torch.cuda.empty_cache()
     return out
 
 
@@ -501,6 +562,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(d, a.cpu_seconds)
         if not a.no_batch:
             out["batch"] = run_batch(a, dev, dev_index, 0, 1, None, barrier)
+            if not a.no_batch_4096:
+                # all 4096 candidates of BASELINE config 4 on this one GPU (6.55 GB resident): the
+                # anchor for reading the N > 1 lines (512 pairs per GPU) as strong scaling as well
+                out["batch_4096"] = run_batch(a, dev, dev_index, 0, 1, None, barrier, ppr=4096, steps=max(3, min(a.steps, 10)))
         if a.with_3d or a.all_configs:
             out["3d"] = run_3d(a, dev, dev_index)
         # the other single-pair configs of BASELINE.json beside the headline (parity-test cases; cheap to time)

@@ -29,15 +29,17 @@ class CResult(C.Structure):
                 ("status", C.c_int32), ("reserved", C.c_int32)]
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} missing: run __graft_entry__.build()")
-        lib = C.CDLL(LIB_PATH)
+def load(path: str | None = None):
+    """The default build (oracle/_build/libndt_oracle.so) or another build of the same source
+    (bench.py's cpu_baseline leg passes its -O3 -march=native build)."""
+    path = path or LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run __graft_entry__.build()")
+        lib = C.CDLL(path)
         lib.orc2d_build_grid.restype = C.c_void_p
         lib.orc2d_build_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(CParams)]
         lib.orc2d_free_grid.argtypes = [C.c_void_p]
@@ -50,8 +52,8 @@ def load():
         lib.orc2d_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.POINTER(CParams), C.c_int, C.POINTER(CResult)]
         lib.orc_max_threads.restype = C.c_int32
-        _lib = lib
-    return _lib
+        _libs[path] = lib
+    return _libs[path]
 
 
 def cparams(p: NdtParams) -> CParams:
@@ -61,8 +63,8 @@ def cparams(p: NdtParams) -> CParams:
 
 
 class CGrid:
-    def __init__(self, tx, ty, prm: NdtParams):
-        self.lib = load()
+    def __init__(self, tx, ty, prm: NdtParams, lib_path: str | None = None):
+        self.lib = load(lib_path)
         self.prm = cparams(prm)
         self._tx = np.ascontiguousarray(tx, dtype=np.float32)
         self._ty = np.ascontiguousarray(ty, dtype=np.float32)
