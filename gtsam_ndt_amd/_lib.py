@@ -123,6 +123,9 @@ SIGNATURES = {
     "ndt2d_align_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp]),
     "ndt2d_align_finish": (C.c_int32, [_vp, C.POINTER(Result2D)]),
     "ndt2d_stream": (_vp, [_vp]),
+    "ndt2d_wait_stream": (C.c_int32, [_vp, _vp]),
+    "ndt2d_batch_wait_stream": (C.c_int32, [_vp, _vp]),
+    "ndt3d_wait_stream": (C.c_int32, [_vp, _vp]),
     "ndt_magnusson_constants": (C.c_int32, [C.c_double, C.c_double, C.c_int32, _dp, _dp]),
     "ndt2d_polar_to_points_dev": (C.c_int32, [_vp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp]),
     "ndt2d_batch_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),

@@ -592,6 +592,13 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
 
 void* ndt2d_stream(ndt2d_handle* h) { return h ? (void*)h->stream : nullptr; }
 
+int32_t ndt2d_wait_stream(ndt2d_handle* h, void* producer_stream) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(order_after(h->stream, (hipStream_t)producer_stream));
+  return NDT_OK;
+}
+
 int32_t ndt2d_set_target(ndt2d_handle* h, const float* x, const float* y, size_t n) {
   if (!h || !x || !y || n == 0) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
@@ -636,14 +643,7 @@ int32_t ndt2d_add_target_points_dev(ndt2d_handle* h, const float* d_x, const flo
   HIP_TRY(hipSetDevice(h->device));
   { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   // order after the caller's producer stream, as ndt2d_set_target_dev does
-  if (stream && (hipStream_t)stream != h->stream) {
-    hipEvent_t ev;
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(ev, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ev, 0);
-    (void)hipEventDestroy(ev);
-    HIP_TRY(e);
-  }
+  if (stream) HIP_TRY(order_after(h->stream, (hipStream_t)stream));
   const float* px = d_x;
   const float* py = d_y;
   if (pose) {

@@ -274,7 +274,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     int status = __builtin_amdgcn_readfirstlane(misc[3]);
     const float ox = uniformf(reinterpret_cast<float*>(misc)[4]), oy = uniformf(reinterpret_cast<float*>(misc)[5]);
     const float inv_c = (float)(1.0 / a.cell);
-    const float fW = (float)W, fH = (float)Hh;
+    const float fWm1 = (float)(W - 1), fHm1 = (float)(Hh - 1);
     const int ncell = W * Hh;
     const double fix_scale = 4194304.0 / a.cell;     // 2^kFixShift / c
     static_assert(kFixShift == 22, "fix_scale literal");
@@ -297,7 +297,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     __syncthreads();
     for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
       const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
-      if ((fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH)) {
+      if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
         const int key = (int)fy * W + (int)fx;
         if (Cfg::kPackedCount) atomicAdd(&cnt_pairs[key >> 1], (key & 1) ? 0x10000u : 1u);   // nt < 65536: no carry
         else atomicAdd(&cnt[key], 1u);
@@ -342,7 +342,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics)
     for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
       const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
-      if ((fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH)) {
+      if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
         const int ix = (int)fx, iy = (int)fy;
         const int slot = idx[iy * W + ix];
         if (slot) {

@@ -188,6 +188,13 @@ int64_t ndt2d_batch_last_large_count(const ndt2d_batch* b) { return b ? b->last_
 
 void* ndt2d_batch_stream(ndt2d_batch* b) { return b ? (void*)b->stream : nullptr; }
 
+int32_t ndt2d_batch_wait_stream(ndt2d_batch* b, void* producer_stream) {
+  if (!b) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(ndt::order_after(b->stream, (hipStream_t)producer_stream));
+  return NDT_OK;
+}
+
 int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_ty, const uint64_t* d_toff,
                               const float* d_sx, const float* d_sy, const uint64_t* d_soff,
                               const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream) {

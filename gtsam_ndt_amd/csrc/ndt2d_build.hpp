@@ -25,7 +25,7 @@ struct BinGeom {
 
 __device__ __forceinline__ int tile_of(const BinGeom& g, float px, float py) {
   const float fx = (px - g.ox) * g.inv_c, fy = (py - g.oy) * g.inv_c;
-  const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H);
+  const bool in = in_interior(fx, fy, g.W, g.H);      // ring cells stay empty (ndt2d_kernels.hpp)
   return in ? (((int)fy >> kTileShift) * g.ntx + ((int)fx >> kTileShift)) : -1;
 }
 

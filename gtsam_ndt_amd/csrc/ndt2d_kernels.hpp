@@ -163,6 +163,18 @@ __global__ __launch_bounds__(kBlock) void k_bounds(const float* __restrict__ x,
   }
 }
 
+// The grid's outermost ring of cells never receives a target point: the source-side lookup clamps
+// keys onto the grid instead of testing them (image_key below), so every out-of-range, NaN or
+// dead-lane lookup lands on a ring cell, which must therefore stay invalid.  ndt2d_set_target's
+// geometry leaves the ring empty by construction (one guard cell either side) except for a
+// boundary point that float32 rounding of (x - ox) * inv_c puts into cell 0 with a cell size that
+// is not a power of two; ndt2d_reserve_target + ndt2d_add_target_points can put points anywhere.
+// Both are handled here: a point whose cell lies on the ring counts as outside the grid
+// (oracle/ndt2d.py cell_keys32(interior=True) states the same rule).
+__device__ __forceinline__ bool in_interior(float fx, float fy, int W, int H) {
+  return (fx >= 1.f) & (fx < (float)(W - 1)) & (fy >= 1.f) & (fy < (float)(H - 1));
+}
+
 // ---------------------------------------------------------------- shared cell arithmetic
 // Used verbatim by the global-memory path (k_accumulate/k_finalise) and by the LDS-resident
 // batch kernel, so both build bit-identical cell records from the same points.
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float* __restrict__
       const float ox = g.gx[q], oy = g.gy[q];
       const float fx = (px - ox) * g.inv_c;
       const float fy = (py - oy) * g.inv_c;
-      const bool in = (fx >= 0.f) & (fx < (float)g.W) & (fy >= 0.f) & (fy < (float)g.H);
+      const bool in = in_interior(fx, fy, g.W, g.H);
       if (in) {
         any = true;
         const int ix = (int)fx, iy = (int)fy;

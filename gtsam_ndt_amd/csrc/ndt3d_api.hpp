@@ -280,6 +280,13 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   return NDT_OK;
 }
 
+int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ndt::order_after(h->stream, (hipStream_t)producer_stream));
+  return NDT_OK;
+}
+
 int32_t ndt3d_add_target_points(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n, size_t* n_outside) {
   if (!h || !x || !y || !z || n == 0) return NDT_ERR_INVALID_ARG;
   if (!h->has_target) return NDT_ERR_NO_TARGET;

@@ -18,6 +18,19 @@ inline void set_error(const char* msg) { last_error() = msg ? msg : ""; }
 
 namespace ndt {
 
+// Orders everything enqueued on `consumer` from now on behind the work that is in `producer` now
+// (event record + stream wait; the host does not block).
+inline hipError_t order_after(hipStream_t consumer, hipStream_t producer) {
+  if (producer == consumer) return hipSuccess;
+  hipEvent_t ev;
+  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(ev, producer);
+  if (e == hipSuccess) e = hipStreamWaitEvent(consumer, ev, 0);
+  (void)hipEventDestroy(ev);            // released by the runtime once the wait has been satisfied
+  return e;
+}
+
 // A linear chain of `launches` launches of one kernel whose last argument is the launch parity
 // (k & 1), built with explicit graph nodes.  No stream capture: capture state is process-wide
 // in the HIP runtime and this library's handles may be driven from several threads at once.

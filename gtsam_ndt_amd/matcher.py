@@ -167,12 +167,21 @@ class NdtMatcher2D:
         return (np.array(out.H, dtype=np.float64).reshape(3, 3), np.array(out.g, dtype=np.float64),
                 float(out.score), int(out.n_hit))
 
+    def wait_stream(self, stream=None):
+        """Order the handle's stream behind `stream` (default: torch's current stream): device arrays
+        written there are complete before the handle's next kernels read them (ndt2d_wait_stream)."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        L.check(self._lib.ndt2d_wait_stream(self._h, C.c_void_p(int(stream))), "ndt2d_wait_stream")
+
     # ---- full alignment
     def align(self, sx, sy, init_pose=(0.0, 0.0, 0.0)) -> AlignResult:
         p = (C.c_double * 3)(*[float(v) for v in init_pose])
         r = L.Result2D()
         if _is_dev(sx):
             n = sx.numel()
+            self.wait_stream()           # the tensors may still be in flight on torch's current stream
             st = self._lib.ndt2d_align_dev(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), n, p, C.byref(r))
         else:
             sx, sy = _host_f32(sx), _host_f32(sy)
@@ -185,6 +194,7 @@ class NdtMatcher2D:
         p = (C.c_double * 3)(*[float(v) for v in init_pose])
         n = sx.numel()
         self._keep = (sx, sy)
+        self.wait_stream()
         L.check(self._lib.ndt2d_align_dev_async(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), n, p),
                 "ndt2d_align_dev_async")
 
@@ -364,7 +374,9 @@ class NdtBatch2D:
     def align_dev(self, tx, ty, toff, sx, sy, soff, init, out=None, stream=None):
         """Everything already on the device (torch CUDA tensors: float32 clouds, int64
         offsets [n+1], float64 init [n,3]).  Asynchronous; returns the float64 [n,18] result
-        tensor (decode with ``decode``) - valid once the stream is synchronised."""
+        tensor (decode with ``decode``) - valid once the stream is synchronised.  stream=None runs on
+        the context's own stream, ordered behind torch's current stream on the way in and ahead of it
+        on the way out, so the call composes with torch code like any torch op."""
         import torch
         n = int(toff.numel()) - 1
         if out is None:
@@ -374,11 +386,19 @@ class NdtBatch2D:
             if not (t.is_cuda and t.dtype == dt and t.is_contiguous()):
                 raise ValueError("batch tensors must be contiguous CUDA tensors of the documented dtypes")
         self._keep = (tx, ty, toff, sx, sy, soff, init, out)
+        if not stream:
+            # the context's own stream: order it behind torch's current stream, which may still be
+            # writing the clouds
+            L.check(self._lib.ndt2d_batch_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "ndt2d_batch_wait_stream")
         L.check(self._lib.ndt2d_batch_align_dev(
             self._h, C.c_void_p(tx.data_ptr()), C.c_void_p(ty.data_ptr()), C.c_void_p(toff.data_ptr()),
             C.c_void_p(sx.data_ptr()), C.c_void_p(sy.data_ptr()), C.c_void_p(soff.data_ptr()),
             C.c_void_p(init.data_ptr()), n, C.c_void_p(out.data_ptr()),
             C.c_void_p(stream if stream is not None else 0)), "ndt2d_batch_align_dev")
+        if not stream:
+            # ... and torch's current stream behind the context's: `out` can be consumed there in order
+            torch.cuda.current_stream().wait_stream(torch.cuda.ExternalStream(self.stream))
         return out
 
     @staticmethod
@@ -485,7 +505,10 @@ class NdtMatcher3D:
         p = (C.c_double * 6)(*[float(v) for v in init_pose])
         r = L.Result3D()
         if _is_dev(sx):
+            import torch
             n = sx.numel()
+            L.check(self._lib.ndt3d_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "ndt3d_wait_stream")
             st = self._lib.ndt3d_align_dev(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), _dev_ptr(sz, n), n, p, C.byref(r))
         else:
             sx, sy, sz = _host_f32(sx), _host_f32(sy), _host_f32(sz)

@@ -141,7 +141,9 @@ int32_t ndt2d_set_target_dev(ndt2d_handle* h, const float* d_x, const float* d_y
 int32_t ndt2d_reserve_target(ndt2d_handle* h, double xmin, double ymin, double xmax, double ymax);
 /* Incremental submap update: bins n more points into the
  * cached grid's exact per-cell sums and re-finalises.  Points outside the cached extent
- * are counted in *n_outside (may be NULL) and ignored. */
+ * are counted in *n_outside (may be NULL) and ignored; so are points whose cell lies on the grid's
+ * outermost ring (within one cell of the extent's border): the ring stays empty by contract,
+ * because alignments clamp out-of-range lookups onto it. */
 int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y, size_t n,
                                 size_t* n_outside);
 /* The same with the points already on the device, optionally moved into the map frame first:
@@ -177,6 +179,15 @@ int32_t ndt2d_align_dev_async(ndt2d_handle* h, const float* d_sx, const float* d
 int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out);
 /* hipStream_t the handle enqueues on (as void*), for event timing by the caller */
 void* ndt2d_stream(ndt2d_handle* h);
+/* Stream ordering of the device-pointer entry points.  A handle enqueues on its own non-blocking
+ * stream, which is NOT ordered against the stream that produced the caller's device arrays (torch's
+ * current stream, a driver's stream, the stream given to ndt2d_polar_to_points_dev).
+ * ndt2d_wait_stream orders everything the handle enqueues after this call behind the work that is
+ * in producer_stream now (event record + stream wait: the host does not block; NULL = the legacy
+ * default stream).  Call it before ndt2d_align_dev / ndt2d_align_dev_async whenever the source
+ * arrays were written on another stream and that stream has not been synchronised.
+ * (ndt2d_set_target_dev and ndt2d_add_target_points_dev take the producer stream themselves.) */
+int32_t ndt2d_wait_stream(ndt2d_handle* h, void* producer_stream);
 
 /* ---- either side of the path --------------------------- */
 /* Magnusson's outlier-mixture score constants (PhD thesis 2009, eq. 6.8-6.10) expressed as the
@@ -222,6 +233,8 @@ int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_
                               const float* d_sx, const float* d_sy, const uint64_t* d_soff,
                               const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream);
 void* ndt2d_batch_stream(ndt2d_batch* b);
+/* as ndt2d_wait_stream, for calls that run on the context's own stream (stream == NULL above) */
+int32_t ndt2d_batch_wait_stream(ndt2d_batch* b, void* producer_stream);
 /* Of the pairs of the last ndt2d_batch_align() call, how many ran on the 1024-thread variant of
  * the kernel (the rest fitted the 256-thread variant for lidar-sized scans: clouds of at most 8192
  * points, at most 767 occupied cells); -1 before the first call.  Diagnostic. */
@@ -298,6 +311,8 @@ int32_t ndt3d_align(ndt3d_handle* h, const float* sx, const float* sy, const flo
                     const double init_pose[6], ndt3d_result* out);
 int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
                         const double init_pose[6], ndt3d_result* out);
+/* as ndt2d_wait_stream: order the handle's stream behind the producer of the device arrays */
+int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,18 @@ class NdtMatcherHip {
   MatchResult align(const std::vector<float>& sx, const std::vector<float>& sy, const Pose2& guess = Pose2()) {
     return align(sx.data(), sy.data(), sx.size(), guess);
   }
+  // Source scan already on the device (e.g. from ndt2d_polar_to_points_dev).  producer_stream is
+  // the stream that wrote d_sx / d_sy: the handle's own stream is ordered behind it first
+  // (ndt2d_wait_stream; nullptr = the legacy default stream); complete = true when those arrays are
+  // known to be complete (the producer was synchronised), which skips the ordering.
+  MatchResult alignDev(const float* d_sx, const float* d_sy, size_t n, const Pose2& guess, void* producer_stream,
+                       bool complete = false) {
+    if (!complete) check(ndt2d_wait_stream(h_, producer_stream), "ndt2d_wait_stream");
+    const double init[3] = {guess.x, guess.y, guess.theta};
+    ndt2d_result r;
+    check(ndt2d_align_dev(h_, d_sx, d_sy, n, init, &r), "ndt2d_align_dev");
+    return to_match_result(r);
+  }
   // one evaluation at a fixed pose, for callers with their own optimiser
   ndt2d_eval evaluate(const float* sx, const float* sy, size_t n, const Pose2& at) {
     const double p[3] = {at.x, at.y, at.theta};

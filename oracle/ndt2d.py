@@ -88,15 +88,20 @@ class Grid2D:
 OVERLAP_SHIFTS = ((0.0, 0.0), (0.5, 0.0), (0.0, 0.5), (0.5, 0.5))   # in cells (Biber & Strasser 2003)
 
 
-def grid_geometry(tx: np.ndarray, ty: np.ndarray, cell: float, shift=(0.0, 0.0), extra: int = 0):
+def grid_geometry(tx: np.ndarray, ty: np.ndarray, cell: float, shift=(0.0, 0.0), extra: int = 0, bounds=None):
     """Origin/extent rule.  One guard cell below the minimum; the
     extent is whatever the float32 key formula yields for the maximum, plus one.  With
     overlapping grids the origin moves down by `shift` cells and every grid gets one `extra`
-    column and row so that the shifted grids still cover the maximum with a guard cell."""
+    column and row so that the shifted grids still cover the maximum with a guard cell.
+    bounds = (xmin, ymin, xmax, ymax): the geometry ndt2d_reserve_target derives from a caller-
+    chosen extent instead of the cloud's own bounding box."""
     c = float(cell)
     inv_c = np.float32(1.0 / c)
-    xmin, xmax = np.float32(tx.min()), np.float32(tx.max())
-    ymin, ymax = np.float32(ty.min()), np.float32(ty.max())
+    if bounds is None:
+        xmin, xmax = np.float32(tx.min()), np.float32(tx.max())
+        ymin, ymax = np.float32(ty.min()), np.float32(ty.max())
+    else:
+        xmin, ymin, xmax, ymax = (np.float32(v) for v in bounds)
     ox0 = np.float32((math.floor(float(xmin) / c) - 1.0) * c)
     oy0 = np.float32((math.floor(float(ymin) / c) - 1.0) * c)
     kx = int(np.floor((xmax - ox0) * inv_c))      # float32 arithmetic, on the unshifted grid
@@ -106,13 +111,19 @@ def grid_geometry(tx: np.ndarray, ty: np.ndarray, cell: float, shift=(0.0, 0.0),
     return ox, oy, inv_c, kx + 2 + extra, ky + 2 + extra
 
 
-def cell_keys32(x: np.ndarray, y: np.ndarray, ox, oy, inv_c, W, H):
-    """floorf((x-ox)*inv_c) in float32 arithmetic, exactly as the kernels do."""
+def cell_keys32(x: np.ndarray, y: np.ndarray, ox, oy, inv_c, W, H, interior: bool = False):
+    """floorf((x-ox)*inv_c) in float32 arithmetic, exactly as the kernels do.
+    interior=True is the target-side rule: a point whose cell lies on the grid's outermost ring
+    counts as outside (the ring stays empty, so that the source side may clamp instead of test)."""
     x = x.astype(np.float32, copy=False)
     y = y.astype(np.float32, copy=False)
-    ix = np.floor((x - np.float32(ox)) * np.float32(inv_c)).astype(np.int64)
-    iy = np.floor((y - np.float32(oy)) * np.float32(inv_c)).astype(np.int64)
-    inside = (ix >= 0) & (ix < W) & (iy >= 0) & (iy < H)
+    with np.errstate(invalid="ignore"):
+        fx = np.floor((x - np.float32(ox)) * np.float32(inv_c))
+        fy = np.floor((y - np.float32(oy)) * np.float32(inv_c))
+    lo = 1 if interior else 0
+    inside = (fx >= lo) & (fx < W - lo) & (fy >= lo) & (fy < H - lo)      # NaN compares false
+    ix = np.where(inside, fx, 0).astype(np.int64)
+    iy = np.where(inside, fy, 0).astype(np.int64)
     key = np.where(inside, iy * W + ix, 0)
     return key, inside
 
@@ -157,21 +168,25 @@ def finalise_cell(n: int, mx: float, my: float, m2xx: float, m2xy: float, m2yy: 
     return True, a, b, c
 
 
-def build_grids(tx: np.ndarray, ty: np.ndarray, prm: NdtParams):
+def build_grids(tx: np.ndarray, ty: np.ndarray, prm: NdtParams, bounds=None):
     """The list of grids an alignment uses: one, or Biber's four half-cell-shifted ones."""
     if prm.overlap <= 1:
-        return [build_grid(tx, ty, prm)]
-    return [build_grid(tx, ty, prm, shift=sh, extra=1) for sh in OVERLAP_SHIFTS]
+        return [build_grid(tx, ty, prm, bounds=bounds)]
+    return [build_grid(tx, ty, prm, shift=sh, extra=1, bounds=bounds) for sh in OVERLAP_SHIFTS]
 
 
-def build_grid(tx: np.ndarray, ty: np.ndarray, prm: NdtParams, shift=(0.0, 0.0), extra: int = 0) -> Grid2D:
+def build_grid(tx: np.ndarray, ty: np.ndarray, prm: NdtParams, shift=(0.0, 0.0), extra: int = 0, bounds=None) -> Grid2D:
     """Rows a1-a3.  Per-cell mean and centred second moment in float64 (two-pass form,
-    equal to Welford's result up to float64 rounding), then finalise."""
+    equal to Welford's result up to float64 rounding), then finalise.  Points outside the grid's
+    interior (non-finite, beyond `bounds`, or rounded onto the outermost ring) are ignored, as
+    ndt2d_set_target / ndt2d_add_target_points ignore them."""
     tx = np.ascontiguousarray(tx, dtype=np.float32)
     ty = np.ascontiguousarray(ty, dtype=np.float32)
-    ox, oy, inv_c, W, H = grid_geometry(tx, ty, prm.cell_size, shift, extra)
-    key, inside = cell_keys32(tx, ty, ox, oy, inv_c, W, H)
-    assert inside.all()
+    fin = np.isfinite(tx) & np.isfinite(ty)
+    ox, oy, inv_c, W, H = grid_geometry(tx[fin], ty[fin], prm.cell_size, shift, extra, bounds)
+    key, inside = cell_keys32(tx, ty, ox, oy, inv_c, W, H, interior=True)
+    inside &= fin
+    tx, ty, key = tx[inside], ty[inside], key[inside]
     nc = W * H
     x = tx.astype(np.float64)
     y = ty.astype(np.float64)

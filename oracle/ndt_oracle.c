@@ -112,6 +112,8 @@ orc_grid2d* orc2d_build_grid(const float* x, const float* y, size_t n, const orc
   double* m2 = (double*)calloc(nc * 3, sizeof(double));
   for (size_t i = 0; i < n; ++i) {
     volatile float fx = (x[i] - g->ox) * g->inv_c, fy = (y[i] - g->oy) * g->inv_c;
+    /* a point whose cell lies on the outermost ring counts as outside (cell_keys32(interior=True)) */
+    if (!(fx >= 1.0f && fx < (float)(g->W - 1) && fy >= 1.0f && fy < (float)(g->H - 1))) { key[i] = -1; continue; }
     const int32_t ix = (int32_t)floorf(fx), iy = (int32_t)floorf(fy);
     key[i] = iy * g->W + ix;
     g->count[key[i]] += 1;
@@ -123,6 +125,7 @@ orc_grid2d* orc2d_build_grid(const float* x, const float* y, size_t n, const orc
     mx[k] /= nz; my[k] /= nz;
   }
   for (size_t i = 0; i < n; ++i) {   /* re-centre the mean */
+    if (key[i] < 0) continue;
     cx[key[i]] += (double)x[i] - mx[key[i]];
     cy[key[i]] += (double)y[i] - my[key[i]];
   }
@@ -132,6 +135,7 @@ orc_grid2d* orc2d_build_grid(const float* x, const float* y, size_t n, const orc
     my[k] = my[k] + cy[k] / nz;
   }
   for (size_t i = 0; i < n; ++i) {
+    if (key[i] < 0) continue;
     const double dx = (double)x[i] - mx[key[i]], dy = (double)y[i] - my[key[i]];
     m2[3 * (size_t)key[i]] += dx * dx;
     m2[3 * (size_t)key[i] + 1] += dx * dy;
