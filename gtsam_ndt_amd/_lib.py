@@ -122,6 +122,7 @@ SIGNATURES = {
     "ndt2d_align_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result2D)]),
     "ndt2d_align_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp]),
     "ndt2d_align_finish": (C.c_int32, [_vp, C.POINTER(Result2D)]),
+    "ndt2d_align_multi_start_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int32, _vp]),
     "ndt2d_stream": (_vp, [_vp]),
     "ndt2d_wait_stream": (C.c_int32, [_vp, _vp]),
     "ndt2d_batch_wait_stream": (C.c_int32, [_vp, _vp]),

@@ -14,6 +14,7 @@
 #include "ndt2d_kernels.hpp"
 #include "ndt2d_small.hpp"
 #include "ndt2d_build.hpp"
+#include "ndt2d_multi_start.hpp"
 #include "ndt_host.hpp"
 
 using namespace ndt;
@@ -52,6 +53,8 @@ struct ndt2d_handle {
   // hipGraph of the launch chain (launch-bound inner loop: one replay instead of K+1 launches)
   ChainGraphCache graphs;
   hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
+  AlignDynMulti* d_dyn_multi = nullptr;    // multi-start chains (ndt2d_multi_start.hpp), allocated on first use
+  IterState* h_state_multi = nullptr;      // pinned [kMaxStarts]
   ChunkRun chunk_run;                      // converged-mode loop begun by ndt2d_align_dev_async
   int call_seq = 0;                        // alignments enqueued so far (never 0 once one has run)
   bool wide = false;                       // this alignment's k_iterate launches use 1024-thread workgroups
@@ -66,6 +69,8 @@ struct ndt2d_handle {
 namespace {
 
 constexpr size_t kMaxCells = (size_t)1 << 27;
+// k_iterate indexes points with int and looks three strides (of up to 256 x 1024 threads) ahead
+constexpr size_t kMaxSourcePoints = 0x7fffffffull - 4ull * kMaxBlocks * 1024ull;
 #ifndef NDT_ITER_THREADS
 #define NDT_ITER_THREADS 256
 #endif
@@ -328,7 +333,7 @@ int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
     func = newton ? (four ? (const void*)&k_iterate<1, 0, kIterThreads, 4> : (const void*)&k_iterate<1, 0, kIterThreads, 1>)
                   : (four ? (const void*)&k_iterate<0, 0, kIterThreads, 4> : (const void*)&k_iterate<0, 0, kIterThreads, 1>);
   HIP_TRY(h->graphs.get(func, dim3(blocks), dim3(h->wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static, (void*)h->d_call,
-                        (void*)h->d_dyn, launches, h->prm.hessian_mode | (h->wide ? 16 : 0), &h->graph_exec));
+                        (void*)h->d_dyn, launches, h->prm.hessian_mode | (h->wide ? 16 : 0), h->stream, &h->graph_exec));
   return NDT_OK;
 }
 
@@ -364,7 +369,7 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
                   int fixed_override, int check_every, bool wait = true, bool own_source = false) {
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }   // an unfinished asynchronous call
-  if (n == 0 || n > 0x7fffffffull || !pose) return NDT_ERR_INVALID_ARG;
+  if (n == 0 || n > kMaxSourcePoints || !pose) return NDT_ERR_INVALID_ARG;
   if (h->n_valid < 1) {
     h->pending = false;
     std::memset(h->h_state, 0, sizeof(IterState));
@@ -579,7 +584,8 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   (void)finish_chunk_run(h);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
-  void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
+  if (h->h_state_multi) (void)hipHostFree(h->h_state_multi);
+  void* dev[] = {h->d_dyn_multi, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
                  h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag};
@@ -790,6 +796,97 @@ int32_t ndt2d_align(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
 }
 
 }  // extern "C"
+
+
+// ---- multi-start alignment (ndt2d_multi_start.hpp) ---------------------------------------------
+namespace {
+
+template <int MODE, int THREADS>
+const void* multi_kernel(int nh) {
+  if constexpr (THREADS <= 256) {           // a 1024-thread workgroup fills its CU with one start
+    if (nh == 2) return (const void*)&k_iterate_multi<MODE, 2, THREADS>;
+    if (nh == 4) return (const void*)&k_iterate_multi<MODE, 4, THREADS>;
+  }
+  return (const void*)&k_iterate_multi<MODE, 1, THREADS>;
+}
+
+void state_to_result(const IterState& s, ndt2d_result* out) {
+  std::memset(out, 0, sizeof(*out));
+  for (int j = 0; j < 3; ++j) { out->pose[j] = s.pose[j]; out->g[j] = s.g[j]; }
+  sym6_to_9(s.H, out->H);
+  out->score = s.score;
+  out->iterations = s.iter;
+  out->n_hit = s.n_hit;
+  out->status = s.status;
+}
+
+}  // namespace
+
+extern "C" int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
+                                               const double* init_poses, int32_t m, ndt2d_result* results) {
+  if (!h || !d_sx || !d_sy || !init_poses || !results || m < 1 || m > kMaxStarts) return NDT_ERR_INVALID_ARG;
+  if (n == 0 || n > kMaxSourcePoints) return NDT_ERR_INVALID_ARG;
+  if (h->prm.overlap_grids == 4) { set_error("multi-start runs on the single grid only"); return NDT_ERR_INVALID_ARG; }
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
+  if (h->n_valid < 1) {
+    for (int32_t k = 0; k < m; ++k) {
+      std::memset(&results[k], 0, sizeof(ndt2d_result));
+      for (int j = 0; j < 3; ++j) results[k].pose[j] = init_poses[3 * k + j];
+      results[k].status = NDT_TOO_FEW_CELLS;
+    }
+    return NDT_OK;
+  }
+  if (!h->d_dyn_multi) {
+    HIP_TRY(hipMalloc((void**)&h->d_dyn_multi, sizeof(AlignDynMulti)));
+    HIP_TRY(hipMemsetAsync(h->d_dyn_multi, 0, sizeof(AlignDynMulti), h->stream));
+    HIP_TRY(hipHostMalloc((void**)&h->h_state_multi, kMaxStarts * sizeof(IterState), hipHostMallocDefault));
+  }
+  const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON;
+  const bool wide = h->use_wide && n >= h->wide_threshold;
+  const int fixed = h->prm.fixed_iterations;
+  const int K = fixed > 0 ? fixed : h->prm.max_iterations;
+  const bool converged_mode = fixed == 0;
+  // grid = (256 workgroups) x (subsets of nh starts): up to four workgroups per CU carry one start
+  // each, more starts double up inside the workgroups; a 1024-thread workgroup fills a CU alone
+  const int group_max = kMaxStarts;
+  for (int32_t first = 0; first < m; first += group_max) {
+    const int mg = m - first < group_max ? m - first : group_max;
+    const int nh = (wide || mg <= 6) ? 1 : (mg <= 12 ? 2 : 4);     // six one-start workgroups fit a CU (78 VGPRs)
+    const int subsets = (mg + nh - 1) / nh;
+    const void* func = wide ? (newton ? multi_kernel<1, kIterThreadsWide>(nh) : multi_kernel<0, kIterThreadsWide>(nh))
+                            : (newton ? multi_kernel<1, kIterThreads>(nh) : multi_kernel<0, kIterThreads>(nh));
+    __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
+    __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
+    h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
+    StartPoses sp{};
+    for (int k = 0; k < mg; ++k)
+      for (int j = 0; j < 3; ++j) sp.p[k][j] = init_poses[3 * (first + k) + j];
+    hipLaunchKernelGGL(k_begin_multi, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn_multi, d_sx, d_sy, (int)n, sp, mg,
+                       fixed, converged_mode ? h->h_state_multi : (IterState*)nullptr,
+                       converged_mode ? h->h_flag : (int*)nullptr, h->call_seq);
+    HIP_TRY(hipGetLastError());
+    const int launches = converged_mode ? h->check_every + (h->check_every & 1) : K + 1;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(h->graphs.get(func, dim3(kMaxBlocks, subsets), dim3(wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static,
+                          (void*)h->d_call, (void*)h->d_dyn_multi, launches,
+                          0x1000 | (nh << 5) | (subsets << 8) | h->prm.hessian_mode | (wide ? 16 : 0), h->stream, &exec));
+    if (converged_mode) {
+      bool seen = false;
+      HIP_TRY(run_chunks_until_flag(exec, h->stream, h->h_flag, launches, K + 1, h->call_seq, &seen));
+      HIP_TRY(hipGetLastError());
+      if (!seen) { set_error("the multi-start loop did not report its end"); return NDT_ERR_HIP; }
+    } else {
+      HIP_TRY(hipGraphLaunch(exec, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->h_state_multi, h->d_dyn_multi->state[K & 1], kMaxStarts * sizeof(IterState),
+                             hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    for (int k = 0; k < mg; ++k) state_to_result(h->h_state_multi[k], &results[first + k]);
+  }
+  return NDT_OK;
+}
 
 #include "ndt2d_batch_api.hpp"
 #include "ndt2d_multi_api.hpp"

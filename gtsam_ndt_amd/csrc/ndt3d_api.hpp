@@ -166,7 +166,7 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
 int32_t ensure_graph3(ndt3d_handle* h, int launches) {
   using namespace ndt;
   HIP_TRY(h->graphs.get((const void*)&k_iterate3, dim3(kMaxBlocks), dim3(kBlock), (void*)h->d_static, (void*)h->d_call,
-                        (void*)h->d_dyn, launches, 0, &h->graph_exec));
+                        (void*)h->d_dyn, launches, 0, h->stream, &h->graph_exec));
   return NDT_OK;
 }
 
@@ -175,7 +175,7 @@ int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const floa
                    int fixed_override) {
   using namespace ndt;
   if (!h->has_target) return NDT_ERR_NO_TARGET;
-  if (n == 0 || n > 0x7fffffffull) return NDT_ERR_INVALID_ARG;
+  if (n == 0 || n > kMaxSourcePoints) return NDT_ERR_INVALID_ARG;
   if (h->n_valid < 1) {
     std::memset(h->h_state, 0, sizeof(IterState3));
     for (int j = 0; j < 6; ++j) h->h_state->pose[j] = pose[j];

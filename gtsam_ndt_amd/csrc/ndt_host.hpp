@@ -64,7 +64,7 @@ inline hipError_t build_chain_graph(const void* func, dim3 grid, dim3 block, voi
 // timing run, the 2-launch chain of an evaluation): keep the last few instantiated graphs instead
 // of rebuilding one on every change.
 struct ChainGraphCache {
-  static constexpr int kSlots = 4;
+  static constexpr int kSlots = 8;
   struct Slot { int launches = 0, blocks = 0, mode = -1; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long stamp = 0; };
   Slot slot[kSlots];
   unsigned long clock = 0;
@@ -74,13 +74,16 @@ struct ChainGraphCache {
       if (s.exec && s.launches == launches && s.blocks == blocks && s.mode == mode) { s.stamp = ++clock; return s.exec; }
     return nullptr;
   }
-  // the slot to build into: an empty one, else the least recently used (destroyed first)
-  Slot* victim() {
+  // the slot to build into: an empty one, else the least recently used (destroyed first).  Replays
+  // of the evicted exec may still be queued (a converged-mode loop leaves up to two chunks of no-op
+  // launches behind): the owner's stream is drained before the exec is destroyed.
+  Slot* victim(hipStream_t stream) {
     Slot* v = &slot[0];
     for (Slot& s : slot) {
       if (!s.exec) { v = &s; break; }
       if (s.stamp < v->stamp) v = &s;
     }
+    if (v->exec) (void)hipStreamSynchronize(stream);
     release(*v);
     return v;
   }
@@ -91,9 +94,9 @@ struct ChainGraphCache {
   }
   void clear() { for (Slot& s : slot) release(s); }
   hipError_t get(const void* func, dim3 grid, dim3 block, void* a0, void* a1, void* a2, int launches, int mode,
-                 hipGraphExec_t* out) {
+                 hipStream_t stream, hipGraphExec_t* out) {
     if (hipGraphExec_t e = find(launches, (int)grid.x, mode)) { *out = e; return hipSuccess; }
-    Slot* s = victim();
+    Slot* s = victim(stream);
     const hipError_t err = build_chain_graph(func, grid, block, a0, a1, a2, launches, &s->graph, &s->exec);
     if (err != hipSuccess) { *s = Slot{}; return err; }
     s->launches = launches; s->blocks = (int)grid.x; s->mode = mode; s->stamp = ++clock;

@@ -189,6 +189,18 @@ class NdtMatcher2D:
         L.check(st, "ndt2d_align")
         return _to_result(r)
 
+    def align_multi_start(self, sx, sy, init_poses):
+        """Up to 8 alignments of the same device scan from different initial poses in one launch chain
+        (ndt2d_align_multi_start_dev).  Returns a list of AlignResult, one per start."""
+        poses = np.ascontiguousarray(init_poses, dtype=np.float64).reshape(-1, 3)
+        m = poses.shape[0]
+        n = sx.numel()
+        out = (L.Result2D * m)()
+        self.wait_stream()
+        L.check(self._lib.ndt2d_align_multi_start_dev(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), n, poses.ctypes.data, m,
+                                                      C.cast(out, C.c_void_p)), "ndt2d_align_multi_start_dev")
+        return [_to_result(r) for r in out]
+
     def align_async(self, sx, sy, init_pose=(0.0, 0.0, 0.0)):
         """Enqueue the whole loop on the handle's stream (device tensors only)."""
         p = (C.c_double * 3)(*[float(v) for v in init_pose])

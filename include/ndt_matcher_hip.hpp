@@ -130,6 +130,20 @@ class NdtMatcherHip {
     check(ndt2d_align_dev(h_, d_sx, d_sy, n, init, &r), "ndt2d_align_dev");
     return to_match_result(r);
   }
+  // Several starts around a poor guess in one launch chain (ndt2d_align_multi_start_dev, at most 16):
+  // result k is what alignDev(guesses[k]) returns; pick e.g. the best score among the converged ones.
+  std::vector<MatchResult> alignMultiStartDev(const float* d_sx, const float* d_sy, size_t n, const std::vector<Pose2>& guesses,
+                                              void* producer_stream, bool complete = false) {
+    if (!complete) check(ndt2d_wait_stream(h_, producer_stream), "ndt2d_wait_stream");
+    std::vector<double> init(3 * guesses.size());
+    for (size_t k = 0; k < guesses.size(); ++k) { init[3 * k] = guesses[k].x; init[3 * k + 1] = guesses[k].y; init[3 * k + 2] = guesses[k].theta; }
+    std::vector<ndt2d_result> r(guesses.size());
+    check(ndt2d_align_multi_start_dev(h_, d_sx, d_sy, n, init.data(), (int32_t)guesses.size(), r.data()),
+          "ndt2d_align_multi_start_dev");
+    std::vector<MatchResult> out;
+    for (const ndt2d_result& q : r) out.push_back(to_match_result(q));
+    return out;
+  }
   // one evaluation at a fixed pose, for callers with their own optimiser
   ndt2d_eval evaluate(const float* sx, const float* sy, size_t n, const Pose2& at) {
     const double p[3] = {at.x, at.y, at.theta};
