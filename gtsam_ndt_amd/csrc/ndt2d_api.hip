@@ -59,11 +59,12 @@ struct ndt2d_handle {
   int call_seq = 0;                        // alignments enqueued so far (never 0 once one has run)
   bool wide = false;                       // this alignment's k_iterate launches use 1024-thread workgroups
   bool small_run = false;                  // a k_align_small launch whose flag has not been waited for
-  bool use_small = true;                   // NDT_DEBUG_NO_SMALL=1: short scans go through k_iterate too
-  bool use_wide = true;                    // NDT_DEBUG_NO_WIDE=1: 256-thread workgroups whatever the scan size
-  size_t wide_threshold = 300000;          // scan size from which they are used (NDT_WIDE_THRESHOLD overrides)
+  // execution strategy knobs (ndt2d_set_tuning; results do not depend on them beyond float32 summation order)
+  bool use_small = true;                   // short scans run the whole loop in one workgroup (k_align_small)
+  bool use_wide = true;                    // 1024-thread workgroups for large scans ...
+  size_t wide_threshold = 300000;          // ... from this many source points
   bool use_graph = true;
-  int check_every = 8;                     // converged mode: launches per chunk (NDT_DEBUG_CHUNK overrides)
+  int check_every = 8;                     // converged mode: launches per chunk
 };
 
 namespace {
@@ -568,12 +569,6 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   *h->h_flag = 0;
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
-  { const char* e = std::getenv("NDT_DEBUG_NO_GRAPH"); h->use_graph = !(e && e[0] == '1'); }
-  { const char* e = std::getenv("NDT_DEBUG_NO_WIDE"); h->use_wide = !(e && e[0] == '1'); }
-  { const char* e = std::getenv("NDT_WIDE_THRESHOLD"); const long v = e ? std::atol(e) : 0; if (v > 0) h->wide_threshold = (size_t)v; }
-  { const char* e = std::getenv("NDT_DEBUG_NO_SMALL"); h->use_small = !(e && e[0] == '1'); }
-  { const char* e = std::getenv("NDT_DEBUG_CHUNK"); const int v = e ? std::atoi(e) : 0; if (v >= 2 && v <= 128) h->check_every = v; }
-  { const char* e = std::getenv("NDT_DEBUG_ATOMIC_BUILD"); h->use_binned_build = !(e && e[0] == '1'); }
   *out = h;
   return NDT_OK;
 }
@@ -597,6 +592,20 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
 }
 
 void* ndt2d_stream(ndt2d_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
+  switch (knob) {
+    case NDT_TUNE_LAUNCH_GRAPHS: h->use_graph = value != 0; return NDT_OK;
+    case NDT_TUNE_WIDE_THRESHOLD: h->use_wide = value > 0; if (value > 0) h->wide_threshold = (size_t)value; return NDT_OK;
+    case NDT_TUNE_SHORT_SCAN_KERNEL: h->use_small = value != 0; return NDT_OK;
+    case NDT_TUNE_CHUNK_LAUNCHES: if (value < 2 || value > 128) return NDT_ERR_INVALID_ARG; h->check_every = (int)value; return NDT_OK;
+    case NDT_TUNE_BINNED_BUILD: h->use_binned_build = value != 0; return NDT_OK;
+    default: return NDT_ERR_INVALID_ARG;
+  }
+}
 
 int32_t ndt2d_wait_stream(ndt2d_handle* h, void* producer_stream) {
   if (!h) return NDT_ERR_INVALID_ARG;

@@ -22,7 +22,7 @@ struct ndt2d_batch {
   std::vector<ndt2d_handle*> fallback;   // global-memory path (one handle per level) for pairs over the LDS capacity
   int* d_marks = nullptr;                // [n_pairs]: pairs the small variant left to the large one
   size_t marks_cap = 0;
-  bool use_small = true;                 // NDT_DEBUG_NO_BATCH_SMALL=1: every pair through the large variant
+  bool use_small = true;                 // lidar-sized pairs run on the 256-thread variant first (ndt2d_batch_set_tuning)
   int64_t last_large = -1;               // pairs the last host-pointer call's final level ran on the large variant
 };
 
@@ -162,7 +162,6 @@ int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels,
                           ndt::kBatchLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::kBatchLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
-  { const char* e = std::getenv("NDT_DEBUG_NO_BATCH_SMALL"); b->use_small = !(e && e[0] == '1'); }
   *out = b;
   return NDT_OK;
 }
@@ -187,6 +186,15 @@ int32_t ndt2d_batch_destroy(ndt2d_batch* b) {
 int64_t ndt2d_batch_last_large_count(const ndt2d_batch* b) { return b ? b->last_large : -1; }
 
 void* ndt2d_batch_stream(ndt2d_batch* b) { return b ? (void*)b->stream : nullptr; }
+
+int32_t ndt2d_batch_set_tuning(ndt2d_batch* b, int32_t knob, int64_t value) {
+  if (!b) return NDT_ERR_INVALID_ARG;
+  if (knob != NDT_TUNE_BATCH_SMALL_VARIANT) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->use_small = value != 0;
+  return NDT_OK;
+}
 
 int32_t ndt2d_batch_wait_stream(ndt2d_batch* b, void* producer_stream) {
   if (!b) return NDT_ERR_INVALID_ARG;

@@ -73,7 +73,8 @@ def _to_result(r: L.Result2D) -> AlignResult:
 class NdtMatcher2D:
     """One handle = one device stream + one cached target grid."""
 
-    def __init__(self, device: int = 0, params: L.Params2D | None = None, **overrides):
+    def __init__(self, device: int = 0, params: L.Params2D | None = None, tuning: dict | None = None, **overrides):
+        """tuning: execution-strategy knobs by name (L.TUNING), e.g. {"short_scan_kernel": 0}."""
         self._lib = L.load()
         self.params = params if params is not None else default_params(**overrides)
         if params is not None:
@@ -83,6 +84,11 @@ class NdtMatcher2D:
         L.check(self._lib.ndt2d_create(C.byref(self.params), int(device), C.byref(h)), "ndt2d_create")
         self._h = h
         self._keep = None
+        for k, v in (tuning or {}).items():
+            self.set_tuning(k, v)
+
+    def set_tuning(self, knob: str, value: int):
+        L.check(self._lib.ndt2d_set_tuning(self._h, L.TUNING[knob], int(value)), "ndt2d_set_tuning")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -329,8 +335,10 @@ class NdtBatch2D:
     (one persistent workgroup per CU, target grid resident in LDS).  Mirrors
     ndt2d_batch_* of include/ndt_hip.h."""
 
-    def __init__(self, device: int = 0, params: L.Params2D | None = None, levels=None, **overrides):
-        """levels: coarse-to-fine list of Params2D (e.g. pyramid_params()); otherwise one level."""
+    def __init__(self, device: int = 0, params: L.Params2D | None = None, levels=None, small_variant: bool = True,
+                 **overrides):
+        """levels: coarse-to-fine list of Params2D (e.g. pyramid_params()); otherwise one level.
+        small_variant=False: every pair on the 1024-thread kernel (ndt2d_batch_set_tuning)."""
         self._lib = L.load()
         self.params = params if params is not None else default_params(**overrides)
         if params is not None:
@@ -346,6 +354,8 @@ class NdtBatch2D:
             L.check(self._lib.ndt2d_batch_create(C.byref(self.params), int(device), C.byref(h)), "ndt2d_batch_create")
         self._h = h
         self._keep = None
+        if not small_variant:
+            L.check(self._lib.ndt2d_batch_set_tuning(self._h, L.TUNING["batch_small_variant"], 0), "ndt2d_batch_set_tuning")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -187,6 +187,26 @@ int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out);
  * Synchronous in the results (host memory).  Single grid only (overlap_grids must not be 4). */
 int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
                                     const double* init_poses, int32_t m, ndt2d_result* results);
+/* Execution-strategy knobs of a handle.  They choose between kernels that compute the same alignment
+ * (results agree up to float32 summation order; the tests pin each pair of choices against each other
+ * and against the oracle); the defaults are the measured best, nothing reads the environment.
+ *   NDT_TUNE_LAUNCH_GRAPHS      1 (default): launch chains are hipGraph replays; 0: plain launches
+ *   NDT_TUNE_WIDE_THRESHOLD     source points from which k_iterate runs on 1024-thread workgroups
+ *                               (default 300000); 0: never
+ *   NDT_TUNE_SHORT_SCAN_KERNEL  1 (default): scans of <= 4096 points run the whole loop in one workgroup
+ *   NDT_TUNE_CHUNK_LAUNCHES     converged mode: launches per graph replay, 2..128 (default 8)
+ *   NDT_TUNE_BINNED_BUILD       1 (default): LDS-binned grid build; 0: scattered global atomics
+ *   NDT_TUNE_BATCH_SMALL_VARIANT (batch contexts) 1 (default): lidar-sized pairs run on the 256-thread
+ *                               variant of the batch kernel first; 0: every pair on the 1024-thread one */
+enum {
+  NDT_TUNE_LAUNCH_GRAPHS = 1,
+  NDT_TUNE_WIDE_THRESHOLD = 2,
+  NDT_TUNE_SHORT_SCAN_KERNEL = 3,
+  NDT_TUNE_CHUNK_LAUNCHES = 4,
+  NDT_TUNE_BINNED_BUILD = 5,
+  NDT_TUNE_BATCH_SMALL_VARIANT = 6
+};
+int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value);
 /* hipStream_t the handle enqueues on (as void*), for event timing by the caller */
 void* ndt2d_stream(ndt2d_handle* h);
 /* Stream ordering of the device-pointer entry points.  A handle enqueues on its own non-blocking
@@ -243,6 +263,7 @@ int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_
                               const float* d_sx, const float* d_sy, const uint64_t* d_soff,
                               const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream);
 void* ndt2d_batch_stream(ndt2d_batch* b);
+int32_t ndt2d_batch_set_tuning(ndt2d_batch* b, int32_t knob, int64_t value);   /* NDT_TUNE_BATCH_SMALL_VARIANT */
 /* as ndt2d_wait_stream, for calls that run on the context's own stream (stream == NULL above) */
 int32_t ndt2d_batch_wait_stream(ndt2d_batch* b, void* producer_stream);
 /* Of the pairs of the last ndt2d_batch_align() call, how many ran on the 1024-thread variant of

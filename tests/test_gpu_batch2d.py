@@ -212,7 +212,7 @@ def test_batch_pyramid_matches_oracle_composition_and_widens_the_basin(gpu_lib, 
     assert bad[1].pose == res[1].pose
 
 
-def test_small_pair_variant_equals_large_variant_and_oracle(gpu_lib, monkeypatch):
+def test_small_pair_variant_equals_large_variant_and_oracle(gpu_lib):
     """Lidar-sized pairs run on the 256-thread variant of the batch kernel (three pairs per CU);
     pairs over its limits (points, cells, occupied cells) are left to the 1024-thread variant in
     the same call.  Same results as with the small variant switched off, and as the oracle."""
@@ -231,8 +231,7 @@ def test_small_pair_variant_equals_large_variant_and_oracle(gpu_lib, monkeypatch
     I = [p["init"] for p in pairs]
     res = {}
     for off in ("0", "1"):
-        monkeypatch.setenv("NDT_DEBUG_NO_BATCH_SMALL", off)
-        with M.NdtBatch2D() as b:
+        with M.NdtBatch2D(small_variant=(off == "0")) as b:
             res[off] = b.align(T, S, I)
             # (8193, 500), (500, 8193), (20000, 20000) exceed the point limit; (8192, 8192) occupies more
             # than 767 cells; the others fit the small variant
@@ -251,17 +250,14 @@ def test_small_pair_variant_equals_large_variant_and_oracle(gpu_lib, monkeypatch
                 assert np.abs(np.array(a.pose) - np.array(ref["pose"])).max() < 1e-5, k
     # a cell size that needs more than 64 x 64 cells: the small variant hands the pair over
     for off in ("0", "1"):
-        monkeypatch.setenv("NDT_DEBUG_NO_BATCH_SMALL", off)
-        with M.NdtBatch2D(cell_size=0.2) as b:
+        with M.NdtBatch2D(cell_size=0.2, small_variant=(off == "0")) as b:
             res[off] = b.align(T[:3], S[:3], I[:3])
     for a, b in zip(res["0"], res["1"]):
         assert a.status == b.status and np.abs(np.array(a.pose) - np.array(b.pose)).max() < 2e-5
     # coarse-to-fine over a mixed batch
-    monkeypatch.setenv("NDT_DEBUG_NO_BATCH_SMALL", "0")
     with M.NdtBatch2D(levels=M.pyramid_params()) as b:
         pyr = b.align(T[:8], S[:8], I[:8])
-    monkeypatch.setenv("NDT_DEBUG_NO_BATCH_SMALL", "1")
-    with M.NdtBatch2D(levels=M.pyramid_params()) as b:
+    with M.NdtBatch2D(levels=M.pyramid_params(), small_variant=False) as b:
         pyr_l = b.align(T[:8], S[:8], I[:8])
     for a, b in zip(pyr, pyr_l):
         assert a.status == b.status and abs(a.iterations - b.iterations) <= 3

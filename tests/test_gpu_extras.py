@@ -128,9 +128,9 @@ def test_async_converged_mode(gpu_lib):
 @pytest.mark.parametrize("n_src,kw", [(360, {}), (1000, {}), (2048, {}), (2049, {}), (4096, {}), (1000, dict(hessian_mode=1)),
                                       (1500, dict(overlap_grids=4)), (777, dict(line_search=3)), (900, dict(step_scale=2.5)),
                                       (1000, dict(fixed_iterations=7))])
-def test_short_scan_kernel_equals_launch_per_iteration_path(gpu_lib, monkeypatch, n_src, kw):
+def test_short_scan_kernel_equals_launch_per_iteration_path(gpu_lib, n_src, kw):
     """Scans of up to 4096 points run the whole loop in one workgroup (k_align_small); the result
-    must be what the general path (one launch per iteration, NDT_DEBUG_NO_SMALL=1) returns, up to
+    must be what the general path (one launch per iteration, tuning short_scan_kernel = 0) returns, up to
     the float32 summation order, and what the oracle returns."""
     import torch
     from gtsam_ndt_amd.matcher import NdtMatcher2D
@@ -139,8 +139,7 @@ def test_short_scan_kernel_equals_launch_per_iteration_path(gpu_lib, monkeypatch
     sx, sy = torch.from_numpy(d["sx"]).cuda(), torch.from_numpy(d["sy"]).cuda()
     res = {}
     for no_small in ("0", "1"):
-        monkeypatch.setenv("NDT_DEBUG_NO_SMALL", no_small)
-        with NdtMatcher2D(**kw) as m:
+        with NdtMatcher2D(tuning={"short_scan_kernel": 0 if no_small == "1" else 1}, **kw) as m:
             m.set_target(d["tx"], d["ty"])
             res[no_small] = (m.align(sx, sy, d["init"]), m.align(d["sx"], d["sy"], d["init"]),
                              m.evaluate(d["sx"], d["sy"], d["pose"]))
@@ -173,8 +172,8 @@ def test_short_scan_kernel_equals_launch_per_iteration_path(gpu_lib, monkeypatch
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"NDT_DEBUG_NO_GRAPH": "1"}, {"NDT_DEBUG_CHUNK": "2"}, {"NDT_DEBUG_CHUNK": "64"}])
-def test_launch_chain_drivers_agree(gpu_lib, monkeypatch, env):
+@pytest.mark.parametrize("env", [{"launch_graphs": 0}, {"chunk_launches": 2}, {"chunk_launches": 64}])
+def test_launch_chain_drivers_agree(gpu_lib, env):
     """The converged-mode loop gives the same result however the host feeds it: plain stream
     launches with a poll per chunk, or graph replays of 2, 8 (default) or 64 launches."""
     import torch
@@ -184,9 +183,7 @@ def test_launch_chain_drivers_agree(gpu_lib, monkeypatch, env):
     with NdtMatcher2D() as m:
         m.set_target(d["tx"], d["ty"])
         ref = m.align(sx, sy, d["init"])
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    with NdtMatcher2D() as m:
+    with NdtMatcher2D(tuning=env) as m:
         m.set_target(d["tx"], d["ty"])
         for src in ((sx, sy), (d["sx"], d["sy"])):
             for _ in range(3):
@@ -199,7 +196,7 @@ def test_launch_chain_drivers_agree(gpu_lib, monkeypatch, env):
 
 
 @pytest.mark.gpu
-def test_wide_workgroups_for_large_scans_equal_the_narrow_ones(gpu_lib, monkeypatch):
+def test_wide_workgroups_for_large_scans_equal_the_narrow_ones(gpu_lib):
     """Scans of >= 300k points run k_iterate with 1024-thread workgroups (loads in flight); the
     result is the 256-thread one up to the float32 summation order."""
     import torch
@@ -208,8 +205,7 @@ def test_wide_workgroups_for_large_scans_equal_the_narrow_ones(gpu_lib, monkeypa
     tx, ty, sx, sy = (torch.from_numpy(d[k]).cuda() for k in ("tx", "ty", "sx", "sy"))
     res = {}
     for off in ("0", "1"):
-        monkeypatch.setenv("NDT_DEBUG_NO_WIDE", off)
-        with NdtMatcher2D() as m:
+        with NdtMatcher2D(tuning={"wide_threshold": 0} if off == "1" else None) as m:
             m.set_target(tx, ty)
             res[off] = (m.align(sx, sy, d["init"]), m.align(sx, sy, d["init"]))
     for off in ("0", "1"):

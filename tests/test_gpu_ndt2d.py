@@ -203,7 +203,7 @@ def test_edge_cases(Matcher, gpu_lib):
         assert np.isfinite(r.pose).all()
 
 
-def test_binned_build_equals_atomic_build(Matcher, monkeypatch):
+def test_binned_build_equals_atomic_build(Matcher):
     """The LDS-binned grid build (fast path) and the scattered-global-atomic build produce the
     same exact sums, hence bit-identical records - for a one-shot build, an incremental update
     and overlapping grids, at the full 1M-point size."""
@@ -214,15 +214,15 @@ def test_binned_build_equals_atomic_build(Matcher, monkeypatch):
     rest = np.setdiff1d(np.arange(len(d["tx"])), first)
     out = {}
     for name, env in (("binned", "0"), ("atomic", "1")):
-        monkeypatch.setenv("NDT_DEBUG_ATOMIC_BUILD", env)
-        with Matcher() as m:
+        tune = {"binned_build": 0 if env == "1" else 1}
+        with Matcher(tuning=tune) as m:
             info = m.set_target(d["tx"], d["ty"])
             full = m.grid() + (info.n_valid,)
             m.set_target(d["tx"][first], d["ty"][first])
             assert m.add_target_points(d["tx"][rest], d["ty"][rest]) == 0
             inc = m.grid()
             assert m.add_target_points(d["tx"][:10] + 1e4, d["ty"][:10]) == 10      # outside: counted, ignored
-        with Matcher(overlap_grids=4) as m:
+        with Matcher(overlap_grids=4, tuning=tune) as m:
             ov = m.set_target(d["tx"][:200000], d["ty"][:200000]).n_valid
             r = m.align(d["sx"], d["sy"], d["init"])
         out[name] = (full, inc, ov, r.pose)

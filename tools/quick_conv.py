@@ -11,8 +11,7 @@ tx, ty, sx, sy = (torch.from_numpy(d[k]).to(dev) for k in ("tx", "ty", "sx", "sy
 torch.cuda.synchronize()
 lib = L.load()
 for chunk in (4, 8, 12, 16, 24, 32, 64):
-    os.environ["NDT_DEBUG_CHUNK"] = str(chunk)
-    with NdtMatcher2D() as m:
+    with NdtMatcher2D(tuning={"chunk_launches": chunk}) as m:
         m.set_target(tx, ty)
         init = (C.c_double * 3)(*d["init"])
         out = L.Result2D()
@@ -24,7 +23,6 @@ for chunk in (4, 8, 12, 16, 24, 32, 64):
         print(f"chunk {chunk:3d}: median {1e6*np.median(lat[5:]):.1f} us  min {1e6*min(lat):.1f} us  iters {out.iterations}")
 
 # alternating evaluate / align on one handle: the chain graphs of both lengths stay cached
-os.environ["NDT_DEBUG_CHUNK"] = "8"
 with NdtMatcher2D() as m:
     m.set_target(tx, ty)
     lat = []

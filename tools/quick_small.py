@@ -11,9 +11,8 @@ for n_src in (360, 1000, 2048, 4096):
     sx, sy = torch.from_numpy(d["sx"]).cuda(), torch.from_numpy(d["sy"]).cuda()
     torch.cuda.synchronize()
     for small in ("1", "0"):
-        os.environ["NDT_DEBUG_NO_SMALL"] = "0" if small == "1" else "1"
         for kw in (dict(), dict(fixed_iterations=30)):
-            with NdtMatcher2D(**kw) as m:
+            with NdtMatcher2D(tuning={"short_scan_kernel": int(small)}, **kw) as m:
                 m.set_target(d["tx"], d["ty"])
                 init = (C.c_double * 3)(*d["init"])
                 out = L.Result2D()

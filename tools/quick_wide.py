@@ -10,9 +10,8 @@ for n in (100_000, 150_000, 200_000, 300_000, 500_000, 1_000_000):
     sx, sy = torch.from_numpy(base["sx"][:n].copy()).cuda(), torch.from_numpy(base["sy"][:n].copy()).cuda()
     row = []
     for no_wide, thr in (("1", None), ("0", None)):
-        os.environ["NDT_DEBUG_NO_WIDE"] = no_wide
-        os.environ["NDT_WIDE_THRESHOLD"] = "1"          # with NO_WIDE=0: force the wide variant at every size
-        with NdtMatcher2D(fixed_iterations=30) as m:
+        # wide_threshold 0: never wide; 1: the wide variant at every size
+        with NdtMatcher2D(fixed_iterations=30, tuning={"wide_threshold": 0 if no_wide == "1" else 1}) as m:
             m.set_target(tx, ty)
             for _ in range(3):
                 m.align_async(sx, sy, base["init"]); m.finish()
