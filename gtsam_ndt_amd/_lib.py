@@ -24,6 +24,7 @@ NDT_ERR_HIP = -3
 NDT_ERR_NO_DEVICE = -4
 NDT_ERR_CAPACITY = -5
 NDT_ERR_ALLOC = -6
+NDT_ERR_RCCL = -7
 
 # ndt2d_set_tuning / ndt2d_batch_set_tuning knobs
 TUNING = {"launch_graphs": 1, "wide_threshold": 2, "short_scan_kernel": 3, "chunk_launches": 4, "binned_build": 5,
@@ -148,6 +149,7 @@ SIGNATURES = {
     "ndt2d_multi_destroy": (C.c_int32, [_vp]),
     "ndt2d_multi_device_count": (C.c_int32, [_vp]),
     "ndt2d_multi_align": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ndt2d_multi_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ndt2d_multi_plan": (C.c_int32, [C.c_int32, _vp, _vp, C.c_size_t, C.c_int32, _vp]),
     "ndt3d_default_params": (None, [C.POINTER(Params2D)]),
     "ndt3d_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),

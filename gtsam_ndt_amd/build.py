@@ -24,6 +24,8 @@ HIP_SOURCES = ["ndt2d_api.hip"]
 # the loop-closure kernel.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
              "-Wno-unused-function", "-fno-slp-vectorize"]
+# the multi-device gather of ndt2d_multi_align_dev calls RCCL directly (ncclCommInitAll / ncclAllGather)
+HIP_LIBS = ["-L/opt/rocm/lib", "-lrccl"]
 
 
 def _newer(target: str, deps: list[str]) -> bool:
@@ -55,7 +57,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [hipcc_path(), *HIP_FLAGS, "-I", os.path.join(ROOT, "include"), "-o", LIB,
-           *[os.path.join(CSRC, s) for s in HIP_SOURCES]]
+           *[os.path.join(CSRC, s) for s in HIP_SOURCES], *HIP_LIBS]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=ROOT)

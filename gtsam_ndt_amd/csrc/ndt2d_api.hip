@@ -486,6 +486,7 @@ const char* ndt_status_string(int32_t s) {
     case NDT_ERR_NO_DEVICE: return "no HIP device";
     case NDT_ERR_CAPACITY: return "capacity limit exceeded";
     case NDT_ERR_ALLOC: return "allocation failed";
+    case NDT_ERR_RCCL: return "RCCL error";
     default: return "unknown status";
   }
 }

@@ -5,6 +5,8 @@
 // there is no collective here; the one-process-per-GPU deployment (torch.distributed / RCCL
 // gather) lives in gtsam_ndt_amd/dist.py and bench.py.
 #pragma once
+#include <rccl/rccl.h>
+
 #include <thread>
 #include <vector>
 
@@ -12,10 +14,30 @@ struct ndt2d_multi {
   std::vector<ndt2d_batch*> ctx;
   ndt2d_params prm{};
   int32_t iterations_hint = 30;      // expected evaluations per pair over all levels (shard balancing)
+  // device-resident form (ndt2d_multi_align_dev): one RCCL communicator per context, created on first use
+  std::vector<ncclComm_t> comms;
+  std::vector<ndt2d_result*> d_send;  // [ctx]: this device's rows, padded to the longest shard
+  std::vector<ndt2d_result*> d_recv;  // [ctx]: every device's rows after the all-gather
+  size_t gather_cap = 0;              // rows per shard the buffers hold
 };
+
+#define RCCL_TRY(expr)                                                                    \
+  do {                                                                                    \
+    const ncclResult_t _r = (expr);                                                       \
+    if (_r != ncclSuccess) {                                                              \
+      ::ndt::last_error() = std::string(#expr) + ": " + ncclGetErrorString(_r);           \
+      return NDT_ERR_RCCL;                                                                \
+    }                                                                                     \
+  } while (0)
 
 int32_t ndt2d_multi_destroy(ndt2d_multi* m) {
   if (!m) return NDT_OK;
+  for (size_t d = 0; d < m->ctx.size(); ++d) {
+    (void)hipSetDevice(m->ctx[d]->device);
+    if (d < m->d_send.size() && m->d_send[d]) (void)hipFree(m->d_send[d]);
+    if (d < m->d_recv.size() && m->d_recv[d]) (void)hipFree(m->d_recv[d]);
+  }
+  for (ncclComm_t c : m->comms) if (c) (void)ncclCommDestroy(c);
   for (ndt2d_batch* b : m->ctx) ndt2d_batch_destroy(b);
   delete m;
   return NDT_OK;
@@ -104,5 +126,103 @@ int32_t ndt2d_multi_align(ndt2d_multi* m, const float* tx, const float* ty, cons
   for (std::thread& w : workers) w.join();
   for (int d = 0; d < nd; ++d)
     if (status[d] != NDT_OK) { ndt::set_error(message[d].c_str()); return status[d]; }
+  return NDT_OK;
+}
+
+
+// Device-resident form with the RCCL gather (BASELINE.json north_star: "shards scan pairs across the 8
+// GPUs of one node with a final RCCL gather over xGMI").  One host thread enqueues everything: the
+// batch kernels on every context's stream, then one grouped ncclAllGather of the padded result rows
+// on the same streams - no host copy of a result, no host synchronisation between alignment and gather.
+int32_t ndt2d_multi_align_dev(ndt2d_multi* m, const float* const* d_tx, const float* const* d_ty,
+                              const uint64_t* const* d_toff, const float* const* d_sx, const float* const* d_sy,
+                              const uint64_t* const* d_soff, const double* const* d_init, const size_t* n_pairs,
+                              ndt2d_result** d_results_all, size_t* shard_stride, ndt2d_result* results) {
+  if (!m || m->ctx.empty() || !d_tx || !d_ty || !d_toff || !d_sx || !d_sy || !d_soff || !d_init || !n_pairs)
+    return NDT_ERR_INVALID_ARG;
+  const int nd = static_cast<int>(m->ctx.size());
+  size_t longest = 0, total = 0;
+  for (int d = 0; d < nd; ++d) {
+    if (n_pairs[d] > 0x7fffffffull) return NDT_ERR_INVALID_ARG;
+    if (n_pairs[d] > 0 && (!d_tx[d] || !d_ty[d] || !d_toff[d] || !d_sx[d] || !d_sy[d] || !d_soff[d] || !d_init[d]))
+      return NDT_ERR_INVALID_ARG;
+    longest = n_pairs[d] > longest ? n_pairs[d] : longest;
+    total += n_pairs[d];
+  }
+  if (total == 0) return NDT_ERR_INVALID_ARG;
+  if (m->comms.empty()) {
+    // one communicator per context, all in this process (ncclCommInitAll); a device listed twice
+    // cannot take part in a collective with itself
+    std::vector<int> devs(nd);
+    for (int d = 0; d < nd; ++d) {
+      devs[d] = m->ctx[d]->device;
+      for (int e = 0; e < d; ++e)
+        if (devs[e] == devs[d]) { ndt::set_error("the RCCL gather needs distinct devices"); return NDT_ERR_INVALID_ARG; }
+    }
+    m->comms.assign(nd, nullptr);
+    const ncclResult_t r = ncclCommInitAll(m->comms.data(), nd, devs.data());
+    if (r != ncclSuccess) {
+      m->comms.clear();
+      ndt::last_error() = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
+      return NDT_ERR_RCCL;
+    }
+  }
+  if (longest > m->gather_cap) {
+    m->d_send.resize(nd, nullptr);
+    m->d_recv.resize(nd, nullptr);
+    const size_t want = longest + longest / 4 + 16;
+    for (int d = 0; d < nd; ++d) {
+      HIP_TRY(hipSetDevice(m->ctx[d]->device));
+      HIP_TRY(hipStreamSynchronize(m->ctx[d]->stream));
+      if (m->d_send[d]) (void)hipFree(m->d_send[d]);
+      if (m->d_recv[d]) (void)hipFree(m->d_recv[d]);
+      m->d_send[d] = m->d_recv[d] = nullptr;
+      HIP_TRY(hipMalloc((void**)&m->d_send[d], want * sizeof(ndt2d_result)));
+      HIP_TRY(hipMalloc((void**)&m->d_recv[d], want * nd * sizeof(ndt2d_result)));
+    }
+    m->gather_cap = want;
+  }
+  // the gather moves `stride` rows per shard: the longest shard (padding rows are zero)
+  const size_t stride = longest;
+  for (int d = 0; d < nd; ++d) {
+    HIP_TRY(hipSetDevice(m->ctx[d]->device));
+    hipStream_t st = m->ctx[d]->stream;
+    if (n_pairs[d] < stride)
+      HIP_TRY(hipMemsetAsync(m->d_send[d] + n_pairs[d], 0, (stride - n_pairs[d]) * sizeof(ndt2d_result), st));
+    if (n_pairs[d] > 0) {
+      const int32_t bs = batch_launch(m->ctx[d], d_tx[d], d_ty[d], reinterpret_cast<const unsigned long long*>(d_toff[d]),
+                                      d_sx[d], d_sy[d], reinterpret_cast<const unsigned long long*>(d_soff[d]), d_init[d],
+                                      n_pairs[d], m->d_send[d], st);
+      if (bs != NDT_OK) return bs;
+    }
+  }
+  static_assert(sizeof(ndt2d_result) % sizeof(double) == 0, "rows travel as doubles");
+  const size_t count = stride * (sizeof(ndt2d_result) / sizeof(double));
+  RCCL_TRY(ncclGroupStart());
+  for (int d = 0; d < nd; ++d) {
+    const ncclResult_t r = ncclAllGather(m->d_send[d], m->d_recv[d], count, ncclDouble, m->comms[d], m->ctx[d]->stream);
+    if (r != ncclSuccess) {
+      (void)ncclGroupEnd();
+      ndt::last_error() = std::string("ncclAllGather: ") + ncclGetErrorString(r);
+      return NDT_ERR_RCCL;
+    }
+  }
+  RCCL_TRY(ncclGroupEnd());
+  if (results) {     // global pair order, padding dropped, from the first device's copy of the gather
+    HIP_TRY(hipSetDevice(m->ctx[0]->device));
+    size_t k = 0;
+    for (int d = 0; d < nd; ++d) {
+      if (n_pairs[d] > 0)
+        HIP_TRY(hipMemcpyAsync(results + k, m->d_recv[0] + (size_t)d * stride, n_pairs[d] * sizeof(ndt2d_result),
+                               hipMemcpyDeviceToHost, m->ctx[0]->stream));
+      k += n_pairs[d];
+    }
+  }
+  for (int d = 0; d < nd; ++d) {
+    HIP_TRY(hipSetDevice(m->ctx[d]->device));
+    HIP_TRY(hipStreamSynchronize(m->ctx[d]->stream));
+    if (d_results_all) d_results_all[d] = m->d_recv[d];
+  }
+  if (shard_stride) *shard_stride = stride;
   return NDT_OK;
 }

@@ -330,6 +330,43 @@ class NdtMulti2D:
         return _results_from_bytes(out, n)
 
 
+def _multi_align_dev(self, shards):
+    """ndt2d_multi_align_dev: shards[d] = dict of torch tensors resident on device d (tx, ty, toff, sx,
+    sy, soff, init - the layout of NdtBatch2D.align_dev; an empty shard is None).  Every shard is
+    aligned on its device and the rows are exchanged with one RCCL all-gather; returns the list of
+    AlignResult in global pair order (shard 0's pairs, shard 1's, ...)."""
+    import torch
+    nd = self.device_count
+    if len(shards) != nd:
+        raise ValueError("one shard per device context")
+    arr = lambda: (C.c_void_p * nd)()
+    ptr = {k: arr() for k in ("tx", "ty", "toff", "sx", "sy", "soff", "init")}
+    n_pairs = (C.c_size_t * nd)()
+    for d, sh in enumerate(shards):
+        n_pairs[d] = 0 if sh is None else int(sh["toff"].numel()) - 1
+        for k in ptr:
+            if sh is not None:
+                t = sh[k]
+                want = torch.float32 if k in ("tx", "ty", "sx", "sy") else (torch.int64 if k in ("toff", "soff") else torch.float64)
+                if not (t.is_cuda and t.dtype == want and t.is_contiguous()):
+                    raise ValueError("shard tensors must be contiguous CUDA tensors of the documented dtypes")
+                ptr[k][d] = t.data_ptr()
+    for sh in shards:                       # the contexts' streams are not torch's: finish the producers
+        if sh is not None:
+            torch.cuda.synchronize(sh["tx"].device)
+    total = sum(n_pairs)
+    out = np.zeros(total * RESULT_DOUBLES, dtype=np.float64)
+    stride = C.c_size_t(0)
+    L.check(self._lib.ndt2d_multi_align_dev(self._h, ptr["tx"], ptr["ty"], ptr["toff"], ptr["sx"], ptr["sy"], ptr["soff"],
+                                            ptr["init"], n_pairs, None, C.byref(stride), out.ctypes.data),
+            "ndt2d_multi_align_dev")
+    self.last_shard_stride = int(stride.value)
+    return _results_from_bytes(out, total)
+
+
+NdtMulti2D.align_dev = _multi_align_dev
+
+
 class NdtBatch2D:
     """Loop-closure candidate batch: independent scan pairs aligned concurrently on one GPU
     (one persistent workgroup per CU, target grid resident in LDS).  Mirrors

@@ -47,7 +47,8 @@ enum {
   NDT_ERR_HIP = -3,
   NDT_ERR_NO_DEVICE = -4,
   NDT_ERR_CAPACITY = -5,      /* a per-cell or per-grid capacity limit was exceeded   */
-  NDT_ERR_ALLOC = -6
+  NDT_ERR_ALLOC = -6,
+  NDT_ERR_RCCL = -7           /* an RCCL call of the multi-device gather failed (ndt_last_error has its text) */
 };
 
 enum { NDT_HESSIAN_GAUSS_NEWTON = 0, NDT_HESSIAN_NEWTON = 1 };
@@ -275,8 +276,9 @@ int64_t ndt2d_batch_last_large_count(const ndt2d_batch* b);
  * node's GPUs itself): one batch context and one host thread per device, pairs split into
  * contiguous work-balanced shards, results written into the caller's array.  Pairs are
  * independent, so no data moves between devices.  device_ids == NULL with n_devices == 0 means
- * every visible device; an id may be listed more than once (two contexts on that device).
- * (The one-process-per-GPU deployment with an RCCL gather is gtsam_ndt_amd/dist.py.) */
+ * every visible device; an id may be listed more than once (two contexts on that device; not with
+ * the RCCL gather of ndt2d_multi_align_dev).  (The one-process-per-GPU deployment is
+ * gtsam_ndt_amd/dist.py: the same sharding, the gather through torch.distributed's RCCL backend.) */
 typedef struct ndt2d_multi ndt2d_multi;
 int32_t ndt2d_multi_create(const ndt2d_params* p, const int32_t* device_ids, int32_t n_devices, ndt2d_multi** out);
 int32_t ndt2d_multi_create_pyramid(const ndt2d_params* levels, int32_t n_levels, const int32_t* device_ids,
@@ -287,6 +289,21 @@ int32_t ndt2d_multi_device_count(const ndt2d_multi* m);
 int32_t ndt2d_multi_align(ndt2d_multi* m, const float* tx, const float* ty, const uint64_t* toff,
                           const float* sx, const float* sy, const uint64_t* soff, const double* init,
                           size_t n_pairs, ndt2d_result* results);
+/* Device-resident form with the RCCL gather: shard d's clouds are already on device d (arrays of
+ * n_devices device pointers, each laid out as ndt2d_batch_align_dev takes it; n_pairs[d] pairs on
+ * device d, 0 allowed).  Every context aligns its shard on its own stream and the result rows of all
+ * shards are exchanged with ONE ncclAllGather over those streams (xGMI on a multi-GPU node), so that
+ * every device ends up holding every row - no result passes through host memory on the way.
+ * Layout of a gathered copy: row k of shard d at index d * (*shard_stride) + k, *shard_stride = the
+ * longest shard (shorter shards are zero-padded).  d_results_all[d] (may be NULL) receives device d's
+ * copy - owned by the context, valid until its next call; results (may be NULL, host memory,
+ * sum of n_pairs rows) receives the rows in global pair order without padding.  Synchronous.
+ * The communicators are created on the first call (ncclCommInitAll: one process, one rank per
+ * context, distinct devices required); RCCL failures return NDT_ERR_RCCL. */
+int32_t ndt2d_multi_align_dev(ndt2d_multi* m, const float* const* d_tx, const float* const* d_ty,
+                              const uint64_t* const* d_toff, const float* const* d_sx, const float* const* d_sy,
+                              const uint64_t* const* d_soff, const double* const* d_init, const size_t* n_pairs,
+                              ndt2d_result** d_results_all, size_t* shard_stride, ndt2d_result* results);
 /* The split ndt2d_multi_align uses: shard d owns pairs [shard_begin[d], shard_begin[d+1]);
  * shard_begin has n_shards + 1 entries.  Work of a pair = 3 x target points + iterations_hint x
  * source points (iterations_hint <= 0: 30).  Needs no device. */

@@ -300,6 +300,39 @@ class NdtMultiHip {
                                });
   }
 
+  // Shards already resident on their devices (one DeviceShard per context, in context order; the
+  // pointers are device pointers laid out as ndt2d_batch_align_dev takes them).  Every context aligns
+  // its shard, the result rows are exchanged with one RCCL all-gather on the contexts' streams
+  // (ndt2d_multi_align_dev), and the rows come back in global pair order.
+  struct DeviceShard {
+    const float* tx = nullptr; const float* ty = nullptr; const uint64_t* toff = nullptr;
+    const float* sx = nullptr; const float* sy = nullptr; const uint64_t* soff = nullptr;
+    const double* init = nullptr;
+    size_t n_pairs = 0;
+  };
+  std::vector<MatchResult> alignDev(const std::vector<DeviceShard>& shards) {
+    const size_t nd = shards.size();
+    std::vector<const float*> tx(nd), ty(nd), sx(nd), sy(nd);
+    std::vector<const uint64_t*> toff(nd), soff(nd);
+    std::vector<const double*> init(nd);
+    std::vector<size_t> n(nd);
+    size_t total = 0;
+    for (size_t d = 0; d < nd; ++d) {
+      tx[d] = shards[d].tx; ty[d] = shards[d].ty; toff[d] = shards[d].toff; sx[d] = shards[d].sx; sy[d] = shards[d].sy;
+      soff[d] = shards[d].soff; init[d] = shards[d].init; n[d] = shards[d].n_pairs;
+      total += n[d];
+    }
+    if (static_cast<int>(nd) != deviceCount()) throw NdtError(NDT_ERR_INVALID_ARG, "NdtMultiHip::alignDev: one shard per device");
+    std::vector<ndt2d_result> rows(total);
+    const int32_t st = ndt2d_multi_align_dev(m_, tx.data(), ty.data(), toff.data(), sx.data(), sy.data(), soff.data(),
+                                             init.data(), n.data(), nullptr, nullptr, rows.data());
+    if (st < 0) throw NdtError(st, "ndt2d_multi_align_dev");
+    std::vector<MatchResult> out;
+    out.reserve(total);
+    for (const ndt2d_result& r : rows) out.push_back(to_match_result(r));
+    return out;
+  }
+
  private:
   ndt2d_multi* m_ = nullptr;
 };

@@ -262,3 +262,26 @@ def test_small_pair_variant_equals_large_variant_and_oracle(gpu_lib):
     for a, b in zip(pyr, pyr_l):
         assert a.status == b.status and abs(a.iterations - b.iterations) <= 3
         assert np.abs(np.array(a.pose) - np.array(b.pose)).max() < 2e-5
+
+
+def test_multi_device_context_with_rccl_gather(gpu_lib, pairs):
+    """ndt2d_multi_align_dev: shards resident on their devices, rows exchanged by ncclAllGather on the
+    contexts' streams.  One GPU here, so one rank (the gather is a copy through RCCL); the sharding
+    arithmetic for more ranks is covered by the gloo and plan tests."""
+    import torch
+    from gtsam_ndt_amd import _lib as L, dist as nd
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMulti2D
+    t = {k: torch.from_numpy(v).cuda() for k, v in nd.pack_pairs(pairs).items()}
+    with NdtBatch2D() as b:
+        want = b.decode(b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"]))
+    with NdtMulti2D(devices=[0]) as m:
+        got = m.align_dev([t])
+        assert m.last_shard_stride == len(pairs)
+        again = m.align_dev([t])                      # communicator and buffers are reused
+    for a, b_, c in zip(got, want, again):
+        assert a.status == 0 and a.pose == b_.pose == c.pose and a.iterations == b_.iterations
+        assert np.array_equal(a.H, b_.H)
+    with NdtMulti2D(devices=[0, 0]) as m:             # a device cannot gather with itself
+        with pytest.raises(L.NdtError) as e:
+            m.align_dev([t, None])
+        assert e.value.code == L.NDT_ERR_INVALID_ARG
