@@ -513,6 +513,25 @@ int32_t ndt_magnusson_constants(double outlier_ratio, double cell_size, int32_t 
   return NDT_OK;
 }
 
+int32_t ndt2d_calibrated_covariance(const double H[9], int32_t hessian_mode, double cov[9]) {
+  if (!H || !cov || (hessian_mode != NDT_HESSIAN_GAUSS_NEWTON && hessian_mode != NDT_HESSIAN_NEWTON)) return NDT_ERR_INVALID_ARG;
+  for (int i = 0; i < 9; ++i) cov[i] = 0.0;
+  // symmetric 3x3 inverse by cofactors, positive definiteness by the leading minors
+  const double a = H[0], b = 0.5 * (H[1] + H[3]), c = 0.5 * (H[2] + H[6]), d = H[4], e = 0.5 * (H[5] + H[7]), f = H[8];
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  if (!(a > 0.0) || !(a * d - b * b > 0.0) || !(det > 0.0) || !std::isfinite(det)) return NDT_DEGENERATE_HESSIAN;
+  const bool newton = hessian_mode == NDT_HESSIAN_NEWTON;
+  const double st = std::sqrt(newton ? NDT_COV_SCALE_NEWTON_TRANS : NDT_COV_SCALE_GN_TRANS);
+  const double sr = std::sqrt(newton ? NDT_COV_SCALE_NEWTON_ROT : NDT_COV_SCALE_GN_ROT);
+  const double S[3] = {st, st, sr};
+  const double inv[9] = {c00 / det, c01 / det, c02 / det, c01 / det, (a * f - c * c) / det, (b * c - a * e) / det,
+                         c02 / det, (b * c - a * e) / det, (a * d - b * b) / det};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) cov[3 * i + j] = S[i] * inv[3 * i + j] * S[j];
+  return NDT_OK;
+}
+
 int32_t ndt2d_polar_to_points_dev(const float* d_ranges, size_t n, double angle_min, double angle_inc,
                                   double range_min, double range_max, float* d_x, float* d_y, void* stream) {
   if (!d_ranges || !d_x || !d_y || n == 0 || !std::isfinite(angle_min) || !std::isfinite(angle_inc))

@@ -34,9 +34,18 @@ class AlignResult:
     def converged(self) -> bool:
         return self.status == L.NDT_OK
 
-    def covariance(self) -> np.ndarray:
-        """H^-1: the covariance a BetweenFactor noise model would be built from."""
-        return np.linalg.inv(self.H)
+    def covariance(self, hessian_mode: int = L.HESSIAN_GAUSS_NEWTON) -> np.ndarray:
+        """The calibrated pose covariance a BetweenFactor noise model is built from
+        (ndt2d_calibrated_covariance: S H^-1 S, factors from the Monte-Carlo calibration;
+        hessian_mode = the form of H, i.e. the matcher's hessian_mode).  H^-1 alone underestimates
+        the scatter of the estimate 3 to 4 times in standard deviation."""
+        H = np.ascontiguousarray(self.H, dtype=np.float64)
+        cov = np.zeros(9, dtype=np.float64)
+        st = L.load().ndt2d_calibrated_covariance(H.ctypes.data_as(C.POINTER(C.c_double)), int(hessian_mode),
+                                                  cov.ctypes.data_as(C.POINTER(C.c_double)))
+        if st != L.NDT_OK:
+            raise np.linalg.LinAlgError("Hessian is not positive definite")
+        return cov.reshape(3, 3)
 
 
 def default_params(**overrides) -> L.Params2D:

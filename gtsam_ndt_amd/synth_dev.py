@@ -59,12 +59,19 @@ def room_scene(seed: int, L: float, x0: float = 0.0, y0: float = 0.0) -> synth.S
     return synth.Scene2D(seg[:, 0].copy(), seg[:, 1].copy(), seg[:, 2].copy(), seg[:, 3].copy())
 
 
-def sample_scene(sc: synth.Scene2D, n: int, seed: int, sigma: float = 0.01, first: int = 0, pose=None, device="cuda:0"):
-    """synth.sample_scene (+ synth.to_source_frame when `pose` is given), float32, on the device."""
+def sample_scene(sc: synth.Scene2D, n: int, seed: int, sigma: float = 0.01, first: int = 0, pose=None, device="cuda:0",
+                 out=None):
+    """synth.sample_scene (+ synth.to_source_frame when `pose` is given), float32, on the device.
+    out = (x, y): contiguous float32 CUDA tensors (or slices of one) of n elements to fill."""
     import torch
     seg = np.ascontiguousarray(np.stack([sc.ax, sc.ay, sc.bx, sc.by], axis=1), dtype=np.float64)
-    x = torch.empty(n, dtype=torch.float32, device=device)
-    y = torch.empty(n, dtype=torch.float32, device=device)
+    if out is not None:
+        x, y = out
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n for t in (x, y)):
+            raise ValueError("out must be two contiguous float32 CUDA tensors of n elements")
+    else:
+        x = torch.empty(n, dtype=torch.float32, device=device)
+        y = torch.empty(n, dtype=torch.float32, device=device)
     p = cs = None
     if pose is not None:
         p = (C.c_double * 3)(*[float(v) for v in pose])

@@ -6,8 +6,9 @@
 // on the graded path.  It exists to show the complete drop-in: the iSAM2 graph, the sensor
 // drivers and the GUI glue of the reference stay untouched - only the object that produces
 // the relative pose + noise model changes.  The reference's own factor-construction code is
-// not observable (/root/reference/README.md:1), so the covariance scaling below (H^-1 times a
-// caller-chosen factor) is a documented assumption, see INTEGRATION.md section 3.
+// not observable (/root/reference/README.md:1); the noise model below is the Monte-Carlo-calibrated
+// pose covariance of ndt2d_calibrated_covariance (include/ndt_hip.h) moved
+// into the measured pose's tangent frame, see INTEGRATION.md section 3.
 #ifndef NDT_GTSAM_FACTOR_HPP_
 #define NDT_GTSAM_FACTOR_HPP_
 
@@ -24,14 +25,16 @@ namespace ndt {
 inline gtsam::Pose2 toGtsam(const Pose2& p) { return gtsam::Pose2(p.x, p.y, p.theta); }
 inline Pose2 fromGtsam(const gtsam::Pose2& p) { return Pose2{p.x(), p.y(), p.theta()}; }
 
-// covariance_scale: the NDT score Hessian is an information matrix only up to the scaling of
-// the score (d1, d2 and point density); SLAM stacks calibrate it once against odometry.
+// MatchResult::covariance is already calibrated (S H^-1 S); covariance_scale is left for a stack
+// that wants to inflate it further (e.g. for very sparse scans, where the calibration is off by up
+// to 5x).
 inline gtsam::BetweenFactor<gtsam::Pose2>::shared_ptr makeBetweenFactor(gtsam::Key target_key, gtsam::Key source_key,
                                                                        const MatchResult& m,
                                                                        double covariance_scale = 1.0) {
+  const std::array<double, 9> local = covarianceInLocalFrame(m);
   gtsam::Matrix3 cov;
   for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) cov(r, c) = covariance_scale * m.covariance[3 * r + c];
+    for (int c = 0; c < 3; ++c) cov(r, c) = covariance_scale * local[3 * r + c];
   auto noise = gtsam::noiseModel::Gaussian::Covariance(cov);
   return boost::make_shared<gtsam::BetweenFactor<gtsam::Pose2>>(target_key, source_key, toGtsam(m.pose), noise);
 }

@@ -227,6 +227,24 @@ int32_t ndt2d_wait_stream(ndt2d_handle* h, void* producer_stream);
  * sum d1' exp(-d2/2 m) with d1' = -d1 > 0, which is what is returned in *d1.  dim is 2 or 3. */
 int32_t ndt_magnusson_constants(double outlier_ratio, double cell_size, int32_t dim, double* d1, double* d2);
 
+/* Pose covariance for a factor-graph noise model from the Hessian an
+ * alignment returned: cov = S H^-1 S with S = diag(s_t, s_t, s_r).  H^-1 itself is NOT the covariance
+ * of the estimate: the score is a robust sum over cells, not a likelihood of independent points, and
+ * its piecewise-smooth surface makes the fixed point of the iteration several times more sensitive to
+ * the sampling of both scans than the local curvature says.  The factors are calibrated by Monte-Carlo
+ * over noise realisations of both scans (tests/test_gpu_covariance.py):
+ *   Gauss-Newton Hessian:  s_t^2 = 10,  s_r^2 = 18        Newton Hessian:  s_t^2 = 3.9,  s_r^2 = 7.5
+ * and put the calibrated covariance within a factor 2.5 of the empirical one (every eigenvalue of
+ * C_empirical C_calibrated^-1 in [0.4, 2.5]; the test asserts a factor 3) on scans with some 20 or more
+ * points per occupied cell; the excess over H^-1 is discretisation noise and grows as the scans get
+ * sparser (up to 5.5x off at 7 points per cell: inflate further there).  Needs no device.
+ * Returns NDT_DEGENERATE_HESSIAN (cov zeroed) when H is not positive definite. */
+#define NDT_COV_SCALE_GN_TRANS 10.0
+#define NDT_COV_SCALE_GN_ROT 18.0
+#define NDT_COV_SCALE_NEWTON_TRANS 3.9
+#define NDT_COV_SCALE_NEWTON_ROT 7.5
+int32_t ndt2d_calibrated_covariance(const double H[9], int32_t hessian_mode, double cov[9]);
+
 /* Range/bearing scan -> SoA Cartesian points on the device (the driver side of the boundary):
  * x[i] = r[i] cos(angle_min + i*angle_inc), y likewise; ranges outside [range_min, range_max]
  * or non-finite become NaN points, which every entry point of this library ignores.

@@ -29,7 +29,8 @@ struct Pose2 {           // tx, ty, theta: maps source-frame points into the tar
 struct MatchResult {
   Pose2 pose;
   std::array<double, 9> information{};   // row-major 3x3 Hessian of -score at the last evaluation
-  std::array<double, 9> covariance{};    // its inverse (zero if the Hessian is singular)
+  std::array<double, 9> covariance{};    // calibrated pose covariance S H^-1 S (ndt2d_calibrated_covariance;
+                                         // zero if the Hessian is not positive definite)
   double score = 0.0;
   int iterations = 0;
   int n_hit = 0;
@@ -61,13 +62,34 @@ inline bool invert3(const double* H, double* C) {
   return true;
 }
 
-inline MatchResult to_match_result(const ndt2d_result& r) {
+inline MatchResult to_match_result(const ndt2d_result& r, int32_t hessian_mode = NDT_HESSIAN_GAUSS_NEWTON) {
   MatchResult m;
   m.pose = {r.pose[0], r.pose[1], r.pose[2]};
   for (int i = 0; i < 9; ++i) m.information[i] = r.H[i];
-  invert3(r.H, m.covariance.data());
+  (void)ndt2d_calibrated_covariance(r.H, hessian_mode, m.covariance.data());
   m.score = r.score; m.iterations = r.iterations; m.n_hit = r.n_hit; m.status = r.status;
   return m;
+}
+
+// The calibrated covariance in the tangent frame of the measured pose, which is what a
+// gtsam::BetweenFactor<Pose2> noise model expects (its error is Logmap(measured^-1 * predicted), i.e.
+// translation errors expressed in the measured pose's own axes): C_local = A C A' with
+// A = diag(R(theta)', 1).  MatchResult::covariance itself is for additive errors on (tx, ty, theta)
+// in the target frame.
+inline std::array<double, 9> covarianceInLocalFrame(const MatchResult& m) {
+  const double c = std::cos(m.pose.theta), s = std::sin(m.pose.theta);
+  const double A[9] = {c, s, 0.0, -s, c, 0.0, 0.0, 0.0, 1.0};
+  double T[9];
+  std::array<double, 9> out{};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      T[3 * i + j] = 0.0;
+      for (int k = 0; k < 3; ++k) T[3 * i + j] += A[3 * i + k] * m.covariance[3 * k + j];
+    }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k) out[3 * i + j] += T[3 * i + k] * A[3 * j + k];
+  return out;
 }
 
 // One matcher = one device stream + one cached target grid.  Not thread-safe; use one
@@ -76,7 +98,7 @@ class NdtMatcherHip {
  public:
   static ndt2d_params defaultParams() { ndt2d_params p; ndt2d_default_params(&p); return p; }
 
-  explicit NdtMatcherHip(const ndt2d_params& params = defaultParams(), int device = 0) {
+  explicit NdtMatcherHip(const ndt2d_params& params = defaultParams(), int device = 0) : mode_(params.hessian_mode) {
     const int32_t st = ndt2d_create(&params, device, &h_);
     if (st != NDT_OK) throw NdtError(st, "ndt2d_create");
   }
@@ -113,7 +135,7 @@ class NdtMatcherHip {
     const double init[3] = {guess.x, guess.y, guess.theta};
     ndt2d_result r;
     check(ndt2d_align(h_, sx, sy, n, init, &r), "ndt2d_align");
-    return to_match_result(r);
+    return to_match_result(r, mode_);
   }
   MatchResult align(const std::vector<float>& sx, const std::vector<float>& sy, const Pose2& guess = Pose2()) {
     return align(sx.data(), sy.data(), sx.size(), guess);
@@ -128,7 +150,7 @@ class NdtMatcherHip {
     const double init[3] = {guess.x, guess.y, guess.theta};
     ndt2d_result r;
     check(ndt2d_align_dev(h_, d_sx, d_sy, n, init, &r), "ndt2d_align_dev");
-    return to_match_result(r);
+    return to_match_result(r, mode_);
   }
   // Several starts around a poor guess in one launch chain (ndt2d_align_multi_start_dev, at most 16):
   // result k is what alignDev(guesses[k]) returns; pick e.g. the best score among the converged ones.
@@ -141,7 +163,7 @@ class NdtMatcherHip {
     check(ndt2d_align_multi_start_dev(h_, d_sx, d_sy, n, init.data(), (int32_t)guesses.size(), r.data()),
           "ndt2d_align_multi_start_dev");
     std::vector<MatchResult> out;
-    for (const ndt2d_result& q : r) out.push_back(to_match_result(q));
+    for (const ndt2d_result& q : r) out.push_back(to_match_result(q, mode_));
     return out;
   }
   // one evaluation at a fixed pose, for callers with their own optimiser
@@ -156,6 +178,7 @@ class NdtMatcherHip {
  private:
   static void check(int32_t st, const char* where) { if (st < 0) throw NdtError(st, where); }
   ndt2d_handle* h_ = nullptr;
+  int32_t mode_ = NDT_HESSIAN_GAUSS_NEWTON;   // the form of the Hessian the results carry (covariance calibration)
 };
 
 // Coarse-to-fine alignment: levels of (cell multiplier, eig_ratio)
@@ -205,7 +228,7 @@ struct CloudView { const float* x; const float* y; size_t n; };
 // concatenates the pairs into the SoA + offsets form of ndt2d_batch_align / ndt2d_multi_align
 template <class Clouds, class Call>
 std::vector<MatchResult> align_pairs(const Clouds& targets, const Clouds& sources, const std::vector<Pose2>& guesses,
-                                     const char* what, Call&& call) {
+                                     const char* what, int32_t hessian_mode, Call&& call) {
   const size_t n = targets.size();
   if (sources.size() != n || guesses.size() != n || n == 0) throw NdtError(NDT_ERR_INVALID_ARG, what);
   std::vector<uint64_t> toff(n + 1, 0), soff(n + 1, 0);
@@ -224,7 +247,7 @@ std::vector<MatchResult> align_pairs(const Clouds& targets, const Clouds& source
   if (st < 0) throw NdtError(st, what);
   std::vector<MatchResult> out;
   out.reserve(n);
-  for (const auto& r : res) out.push_back(to_match_result(r));
+  for (const auto& r : res) out.push_back(to_match_result(r, hessian_mode));
   return out;
 }
 }  // namespace detail
@@ -234,12 +257,14 @@ class NdtBatchHip {
  public:
   struct Cloud { const float* x; const float* y; size_t n; };
 
-  explicit NdtBatchHip(const ndt2d_params& params = NdtMatcherHip::defaultParams(), int device = 0) {
+  explicit NdtBatchHip(const ndt2d_params& params = NdtMatcherHip::defaultParams(), int device = 0)
+      : mode_(params.hessian_mode) {
     const int32_t st = ndt2d_batch_create(&params, device, &b_);
     if (st != NDT_OK) throw NdtError(st, "ndt2d_batch_create");
   }
   // coarse-to-fine: `levels` ordered coarse to fine (see standardPyramid)
-  NdtBatchHip(const std::vector<ndt2d_params>& levels, int device) {
+  NdtBatchHip(const std::vector<ndt2d_params>& levels, int device)
+      : mode_(levels.empty() ? NDT_HESSIAN_GAUSS_NEWTON : levels.back().hessian_mode) {
     const int32_t st = ndt2d_batch_create_pyramid(levels.data(), static_cast<int32_t>(levels.size()), device, &b_);
     if (st != NDT_OK) throw NdtError(st, "ndt2d_batch_create_pyramid");
   }
@@ -256,7 +281,7 @@ class NdtBatchHip {
 
   std::vector<MatchResult> align(const std::vector<Cloud>& targets, const std::vector<Cloud>& sources,
                                  const std::vector<Pose2>& guesses) {
-    return detail::align_pairs(targets, sources, guesses, "ndt2d_batch_align",
+    return detail::align_pairs(targets, sources, guesses, "ndt2d_batch_align", mode_,
                                [&](const float* tx, const float* ty, const uint64_t* toff, const float* sx, const float* sy,
                                    const uint64_t* soff, const double* init, size_t n, ndt2d_result* res) {
                                  return ndt2d_batch_align(b_, tx, ty, toff, sx, sy, soff, init, n, res);
@@ -265,6 +290,7 @@ class NdtBatchHip {
 
  private:
   ndt2d_batch* b_ = nullptr;
+  int32_t mode_ = NDT_HESSIAN_GAUSS_NEWTON;
 };
 
 // The same over several GPUs owned by this process: pairs are split into contiguous
@@ -274,12 +300,14 @@ class NdtMultiHip {
   using Cloud = NdtBatchHip::Cloud;
 
   // devices empty = every visible device
-  explicit NdtMultiHip(const ndt2d_params& params = NdtMatcherHip::defaultParams(), const std::vector<int32_t>& devices = {}) {
+  explicit NdtMultiHip(const ndt2d_params& params = NdtMatcherHip::defaultParams(), const std::vector<int32_t>& devices = {})
+      : mode_(params.hessian_mode) {
     const int32_t st = ndt2d_multi_create(&params, devices.empty() ? nullptr : devices.data(),
                                           static_cast<int32_t>(devices.size()), &m_);
     if (st != NDT_OK) throw NdtError(st, "ndt2d_multi_create");
   }
-  NdtMultiHip(const std::vector<ndt2d_params>& levels, const std::vector<int32_t>& devices) {
+  NdtMultiHip(const std::vector<ndt2d_params>& levels, const std::vector<int32_t>& devices)
+      : mode_(levels.empty() ? NDT_HESSIAN_GAUSS_NEWTON : levels.back().hessian_mode) {
     const int32_t st = ndt2d_multi_create_pyramid(levels.data(), static_cast<int32_t>(levels.size()),
                                                   devices.empty() ? nullptr : devices.data(),
                                                   static_cast<int32_t>(devices.size()), &m_);
@@ -293,7 +321,7 @@ class NdtMultiHip {
 
   std::vector<MatchResult> align(const std::vector<Cloud>& targets, const std::vector<Cloud>& sources,
                                  const std::vector<Pose2>& guesses) {
-    return detail::align_pairs(targets, sources, guesses, "ndt2d_multi_align",
+    return detail::align_pairs(targets, sources, guesses, "ndt2d_multi_align", mode_,
                                [&](const float* tx, const float* ty, const uint64_t* toff, const float* sx, const float* sy,
                                    const uint64_t* soff, const double* init, size_t n, ndt2d_result* res) {
                                  return ndt2d_multi_align(m_, tx, ty, toff, sx, sy, soff, init, n, res);
@@ -329,12 +357,13 @@ class NdtMultiHip {
     if (st < 0) throw NdtError(st, "ndt2d_multi_align_dev");
     std::vector<MatchResult> out;
     out.reserve(total);
-    for (const ndt2d_result& r : rows) out.push_back(to_match_result(r));
+    for (const ndt2d_result& r : rows) out.push_back(to_match_result(r, mode_));
     return out;
   }
 
  private:
   ndt2d_multi* m_ = nullptr;
+  int32_t mode_ = NDT_HESSIAN_GAUSS_NEWTON;
 };
 
 // ---- 3D (SE(3), BASELINE config 5): the same shape over the ndt3d_* entry points ----------------

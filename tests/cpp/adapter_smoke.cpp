@@ -1,6 +1,7 @@
 // C++ adapter smoke test: reads two scans (raw float32 files written by the pytest driver),
 // aligns them through ndt::NdtMatcherHip / ndt::NdtBatchHip and prints the result as JSON-ish
 // text that the driver compares with the oracle.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -46,9 +47,13 @@ int main(int argc, char** argv) {
     m.setTarget(tx, ty);
     const ndt::MatchResult r = m.align(sx, sy, guess);
     std::printf("single %.17g %.17g %.17g %d %d %d\n", r.pose.x, r.pose.y, r.pose.theta, r.iterations, r.n_hit, r.status);
-    double prod = 0.0;   // information * covariance ~ identity
-    for (int k = 0; k < 3; ++k) prod += r.information[k] * r.covariance[3 * k];
+    // covariance = S H^-1 S: row 0 of (S^-1 H S^-1) times column 0 of the covariance is 1
+    const double sc[3] = {std::sqrt(NDT_COV_SCALE_GN_TRANS), std::sqrt(NDT_COV_SCALE_GN_TRANS), std::sqrt(NDT_COV_SCALE_GN_ROT)};
+    double prod = 0.0;
+    for (int k = 0; k < 3; ++k) prod += r.information[k] / (sc[0] * sc[k]) * r.covariance[3 * k];
     std::printf("infocov %.6f\n", prod);
+    const auto loc = ndt::covarianceInLocalFrame(r);   // a rotation of the translation block: trace and rotation variance unchanged
+    std::printf("localcov %.6g %.6g\n", (loc[0] + loc[4]) / (r.covariance[0] + r.covariance[4]), loc[8] / r.covariance[8]);
     ndt::NdtBatchHip b;
     const ndt::NdtBatchHip::Cloud t{tx.data(), ty.data(), tx.size()}, s{sx.data(), sy.data(), sx.size()};
     const auto rs = b.align({t, t}, {s, s}, {guess, guess});

@@ -69,6 +69,7 @@ def test_adapter_matches_oracle(exe, tmp_path, gpu_lib):
     got = [float(v) for v in lines["pyramid"][:3]]
     assert got == list(rp.pose) and int(lines["pyramid"][3]) == rp.iterations and int(lines["pyramid"][4]) == rp.status
     assert abs(float(lines["infocov"][0]) - 1.0) < 1e-6
+    assert abs(float(lines["localcov"][0]) - 1.0) < 1e-9 and abs(float(lines["localcov"][1]) - 1.0) < 1e-12
     # the 3D adapter on a self-generated room: the known motion (0.20, -0.15, 0.05, yaw 0.02) comes back
     p3 = np.array([float(v) for v in lines["three_d"][:6]])
     assert int(lines["three_d"][7]) in (0, 1)
