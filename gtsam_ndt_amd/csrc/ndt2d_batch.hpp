@@ -11,6 +11,8 @@
 // Same arithmetic as the single-pair path (shared device functions of ndt2d_kernels.hpp):
 // the LDS grid holds bit-identical records to k_accumulate/k_finalise.
 #pragma once
+#include <type_traits>
+
 #include "ndt2d_kernels.hpp"
 
 namespace ndt {
@@ -40,6 +42,10 @@ struct BatchArgs {
   int* marks;                // [n_pairs], written by the small variant for every pair: 1 = exceeds its limits,
                              // left alone; the large variant then processes exactly the marked pairs
                              // (null: every pair)
+  unsigned char* slab;       // global-memory tables of the third variant: [workgroup][BatchGlobal::kTabBytes]
+  int* fb_marks;             // [n_pairs], zeroed before the launches: the large variant sets 1 for a pair over
+                             // the on-chip capacity, the third variant processes exactly those
+                             // (null: such pairs get NDT_ERR_CAPACITY at once)
   int n_pairs;
   int min_points;
   int fixed_iterations;
@@ -58,8 +64,14 @@ struct BatchArgs {
 //          points - single lidar scans; the per-iteration fixed costs of a 16-wave workgroup (DPP
 //          trees on four waves per SIMD) are what bounds those, so this variant keeps one wave
 //          per SIMD per pair and sums through LDS (wave_reduce11_lds)
-template <int THREADS, int MAXCELLS, int MAXSLOTS, int MAXPOINTS, bool LDSSUMS, bool PACKEDCOUNT>
+template <int THREADS, int MAXCELLS, int MAXSLOTS, int MAXPOINTS, bool LDSSUMS, bool PACKEDCOUNT, bool GLOBALTABLES = false>
 struct BatchCfg {
+  // Where the grid tables (cell -> slot index, per-slot counts / keys / sums / records) live: in LDS
+  // (the two on-chip variants), or in a per-workgroup slab of global memory (the third variant, which
+  // takes the pairs whose grid does not fit on chip: 32-bit indices, records gathered through L2).
+  static constexpr bool kGlobalTables = GLOBALTABLES;
+  using IdxT = typename std::conditional<GLOBALTABLES, unsigned int, unsigned short>::type;
+  using KeyT = typename std::conditional<GLOBALTABLES, unsigned int, unsigned short>::type;
   static constexpr int kThreads = THREADS;
   static constexpr int kWaves = THREADS / 64;
   static constexpr int kMaxCells = MAXCELLS;      // dense index table
@@ -71,13 +83,18 @@ struct BatchCfg {
   // table aliased onto the sums region - what lets a 128 x 128-cell grid fit a small workgroup
   static constexpr bool kPackedCount = PACKEDCOUNT;
   static constexpr int kSlotsPerThread = (MAXSLOTS + THREADS - 1) / THREADS;
-  static constexpr int kLdsIdx = 0;                                        // u16 [MaxCells]
-  static constexpr int kLdsSlotN = kLdsIdx + MAXCELLS * 2;                 // u32 [MaxSlots]
-  static constexpr int kLdsSlotKey = kLdsSlotN + MAXSLOTS * 4;             // u16 [MaxSlots]
-  static constexpr int kLdsSums = kLdsSlotKey + MAXSLOTS * 2;              // u64 [5][MaxSlots]; aliases:
-                                                                           //   u32 cnt[MaxCells] (build)
-                                                                           //   float4 recA[MaxSlots], recB[MaxSlots]
-  static constexpr int kLdsRed = kLdsSums + 5 * MAXSLOTS * 8;              // float [Waves][kNumAcc]
+  // the tables, as byte offsets from their base (LDS, or this workgroup's slab)
+  static constexpr int kTabIdx = 0;                                                  // IdxT [MaxCells]
+  static constexpr int kTabSlotN = kTabIdx + MAXCELLS * (int)sizeof(IdxT);           // u32 [MaxSlots]
+  static constexpr int kTabSlotKey = kTabSlotN + MAXSLOTS * 4;                       // KeyT [MaxSlots]
+  static constexpr int kTabSums = (kTabSlotKey + MAXSLOTS * (int)sizeof(KeyT) + 15) / 16 * 16;   // u64 [5][MaxSlots]; aliases:
+                                                                                     //   u32 cnt[MaxCells] (build)
+                                                                                     //   float4 recA[MaxSlots], recB[MaxSlots]
+  // global tables: the records get their own region (they are written straight from the finalise loop);
+  // on chip they overwrite the sums, staged through registers
+  static constexpr int kTabRec = GLOBALTABLES ? kTabSums + 5 * MAXSLOTS * 8 : kTabSums;
+  static constexpr int kTabBytes = GLOBALTABLES ? kTabRec + 2 * MAXSLOTS * 16 : kTabSums + 5 * MAXSLOTS * 8;
+  static constexpr int kLdsRed = GLOBALTABLES ? 0 : kTabBytes;             // float [Waves][kNumAcc]
   static constexpr int kLdsBc = kLdsRed + kWaves * kNumAcc * 4;            // double [16] broadcast
   static constexpr int kLdsMisc = kLdsBc + 16 * 8;                         // int [16]
   static constexpr int kLdsScan = kLdsMisc + 16 * 4;                       // int [16]
@@ -89,12 +106,19 @@ struct BatchCfg {
   static_assert(!PACKEDCOUNT || (MAXPOINTS > 0 && MAXPOINTS < 65536), "packed counts are 16-bit");
   static_assert(MAXSLOTS * 32 <= 5 * MAXSLOTS * 8, "records must fit in the sums region");
   static_assert(kLdsBytes <= 160 * 1024, "CDNA4 LDS is 160 KiB per CU");
-  static_assert((kLdsSlotN % 16) == 0 && (kLdsSlotKey % 16) == 0 && (kLdsSums % 16) == 0 && (kLdsRed % 16) == 0 &&
+  static_assert((kTabSlotN % 16) == 0 && (kTabSlotKey % 16) == 0 && (kTabSums % 16) == 0 && (kLdsRed % 16) == 0 &&
                 (kLdsBc % 16) == 0 && (kLdsMisc % 16) == 0 && (kLdsLs % 16) == 0 && (kLdsT % 16) == 0, "16-byte aligned carve");
-  static_assert(MAXSLOTS - 1 <= 0xffff && MAXCELLS <= 0x10000, "u16 slot indices and cell keys");
+  static_assert(GLOBALTABLES || (MAXSLOTS - 1 <= 0xffff && MAXCELLS <= 0x10000), "u16 slot indices and cell keys");
+  static_assert(MAXCELLS <= (1 << 24), "24-bit key multiply");
 };
 using BatchLarge = BatchCfg<NDT_BATCH_THREADS, 16384, 2304, 0, false, false>;
 using BatchSmall = BatchCfg<256, 16384, 768, 8192, true, true>;
+// Third variant: 512 x 512 cells (256 m x 256 m at 0.5 m cells), 32767 occupied, tables in global memory.
+// It exists so that the device-pointer entry point never fails a pair a SLAM front end may legally
+// produce (a scan against a large submap); it runs on kBatchGlobalBlocks workgroups and only on the pairs
+// the large variant handed over.
+using BatchGlobal = BatchCfg<1024, 1 << 18, 32768, 0, false, false, true>;
+constexpr int kBatchGlobalBlocks = 64;
 constexpr int kBatchThreads = BatchLarge::kThreads;       // names the host code and tools/ use
 constexpr int kBatchMaxCells = BatchLarge::kMaxCells;
 constexpr int kBatchMaxSlots = BatchLarge::kMaxSlots;
@@ -136,7 +160,8 @@ __device__ __forceinline__ void write_result(ResultDev* o, const double* pose, c
 }
 
 // a4 with the record served from LDS: dense index table -> slot -> 32-byte record
-__device__ __forceinline__ void lookup_point_lds(const PoseF& P, const unsigned short* __restrict__ idx,
+template <typename IdxT>
+__device__ __forceinline__ void lookup_point_lds(const PoseF& P, const IdxT* __restrict__ idx,
                                                  const float4* __restrict__ recA,
                                                  const float4* __restrict__ recB, float x, float y, bool live,
                                                  PointRec& r) {
@@ -189,13 +214,18 @@ constexpr int kStatusCapacity = -5;   // NDT_ERR_CAPACITY: pair needs the global
 // hipcc's loop restructuring produced a kernel that re-read the same queue slot forever).
 template <int MODE, class Cfg>
 __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair, unsigned char* smem) {
-  unsigned short* idx = reinterpret_cast<unsigned short*>(smem + Cfg::kLdsIdx);
-  unsigned int* slot_n = reinterpret_cast<unsigned int*>(smem + Cfg::kLdsSlotN);
-  unsigned short* slot_key = reinterpret_cast<unsigned short*>(smem + Cfg::kLdsSlotKey);
-  unsigned long long* sums = reinterpret_cast<unsigned long long*>(smem + Cfg::kLdsSums);
-  unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + Cfg::kLdsSums);
-  float4* recA = reinterpret_cast<float4*>(smem + Cfg::kLdsSums);
-  float4* recB = reinterpret_cast<float4*>(smem + Cfg::kLdsSums + Cfg::kMaxSlots * 16);
+  using IdxT = typename Cfg::IdxT;
+  using KeyT = typename Cfg::KeyT;
+  // the grid tables: LDS, or this workgroup's slab of global memory
+  unsigned char* tab = smem;
+  if constexpr (Cfg::kGlobalTables) tab = a.slab + (size_t)blockIdx.x * Cfg::kTabBytes;
+  IdxT* idx = reinterpret_cast<IdxT*>(tab + Cfg::kTabIdx);
+  unsigned int* slot_n = reinterpret_cast<unsigned int*>(tab + Cfg::kTabSlotN);
+  KeyT* slot_key = reinterpret_cast<KeyT*>(tab + Cfg::kTabSlotKey);
+  unsigned long long* sums = reinterpret_cast<unsigned long long*>(tab + Cfg::kTabSums);
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(tab + Cfg::kTabSums);
+  float4* recA = reinterpret_cast<float4*>(tab + Cfg::kTabRec);
+  float4* recB = reinterpret_cast<float4*>(tab + Cfg::kTabRec + Cfg::kMaxSlots * 16);
   float* red = reinterpret_cast<float*>(smem + Cfg::kLdsRed);
   double* bc = reinterpret_cast<double*>(smem + Cfg::kLdsBc);
   int* misc = reinterpret_cast<int*>(smem + Cfg::kLdsMisc);
@@ -217,7 +247,7 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       const bool over = nt > Cfg::kMaxPoints || ns > Cfg::kMaxPoints;     // uniform
       if (tid == 0) a.marks[pair] = over ? 1 : 0;    // every pair passes here once: no memset of the marks
       if (over) return;
-    } else if (a.marks) {                            // the large variant after a small pass: marked pairs only
+    } else if (!Cfg::kGlobalTables && a.marks) {     // the large variant after a small pass: marked pairs only
       if (__builtin_amdgcn_readfirstlane(a.marks[pair]) == 0) return;
     }
     double pose[3] = {a.init[3 * pair], a.init[3 * pair + 1], wrap_angle(a.init[3 * pair + 2])};
@@ -282,6 +312,8 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     if (status != 0) {                               // uniform
       if (tid == 0) {
         if (Cfg::kMaxPoints > 0 && status == kStatusCapacity) a.marks[pair] = 1;   // too many cells for this variant
+        else if (!Cfg::kGlobalTables && Cfg::kMaxPoints == 0 && status == kStatusCapacity && a.fb_marks)
+          a.fb_marks[pair] = 1;                                                    // ... for the on-chip variants: third one
         else write_result(out, pose, zero6, zero6, 0.0, iter_base, 0, status);
       }
       return;
@@ -304,6 +336,8 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       }
     });
     __syncthreads();
+    // global tables: the counts were added at L2; drop what this CU's L1 still holds of the slab
+    if constexpr (Cfg::kGlobalTables) __threadfence();
     // the count of cell k, whichever table holds it (the u16 view of the packed words is idx itself)
     auto cell_count = [&](int k) -> unsigned int { return Cfg::kPackedCount ? (unsigned int)idx[k] : cnt[k]; };
 
@@ -319,6 +353,8 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     if (nslot > Cfg::kMaxSlots - 1 || nslot < 1) {   // uniform (record 0 is the dummy)
       if (tid == 0) {
         if (Cfg::kMaxPoints > 0 && nslot >= 1) a.marks[pair] = 1;                    // too many occupied cells for this variant
+        else if (!Cfg::kGlobalTables && Cfg::kMaxPoints == 0 && nslot >= 1 && a.fb_marks)
+          a.fb_marks[pair] = 1;
         else write_result(out, pose, zero6, zero6, 0.0, iter_base, 0, nslot < 1 ? 4 : kStatusCapacity);
       }
       return;
@@ -326,9 +362,9 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     for (int k = c0; k < c1; ++k) {
       const unsigned int n = cell_count(k);              // read before idx[k] is overwritten (same thread, same k)
       if (n >= (unsigned)minpts) {
-        idx[k] = (unsigned short)(s + 1);
+        idx[k] = (IdxT)(s + 1);
         slot_n[s] = n;
-        slot_key[s] = (unsigned short)k;
+        slot_key[s] = (KeyT)k;
         ++s;
       } else {
         idx[k] = 0;
@@ -359,9 +395,28 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     });
     if (tid == 0) misc[6] = 0;
     __syncthreads();
+    if constexpr (Cfg::kGlobalTables) __threadfence();       // as above, for the sums
 
-    // ---- a3: finalise (<= 3 slots per thread held in registers, then overwrite the sums)
-    {
+    // ---- a3: finalise
+    if constexpr (Cfg::kGlobalTables) {
+      int nvalid = 0;
+      for (int sl = tid; sl < nslot; sl += Cfg::kThreads) {
+        const int key = (int)slot_key[sl];
+        const int n = (int)slot_n[sl];
+        float4 ra, rb;
+        const bool ok = n <= (int)kMaxCellCount &&
+                        finalise_sums(n, (long long)sums[sl], (long long)sums[sl + Cfg::kMaxSlots],
+                                      (long long)sums[sl + 2 * Cfg::kMaxSlots], (long long)sums[sl + 3 * Cfg::kMaxSlots],
+                                      (long long)sums[sl + 4 * Cfg::kMaxSlots], cell_centre(ox, key % W, a.cell),
+                                      cell_centre(oy, key / W, a.cell), fix_scale, a.min_points, a.eig_ratio, ra, rb);
+        if (!ok) { ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = make_float4(0.f, 0.f, 0.f, 0.f); }
+        recA[sl + 1] = ra; recB[sl + 1] = rb;
+        nvalid += ok ? 1 : 0;
+      }
+      if (tid == 0) { recA[0] = make_float4(0.f, 0.f, 0.f, 0.f); recB[0] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      if (nvalid) atomicAdd(&misc[6], nvalid);
+      __syncthreads();
+    } else {   // <= 3 slots per thread held in registers, then overwrite the sums
       float4 ra[Cfg::kSlotsPerThread], rb[Cfg::kSlotsPerThread];
       int nvalid = 0;
 #pragma unroll
@@ -527,6 +582,21 @@ __global__ __launch_bounds__(Cfg::kThreads) void k_batch(BatchArgs a) {
     if (pair >= a.n_pairs) break;
     process_pair<MODE, Cfg>(a, pair, smem);
     __syncthreads();                                 // LDS is rewritten by the next pair
+  }
+}
+
+// Third variant: the pairs the large variant handed over (fb_marks), tables in global memory.  No
+// queue: workgroup b looks at pairs b, b + gridDim.x, ... (one scalar load each; with nothing handed
+// over the launch costs a few microseconds).
+template <int MODE>
+__global__ __launch_bounds__(BatchGlobal::kThreads) void k_batch_fallback(BatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  for (int pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
+    if (__builtin_amdgcn_readfirstlane(a.fb_marks[pair]) != 0) {              // uniform
+      process_pair<MODE, BatchGlobal>(a, pair, smem);
+      __syncthreads();
+      __threadfence();                                // the next pair rewrites this workgroup's slab
+    }
   }
 }
 

@@ -21,7 +21,9 @@ struct ndt2d_batch {
   size_t pcap = 0;
   std::vector<ndt2d_handle*> fallback;   // global-memory path (one handle per level) for pairs over the LDS capacity
   int* d_marks = nullptr;                // [n_pairs]: pairs the small variant left to the large one
+  int* d_fb_list = nullptr;              // [n_pairs]: marks of the pairs the large variant left to the global-table one
   size_t marks_cap = 0;
+  unsigned char* d_slab = nullptr;       // [kBatchGlobalBlocks][BatchGlobal::kTabBytes]
   bool use_small = true;                 // lidar-sized pairs run on the 256-thread variant first (ndt2d_batch_set_tuning)
   int64_t last_large = -1;               // pairs the last host-pointer call's final level ran on the large variant
 };
@@ -46,13 +48,17 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
   // the small variant keeps two workgroups resident per CU
   const size_t small_max = 2 * (size_t)b->n_cu;
   const int blocks_small = (int)(n_pairs < small_max ? n_pairs : small_max);
-  if (b->use_small && n_pairs > b->marks_cap) {
+  if (n_pairs > b->marks_cap) {
     if (b->d_marks) (void)hipFree(b->d_marks);
-    b->d_marks = nullptr; b->marks_cap = 0;
+    if (b->d_fb_list) (void)hipFree(b->d_fb_list);
+    b->d_marks = b->d_fb_list = nullptr; b->marks_cap = 0;
     const size_t want = n_pairs + n_pairs / 4 + 64;
     HIP_TRY(hipMalloc((void**)&b->d_marks, want * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&b->d_fb_list, want * sizeof(int)));
     b->marks_cap = want;
   }
+  a.slab = b->d_slab;
+  a.fb_marks = b->d_fb_list;
   // Per resolution level: the small variant takes every pair it can hold (lidar-sized scans) and
   // marks the rest, the large variant then takes exactly the marked ones.  A later level starts
   // every pair from the pose the previous one left in d_out; stream order is the only
@@ -74,6 +80,7 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
     a.prm.step_scale = p.step_scale > 0.0 ? p.step_scale : 1.0;
     const bool newton = p.hessian_mode == NDT_HESSIAN_NEWTON;
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 16, st));
+    HIP_TRY(hipMemsetAsync(b->d_fb_list, 0, n_pairs * sizeof(int), st));
     a.marks = nullptr;
     if (b->use_small) {
       a.marks = b->d_marks;
@@ -91,6 +98,13 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
       hipLaunchKernelGGL((ndt::k_batch<1, ndt::BatchLarge>), dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
     else
       hipLaunchKernelGGL((ndt::k_batch<0, ndt::BatchLarge>), dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
+    HIP_TRY(hipGetLastError());
+    // pairs whose grid does not fit on chip (handed over through fb_marks): tables in global memory
+    const int blocks_fb = (int)(n_pairs < (size_t)ndt::kBatchGlobalBlocks ? n_pairs : (size_t)ndt::kBatchGlobalBlocks);
+    if (newton)
+      hipLaunchKernelGGL((ndt::k_batch_fallback<1>), dim3(blocks_fb), dim3(ndt::BatchGlobal::kThreads), ndt::BatchGlobal::kLdsBytes, st, a);
+    else
+      hipLaunchKernelGGL((ndt::k_batch_fallback<0>), dim3(blocks_fb), dim3(ndt::BatchGlobal::kThreads), ndt::BatchGlobal::kLdsBytes, st, a);
     HIP_TRY(hipGetLastError());
   }
   return NDT_OK;
@@ -153,6 +167,7 @@ int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels,
   b->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipMalloc((void**)&b->d_queue, 16) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&b->d_slab, (size_t)ndt::kBatchGlobalBlocks * ndt::BatchGlobal::kTabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
   // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<0, ndt::BatchSmall>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::BatchSmall::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
@@ -175,7 +190,7 @@ int32_t ndt2d_batch_destroy(ndt2d_batch* b) {
   if (!b) return NDT_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* dev[] = {b->d_queue, b->d_tx, b->d_ty, b->d_sx, b->d_sy, b->d_toff, b->d_soff, b->d_init, b->d_out, b->d_marks};
+  void* dev[] = {b->d_slab, b->d_fb_list, b->d_queue, b->d_tx, b->d_ty, b->d_sx, b->d_sy, b->d_toff, b->d_soff, b->d_init, b->d_out, b->d_marks};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (ndt2d_handle* f : b->fallback) ndt2d_destroy(f);
   if (b->stream) (void)hipStreamDestroy(b->stream);

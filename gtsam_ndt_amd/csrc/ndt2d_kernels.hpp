@@ -199,12 +199,15 @@ __device__ __forceinline__ bool finalise_sums(int n, long long sx, long long sy,
   ra = make_float4(0.f, 0.f, 0.f, 0.f);
   rb = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n < min_points || n < 2) return false;
-  const double inv_s = 1.0 / fix_scale;
+  // one reciprocal per cell: r = 1 / (n S); mean = centre + Su r; 1 / (n S^2) = r^2 n.  (A reciprocal of
+  // fix_scale alone would be loop-invariant in every caller and cost a register pair held across the
+  // whole build: the 1024-thread batch kernel spilled it.)
   const double dn = (double)n;
-  const double mx = fma((double)sx / dn, inv_s, cx);
-  const double my = fma((double)sy / dn, inv_s, cy);
+  const double r = 1.0 / (dn * fix_scale);
+  const double mx = fma((double)sx, r, cx);
+  const double my = fma((double)sy, r, cy);
   // M2 = (n*Suu - Su*Su) / (n * S^2), numerator exact in 128-bit
-  const double den = 1.0 / (dn * fix_scale * fix_scale);
+  const double den = r * r * dn;
   const double m2xx = to_double(sub128(mul_s64(n, sxx), mul_s64(sx, sx))) * den;
   const double m2xy = to_double(sub128(mul_s64(n, sxy), mul_s64(sx, sy))) * den;
   const double m2yy = to_double(sub128(mul_s64(n, syy), mul_s64(sy, sy))) * den;

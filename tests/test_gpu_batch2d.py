@@ -73,8 +73,8 @@ def test_batch_ragged_and_edge_pairs(gpu_lib, pairs):
 
 
 def test_batch_capacity_fallback(gpu_lib):
-    """A target wider than the on-chip index table (here 100 m at 0.5 m cells) is re-run
-    through the global-memory path by the host-pointer entry point."""
+    """A target wider than the on-chip index table (here 200 m at 0.5 m cells) goes through the third
+    variant of the batch kernel (tables in global memory), host-pointer entry point."""
     from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMatcher2D
     d = synth.make_pair(3, n_tgt=200000, n_src=20000)       # 200 m submap: 404 x 404 cells
     small = synth.make_pair(4, pair_index=3, n_tgt=20000, n_src=20000)
@@ -84,7 +84,8 @@ def test_batch_capacity_fallback(gpu_lib):
     with NdtMatcher2D() as m:
         m.set_target(d["tx"], d["ty"])
         s = m.align(d["sx"], d["sy"], d["init"])
-    assert res[0].status == s.status == 0 and res[0].pose == s.pose
+    assert res[0].status == s.status == 0 and np.abs(np.array(res[0].pose) - np.array(s.pose)).max() < 2e-5
+    assert abs(res[0].iterations - s.iterations) <= 1 and abs(res[0].n_hit - s.n_hit) <= 2
     assert res[1].status == 0
 
 
@@ -285,3 +286,46 @@ def test_multi_device_context_with_rccl_gather(gpu_lib, pairs):
         with pytest.raises(L.NdtError) as e:
             m.align_dev([t, None])
         assert e.value.code == L.NDT_ERR_INVALID_ARG
+
+
+def test_device_entry_point_handles_pairs_over_the_on_chip_capacity(gpu_lib, pairs):
+    """ndt2d_batch_align_dev never fails a pair a front end may legally produce: a scan against a 200 m
+    submap (404 x 404 cells, far over the 128 x 128-cell LDS table) is handed, inside the same call, to the
+    third variant of the kernel (tables in global memory) and gets the single-pair path's result; a 100 m
+    room at 0.5 m cells (over 16384 cells) likewise; the lidar-sized and config-4-sized neighbours in the
+    batch are untouched.  Only a grid beyond 512 x 512 cells still reports NDT_ERR_CAPACITY."""
+    import torch
+    from gtsam_ndt_amd import _lib as L, dist as nd
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMatcher2D
+    big = synth.make_pair(3, n_tgt=300_000, n_src=30_000)                 # 200 m submap
+    sc = synth.room_scene(77, 100.0, -50.0, -50.0)                        # 100 m room: 202 x 202 cells
+    x, y = synth.sample_scene(sc, 150_000, seed=5, sigma=0.03)
+    xs, ys = synth.sample_scene(sc, 40_000, seed=6, sigma=0.03)
+    xs, ys = synth.to_source_frame(xs, ys, (0.08, -0.05, 0.008))
+    room = {"tx": x.astype(np.float32), "ty": y.astype(np.float32), "sx": xs.astype(np.float32), "sy": ys.astype(np.float32),
+            "init": (0.0, 0.0, 0.0)}
+    huge = {"tx": np.array([0.0, 0.1, 0.2, 400.0, 400.1, 400.2], np.float32), "ty": np.array([0.0, 0.1, 0.0, 300.0, 300.1, 300.0], np.float32),
+            "sx": pairs[0]["sx"][:100], "sy": pairs[0]["sy"][:100], "init": (0.0, 0.0, 0.0)}     # 802 x 602 cells
+    batch = [pairs[0], big, pairs[1], room, huge, pairs[2]]
+    t = {k: torch.from_numpy(v).cuda() for k, v in nd.pack_pairs(batch).items()}
+    for kw in (dict(), dict(fixed_iterations=9), dict(small_variant=False)):
+        with NdtBatch2D(**kw) as b:
+            rows = b.decode(b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"]))
+            again = b.decode(b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"]))
+        assert [r.pose for r in rows] == [r.pose for r in again]                 # deterministic, marks reset
+        assert rows[4].status == L.NDT_ERR_CAPACITY
+        mkw = {k: v for k, v in kw.items() if k != "small_variant"}
+        with NdtMatcher2D(**mkw) as m:
+            for k in (0, 1, 2, 3, 5):
+                p = batch[k]
+                m.set_target(p["tx"], p["ty"])
+                s = m.align(p["sx"], p["sy"], p["init"])
+                assert rows[k].status == s.status == 0 and abs(rows[k].iterations - s.iterations) <= 1, (k, rows[k], s)
+                assert np.abs(np.array(rows[k].pose) - np.array(s.pose)).max() < 2e-5, (k, rows[k].pose, s.pose)
+                assert abs(rows[k].n_hit - s.n_hit) <= 2
+    # coarse-to-fine over the same batch: every level hands the big pairs over again
+    from gtsam_ndt_amd.matcher import pyramid_params
+    with NdtBatch2D(levels=pyramid_params()) as b:
+        rows = b.decode(b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"]))
+    assert all(rows[k].status == 0 for k in (0, 1, 2, 3, 5))
+    assert np.abs(np.array(rows[1].pose) - np.array(big["pose"])).max() < 3e-3
