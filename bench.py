@@ -63,8 +63,9 @@ def parse():
     ap.add_argument("--host-path", action="store_true",
                     help="N=1: also time the host-pointer entry points (PCIe-inclusive; reported beside value)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--with-3d", action="store_true",
-                    help="N=1: also time BASELINE config 5 (3D SE(3), 131072-point pair) and report it in '3d'")
+    ap.add_argument("--with-3d", action="store_true", help="(default now) kept for old command lines")
+    ap.add_argument("--multi-starts", type=str, default="6,8,16", help="N=1: start counts of the multi-start figures")
+    ap.add_argument("--no-3d", action="store_true", help="N=1: skip BASELINE config 5 (3D SE(3), 131072-point pair)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the N>1 flow on a 1-GPU box: every rank uses cuda:0 and the result "
                          "gather runs over gloo on host copies (RCCL refuses two ranks on one device)")
@@ -115,11 +116,12 @@ def single_pair_rate(dev, dev_index, cfg: int, steps: int, warmup: int, n_src: i
     tx, ty, sx, sy = (torch.from_numpy(d[k]).to(dev) for k in ("tx", "ty", "sx", "sy"))
     with NdtMatcher2D(device=dev_index, fixed_iterations=K_GN) as m:
         m.set_target(tx, ty)
+        torch.cuda.synchronize()
         for _ in range(warmup):
-            m.align_async(sx, sy, d["init"])
+            m.align_async(sx, sy, d["init"], producer_complete=True)
         m.finish()
         t0 = time.perf_counter()
-        ev_ms = hip_events_ms(m.stream, lambda: [m.align_async(sx, sy, d["init"]) for _ in range(steps)])
+        ev_ms = hip_events_ms(m.stream, lambda: [m.align_async(sx, sy, d["init"], producer_complete=True) for _ in range(steps)])
         m.finish()
         el = time.perf_counter() - t0
     n_src = int(sx.numel())
@@ -144,15 +146,20 @@ def multi_start_rate(dev_index, tx, ty, sx, sy, init, m: int, steps: int, warmup
         for _ in range(max(1, warmup)):
             mm.align_multi_start(sx, sy, starts)
         torch.cuda.synchronize()
+        per_call = []
         t0 = time.perf_counter()
         for _ in range(steps):
+            t1 = time.perf_counter()
             r = mm.align_multi_start(sx, sy, starts)
+            per_call.append(time.perf_counter() - t1)
         el = time.perf_counter() - t0
     assert all(q.iterations == K_GN and q.status == 0 for q in r)
+    med = float(np.median(per_call))             # a call is ~0.3 ms: one host hiccup (tens of ms) would swamp a mean over few calls
     n = int(sx.numel())
-    us = 1e6 * el / (steps * (K_GN + 1))
+    us = 1e6 * med / (K_GN + 1)
     alg = n * (8 + 24 * m)                      # the points once + one 24 B record per point and start
-    return {"starts": m, "iters_per_s_aggregate": round(m * K_GN * steps / el, 1), "ms_per_call": round(1e3 * el / steps, 4),
+    return {"starts": m, "iters_per_s_aggregate": round(m * K_GN / med, 1), "ms_per_call": round(1e3 * med, 4),
+            "ms_per_call_mean": round(1e3 * el / steps, 4), "timing": f"median of {steps} calls, host call to results on the host",
             "us_per_launch_incl_call_overhead": round(us, 3), "algorithmic_bytes_per_launch": alg,
             "achieved_GBps": round(alg / us / 1e3, 1), "frac_of_8TBps": round(alg / us / 1e3 / HBM_PEAK_GBS, 4)}
 
@@ -408,9 +415,9 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=Non
 
 
 def run_3d(a, dev, dev_index):
-    """BASELINE config 5: 3D SE(3), 64 x 2048 beams, fixed 30 Gauss-Newton iterations per step.
-    Each step ends with the synchronous result fetch of ndt3d_align_dev (no async 3D entry point
-    yet), so the figure includes one host round trip per 30 iterations."""
+    """BASELINE config 5: 3D SE(3), 64 x 2048 beams, fixed 30 Gauss-Newton iterations per step, timed as the
+    2D headline is: alignments enqueued back to back (ndt3d_align_dev_async), HIP events on the handle's
+    stream over the timed region, one fetch at the end."""
     from gtsam_ndt_amd import synth3d
     from gtsam_ndt_amd.matcher import NdtMatcher3D
     d = synth3d.make_pair3d()
@@ -423,15 +430,16 @@ def run_3d(a, dev, dev_index):
             t0 = time.perf_counter(); m.set_target(*t); tg.append(time.perf_counter() - t0)
         grid_ms = 1e3 * float(np.median(tg[1:]))
         for _ in range(max(1, a.warmup)):
-            r = m.align(*s, d["init"])
+            m.align_async(*s, d["init"], producer_complete=True)
+        m.finish()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            r = m.align(*s, d["init"])
-        torch.cuda.synchronize()
+        ev_ms = hip_events_ms(m.stream, lambda: [m.align_async(*s, d["init"], producer_complete=True) for _ in range(a.steps)])
+        r = m.finish()
         el = time.perf_counter() - t0
+    assert r.iterations == K_GN and r.status == 0
     n = int(s[0].numel())
-    per_launch_us = 1e6 * el / (a.steps * (K_GN + 1))
+    per_launch_us = 1e3 * ev_ms / (a.steps * (K_GN + 1))
     alg = n * 52                                            # 12 B point + 40 B record
     return {"workload": "config5: 3D NDT SE(3), 131072-pt synthetic 64-beam scans, 1.0 m cells, fixed 30 GN iterations",
             "value": round(a.steps * K_GN / el, 1), "unit": "iters/s", "ms_per_step": round(1e3 * el / a.steps, 4),
@@ -439,7 +447,8 @@ def run_3d(a, dev, dev_index):
             "pose_after_30": list(r.pose), "true_pose": list(d["pose"]),
             "roofline": {"bound": "hbm", "kernel": "k_iterate3", "algorithmic_bytes_per_launch": alg,
                          "traffic": (load_traffic() or {}).get("bytes_per_launch_3d"),
-                         "avg_launch_us_incl_host_sync": round(per_launch_us, 3),
+                         "avg_launch_us": round(per_launch_us, 3),
+                         "timing": "HIP events on the handle's stream over the timed region / launches (kernel + launch boundary)",
                          "achieved": round(alg / (per_launch_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / (per_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
 
@@ -492,7 +501,7 @@ def main():
         n_src = int(sx.numel())
 
         def step():
-            m.align_async(sx, sy, d["init"])
+            m.align_async(sx, sy, d["init"], producer_complete=True)     # inputs resident and complete since the synchronise above
 
         for _ in range(a.warmup):
             step()
@@ -573,7 +582,7 @@ def main():
                 "note": "the same 1M-point target and 100k-point scan, m starts per launch chain (ndt2d_align_multi_start_dev); "
                         "reported beside the single-start headline, never instead of it; bytes = N x (8 + 24 m)",
                 "runs": [multi_start_rate(dev_index, tx, ty, sx, sy, d["init"], mm_, max(5, a.steps // 2), a.warmup)
-                         for mm_ in (6, 8, 16)]}
+                         for mm_ in [int(v) for v in a.multi_starts.split(",") if v]]}
         if a.host_path:
             mh = NdtMatcher2D(device=dev_index, fixed_iterations=K_GN)
             lt, la = [], []
@@ -596,7 +605,7 @@ def main():
                 # all 4096 candidates of BASELINE config 4 on this one GPU (6.55 GB resident): the
                 # anchor for reading the N > 1 lines (512 pairs per GPU) as strong scaling as well
                 out["batch_4096"] = run_batch(a, dev, dev_index, 0, 1, None, barrier, ppr=4096, steps=max(3, min(a.steps, 10)))
-        if a.with_3d or a.all_configs:
+        if not a.no_3d:
             out["3d"] = run_3d(a, dev, dev_index)
         # the other single-pair configs of BASELINE.json beside the headline (parity-test cases; cheap to time)
         if not a.headline_only:

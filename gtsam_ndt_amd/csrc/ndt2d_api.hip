@@ -42,6 +42,7 @@ struct ndt2d_handle {
   AlignDyn* d_dyn = nullptr;
   AlignStatic* h_static = nullptr;         // pinned
   hipEvent_t upload_ev = nullptr;          // recorded after the last upload from h_static
+  hipEvent_t wait_ev = nullptr;            // ndt2d_wait_stream's event
   IterState* h_state = nullptr;            // pinned
   int* h_flag = nullptr;                   // pinned: [0] raised by the launch that ends a converged-mode loop, [1] progress
   int last_parity = 0;
@@ -606,6 +607,7 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag};
   for (void* p : host) if (p) (void)hipHostFree(p);
   if (h->upload_ev) (void)hipEventDestroy(h->upload_ev);
+  if (h->wait_ev) (void)hipEventDestroy(h->wait_ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return NDT_OK;
@@ -630,7 +632,7 @@ int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value) {
 int32_t ndt2d_wait_stream(ndt2d_handle* h, void* producer_stream) {
   if (!h) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(order_after(h->stream, (hipStream_t)producer_stream));
+  HIP_TRY(order_after(h->stream, (hipStream_t)producer_stream, &h->wait_ev));
   return NDT_OK;
 }
 

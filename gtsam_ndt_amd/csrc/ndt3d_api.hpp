@@ -29,6 +29,10 @@ struct ndt3d_handle {
   ndt::ChainGraphCache graphs;
   hipGraphExec_t graph_exec = nullptr;   // selected by ensure_graph3, owned by `graphs`
   bool host_result = false;           // result already in h_state (no device work was enqueued)
+  // an alignment in flight (ndt3d_align_dev_async ... ndt3d_align_finish): 0 none, 1 fixed-K chain with
+  // the state copy enqueued behind it, 2 converged-mode chunk loop
+  int in_flight = 0;
+  ndt::ChunkRun chunk_run;
 };
 
 namespace {
@@ -170,11 +174,30 @@ int32_t ensure_graph3(ndt3d_handle* h, int launches) {
   return NDT_OK;
 }
 
-// runs the loop and leaves the final state in h->h_state
-int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n, const double* pose,
-                   int fixed_override) {
+// waits for the alignment in flight, if any; the final state is in h->h_state afterwards
+int32_t finish_align3(ndt3d_handle* h) {
+  using namespace ndt;
+  const int kind = h->in_flight;
+  h->in_flight = 0;
+  if (kind == 1) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } else if (kind == 2) {
+    bool seen = false;
+    HIP_TRY(chunk_run_finish(h->chunk_run, h->stream, h->h_flag, &seen));
+    HIP_TRY(hipGetLastError());
+    if (!seen) { ndt::set_error("the Gauss-Newton loop did not report its end"); return NDT_ERR_HIP; }
+  }
+  return NDT_OK;
+}
+
+// enqueues the loop; finish_align3 leaves the final state in h->h_state
+int32_t begin_align3(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n, const double* pose,
+                     int fixed_override) {
   using namespace ndt;
   if (!h->has_target) return NDT_ERR_NO_TARGET;
+  // a converged-mode loop needs the host to keep it fed: finish it.  A fixed-K chain in flight is
+  // simply followed on the stream (the caller gave up its result by not fetching it).
+  if (h->in_flight == 2) { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
   if (n == 0 || n > kMaxSourcePoints) return NDT_ERR_INVALID_ARG;
   if (h->n_valid < 1) {
     std::memset(h->h_state, 0, sizeof(IterState3));
@@ -190,26 +213,29 @@ int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const floa
                      pose[2], pose[3], pose[4], pose[5], fixed, fixed > 0 ? (IterState3*)nullptr : h->h_state,
                      fixed > 0 ? (int*)nullptr : h->h_flag, h->call_seq);
   const int K = fixed > 0 ? fixed : h->prm.max_iterations;
-  int last_parity;
   if (fixed > 0) {
     const int32_t gs = ensure_graph3(h, K + 1);
     if (gs != NDT_OK) return gs;
     HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
-    last_parity = K & 1;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[K & 1], sizeof(IterState3), hipMemcpyDeviceToHost, h->stream));
+    h->in_flight = 1;
   } else {
     const int chunk = 8;
     const int32_t gs = ensure_graph3(h, chunk);
     if (gs != NDT_OK) return gs;
-    bool seen = false;
-    HIP_TRY(run_chunks_until_flag(h->graph_exec, h->stream, h->h_flag, chunk, K + 1, h->call_seq, &seen));
-    HIP_TRY(hipGetLastError());
-    if (!seen) { ndt::set_error("the Gauss-Newton loop did not report its end"); return NDT_ERR_HIP; }
-    return NDT_OK;                                     // the finishing launch wrote h_state itself
+    h->chunk_run.drain = true;
+    h->chunk_run.seq = h->call_seq;
+    HIP_TRY(chunk_run_begin(h->chunk_run, h->graph_exec, h->stream, chunk, K + 1));
+    h->in_flight = 2;
   }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[last_parity], sizeof(IterState3), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
   return NDT_OK;
+}
+
+int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n, const double* pose,
+                   int fixed_override) {
+  const int32_t st = begin_align3(h, dx, dy, dz, n, pose, fixed_override);
+  return st != NDT_OK ? st : finish_align3(h);
 }
 
 void unpack_h21(const double* s, double* H) {
@@ -268,6 +294,7 @@ int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** ou
 int32_t ndt3d_destroy(ndt3d_handle* h) {
   if (!h) return NDT_OK;
   (void)hipSetDevice(h->device);
+  (void)finish_align3(h);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->graphs.clear();
   void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
@@ -291,6 +318,7 @@ int32_t ndt3d_add_target_points(ndt3d_handle* h, const float* x, const float* y,
   if (!h || !x || !y || !z || n == 0) return NDT_ERR_INVALID_ARG;
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
   const int32_t st = ensure3(h->d_t, &h->tcap, n);
   if (st != NDT_OK) return st;
   const float* src[3] = {x, y, z};
@@ -305,6 +333,7 @@ int32_t ndt3d_add_target_points(ndt3d_handle* h, const float* x, const float* y,
 int32_t ndt3d_set_target_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n, void* stream) {
   if (!h || !d_x || !d_y || !d_z || n == 0) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
   if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // producer of the device arrays
   return set_target3_impl(h, d_x, d_y, d_z, n);
 }
@@ -312,6 +341,7 @@ int32_t ndt3d_set_target_dev(ndt3d_handle* h, const float* d_x, const float* d_y
 int32_t ndt3d_set_target(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n) {
   if (!h || !x || !y || !z || n == 0) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
   const int32_t st = ensure3(h->d_t, &h->tcap, n);
   if (st != NDT_OK) return st;
   const float* src[3] = {x, y, z};
@@ -355,6 +385,7 @@ int32_t ndt3d_get_grid(ndt3d_handle* h, int32_t* count, float* mean_xyz, float* 
 }
 
 static int32_t upload_source3(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n) {
+  { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
   const int32_t st = ensure3(h->d_s, &h->scap, n);
   if (st != NDT_OK) return st;
   const float* src[3] = {sx, sy, sz};
@@ -379,11 +410,17 @@ int32_t ndt3d_evaluate(ndt3d_handle* h, const float* sx, const float* sy, const 
   return NDT_OK;
 }
 
-int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
-                        const double init_pose[6], ndt3d_result* out) {
-  if (!h || !d_sx || !d_sy || !d_sz || !init_pose || !out) return NDT_ERR_INVALID_ARG;
+int32_t ndt3d_align_dev_async(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                              const double init_pose[6]) {
+  if (!h || !d_sx || !d_sy || !d_sz || !init_pose) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  const int32_t st = run_align3(h, d_sx, d_sy, d_sz, n, init_pose, -1);
+  return begin_align3(h, d_sx, d_sy, d_sz, n, init_pose, -1);
+}
+
+int32_t ndt3d_align_finish(ndt3d_handle* h, ndt3d_result* out) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = finish_align3(h);
   if (st != NDT_OK) return st;
   const ndt::IterState3& s = *h->h_state;
   std::memset(out, 0, sizeof(*out));
@@ -391,6 +428,16 @@ int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, c
   unpack_h21(s.H, out->H);
   out->score = s.score; out->iterations = s.iter; out->n_hit = s.n_hit; out->status = s.status;
   return NDT_OK;
+}
+
+void* ndt3d_stream(ndt3d_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                        const double init_pose[6], ndt3d_result* out) {
+  if (!h || !d_sx || !d_sy || !d_sz || !init_pose || !out) return NDT_ERR_INVALID_ARG;
+  const int32_t st = ndt3d_align_dev_async(h, d_sx, d_sy, d_sz, n, init_pose);
+  if (st != NDT_OK) return st;
+  return ndt3d_align_finish(h, out);
 }
 
 int32_t ndt3d_align(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n,

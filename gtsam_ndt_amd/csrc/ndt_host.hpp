@@ -20,14 +20,20 @@ namespace ndt {
 
 // Orders everything enqueued on `consumer` from now on behind the work that is in `producer` now
 // (event record + stream wait; the host does not block).
-inline hipError_t order_after(hipStream_t consumer, hipStream_t producer) {
+// `cached` (optional): an event the caller keeps for this purpose, created on first use - a wait that
+// is already enqueued refers to the record that preceded it, so re-recording the event is safe.
+inline hipError_t order_after(hipStream_t consumer, hipStream_t producer, hipEvent_t* cached = nullptr) {
   if (producer == consumer) return hipSuccess;
-  hipEvent_t ev;
-  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-  if (e != hipSuccess) return e;
+  hipEvent_t ev = cached ? *cached : nullptr;
+  hipError_t e = hipSuccess;
+  if (!ev) {
+    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    if (cached) *cached = ev;
+  }
   e = hipEventRecord(ev, producer);
   if (e == hipSuccess) e = hipStreamWaitEvent(consumer, ev, 0);
-  (void)hipEventDestroy(ev);            // released by the runtime once the wait has been satisfied
+  if (!cached) (void)hipEventDestroy(ev);            // released by the runtime once the wait has been satisfied
   return e;
 }
 

@@ -216,12 +216,14 @@ class NdtMatcher2D:
                                                       C.cast(out, C.c_void_p)), "ndt2d_align_multi_start_dev")
         return [_to_result(r) for r in out]
 
-    def align_async(self, sx, sy, init_pose=(0.0, 0.0, 0.0)):
-        """Enqueue the whole loop on the handle's stream (device tensors only)."""
+    def align_async(self, sx, sy, init_pose=(0.0, 0.0, 0.0), producer_complete: bool = False):
+        """Enqueue the whole loop on the handle's stream (device tensors only).  producer_complete=True:
+        the caller knows the tensors are complete (their stream was synchronised), no ordering needed."""
         p = (C.c_double * 3)(*[float(v) for v in init_pose])
         n = sx.numel()
         self._keep = (sx, sy)
-        self.wait_stream()
+        if not producer_complete:
+            self.wait_stream()
         L.check(self._lib.ndt2d_align_dev_async(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), n, p),
                 "ndt2d_align_dev_async")
 
@@ -582,9 +584,34 @@ class NdtMatcher3D:
             sx, sy, sz = _host_f32(sx), _host_f32(sy), _host_f32(sz)
             st = self._lib.ndt3d_align(self._h, sx.ctypes.data, sy.ctypes.data, sz.ctypes.data, sx.size, p, C.byref(r))
         L.check(st, "ndt3d_align")
+        return self._result(r)
+
+    @staticmethod
+    def _result(r) -> AlignResult3D:
         return AlignResult3D(tuple(r.pose), np.array(r.H, dtype=np.float64).reshape(6, 6),
                              np.array(r.g, dtype=np.float64), float(r.score), int(r.iterations), int(r.n_hit),
                              int(r.status))
+
+    def align_async(self, sx, sy, sz, init_pose=(0.0,) * 6, producer_complete: bool = False):
+        """Enqueue the loop on the handle's stream (device tensors only); finish() waits and fetches."""
+        import torch
+        p = (C.c_double * 6)(*[float(v) for v in init_pose])
+        n = sx.numel()
+        self._keep = (sx, sy, sz)
+        if not producer_complete:
+            L.check(self._lib.ndt3d_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ndt3d_wait_stream")
+        L.check(self._lib.ndt3d_align_dev_async(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), _dev_ptr(sz, n), n, p),
+                "ndt3d_align_dev_async")
+
+    def finish(self) -> AlignResult3D:
+        r = L.Result3D()
+        L.check(self._lib.ndt3d_align_finish(self._h, C.byref(r)), "ndt3d_align_finish")
+        self._keep = None
+        return self._result(r)
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.ndt3d_stream(self._h) or 0)
 
 
 def magnusson_constants(outlier_ratio: float, cell_size: float, dim: int = 2):

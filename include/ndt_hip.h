@@ -380,6 +380,15 @@ int32_t ndt3d_align(ndt3d_handle* h, const float* sx, const float* sy, const flo
                     const double init_pose[6], ndt3d_result* out);
 int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
                         const double init_pose[6], ndt3d_result* out);
+/* Asynchronous form, as ndt2d_align_dev_async / ndt2d_align_finish: returns once the loop is under way
+ * on the handle's stream (with fixed_iterations > 0 the whole chain and the fetch of its final state
+ * are enqueued, so back-to-back calls keep the GPU busy without a host round trip per alignment);
+ * the d_s* arrays must stay valid until ndt3d_align_finish returns.  Any other call on the handle
+ * finishes an alignment in flight first. */
+int32_t ndt3d_align_dev_async(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                              const double init_pose[6]);
+int32_t ndt3d_align_finish(ndt3d_handle* h, ndt3d_result* out);
+void* ndt3d_stream(ndt3d_handle* h);
 /* as ndt2d_wait_stream: order the handle's stream behind the producer of the device arrays */
 int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
 

@@ -139,3 +139,25 @@ def test_pyramid3d_widens_the_basin(gpu_lib):
     assert r.status == 0 and e[:3].max() < 0.03 and e[3:].max() < 5e-3, (r.pose, d["pose"])
     ef = np.abs(np.array(flat.pose) - true)
     assert ef[:3].max() > e[:3].max()
+
+
+def test_async_entry_point_equals_the_synchronous_one(gpu_lib):
+    """ndt3d_align_dev_async / ndt3d_align_finish: fixed-K chains enqueued back to back without a host
+    round trip (the last one's result is fetched), and a converged-mode loop begun asynchronously."""
+    import torch
+    from gtsam_ndt_amd import synth3d
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    d = synth3d.make_pair3d(n_azim=512)
+    s = [torch.from_numpy(d[k]).cuda() for k in ("sx", "sy", "sz")]
+    for kw in (dict(fixed_iterations=12), dict()):
+        with NdtMatcher3D(**kw) as m:
+            m.set_target(d["tx"], d["ty"], d["tz"])
+            want = m.align(*s, d["init"])
+            for _ in range(3):
+                m.align_async(*s, d["init"])
+            got = m.finish()
+            assert got.pose == want.pose and got.iterations == want.iterations and got.status == want.status
+            assert np.array_equal(got.H, want.H)
+            m.align_async(*s, d["init"])
+            m.set_target(d["tx"], d["ty"], d["tz"])          # any other call finishes the loop in flight first
+            assert m.align(*s, d["init"]).pose == want.pose
