@@ -54,8 +54,9 @@ def parse():
     ap.add_argument("--no-batch", action="store_true", help="N=1: skip the extra loop-closure batch figure")
     ap.add_argument("--no-batch-4096", action="store_true", help="N=1: skip the full 4096-pair single-GPU batch figure")
     ap.add_argument("--headline-only", action="store_true",
-                    help="N=1: only the timed config-3 steps and the config-4 batch (a profile's kernel populations "
-                         "are then exactly the timed launches); implies --no-latency")
+                    help="N=1, for profiling: only the timed config-3 steps, the config-4 batch (512 pairs) and config 5, without "
+                         "the parity legs (converged alignment vs the oracle, batch cross-check) - a profile's kernel "
+                         "populations are then exactly the timed fixed-K launches")
     ap.add_argument("--no-latency", action="store_true",
                     help="N=1: skip the converged-mode call latency (keeps a profile's k_iterate population to the timed steps)")
     ap.add_argument("--all-configs", action="store_true",
@@ -74,6 +75,7 @@ def parse():
     a = ap.parse_args()
     if a.headline_only:
         a.no_latency = True
+        a.no_batch_4096 = True
     return a
 
 
@@ -354,8 +356,8 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=Non
     assert len(rows) == total and all(r.iterations == K_GN and r.status == 0 for r in rows)
     local = rows[mine.start: mine.stop]
     err = np.abs(np.array([r.pose for r in local]) - truth)      # vs the generating pose (sampling noise)
-    cross = cross_check_batch_rows(dev_index, t, local, ppr)
-    if dist is not None:
+    cross = cross_check_batch_rows(dev_index, t, local, ppr) if not a.headline_only else None
+    if dist is not None and cross is not None:
         for k in ("dx_m", "dy_m", "dtheta_rad"):
             cross[k] = nd.max_over_ranks(cross[k], device=dev)
     iters = total * K_GN * steps
@@ -529,31 +531,32 @@ def main():
                               "(kernel + launch boundary)"}
         # converged-pose error vs the CPU oracle (outside the timed region)
         from oracle import ndt2d as oracle
-        mc = NdtMatcher2D(device=dev_index)
-        mc.set_target(tx, ty)
-        rc = mc.align(sx, sy, d["init"])
-        # what a caller sees per scan in converged mode: host call -> result on the host
-        lat = []
-        for _ in range(0 if a.no_latency else 20):
-            t1 = time.perf_counter(); rl = mc.align(sx, sy, d["init"]); lat.append(time.perf_counter() - t1)
-            assert rl.pose == rc.pose
-        conv_ms = 1e3 * float(np.median(lat)) if lat else None
-        mc.close()
-        relaxed = None
-        if not a.no_latency:
-            # the same call with over-relaxed steps (params.step_scale = 3)
-            mr = NdtMatcher2D(device=dev_index, step_scale=3.0)
-            mr.set_target(tx, ty)
+        rc = ref = perr = conv_ms = relaxed = None
+        if not a.headline_only:
+            mc = NdtMatcher2D(device=dev_index)
+            mc.set_target(tx, ty)
+            rc = mc.align(sx, sy, d["init"])
+            # what a caller sees per scan in converged mode: host call -> result on the host
             lat = []
-            for _ in range(20):
-                t1 = time.perf_counter(); rr = mr.align(sx, sy, d["init"]); lat.append(time.perf_counter() - t1)
-            mr.close()
-            relaxed = {"step_scale": 3.0, "ms_per_call": round(1e3 * float(np.median(lat)), 4), "iterations": rr.iterations,
-                       "status": rr.status,
-                       "pose_diff_vs_plain": [abs(u - v) for u, v in zip(rr.pose, rc.pose)]}
-        prm = oracle.NdtParams()
-        ref = oracle.align(oracle.build_grid(d["tx"], d["ty"], prm), d["sx"], d["sy"], d["init"], prm)
-        perr = np.abs(np.array(rc.pose) - np.array(ref["pose"]))
+            for _ in range(0 if a.no_latency else 20):
+                t1 = time.perf_counter(); rl = mc.align(sx, sy, d["init"]); lat.append(time.perf_counter() - t1)
+                assert rl.pose == rc.pose
+            conv_ms = 1e3 * float(np.median(lat)) if lat else None
+            mc.close()
+            if not a.no_latency:
+                # the same call with over-relaxed steps (params.step_scale = 3)
+                mr = NdtMatcher2D(device=dev_index, step_scale=3.0)
+                mr.set_target(tx, ty)
+                lat = []
+                for _ in range(20):
+                    t1 = time.perf_counter(); rr = mr.align(sx, sy, d["init"]); lat.append(time.perf_counter() - t1)
+                mr.close()
+                relaxed = {"step_scale": 3.0, "ms_per_call": round(1e3 * float(np.median(lat)), 4), "iterations": rr.iterations,
+                           "status": rr.status,
+                           "pose_diff_vs_plain": [abs(u - v) for u, v in zip(rr.pose, rc.pose)]}
+            prm = oracle.NdtParams()
+            ref = oracle.align(oracle.build_grid(d["tx"], d["ty"], prm), d["sx"], d["sy"], d["init"], prm)
+            perr = np.abs(np.array(rc.pose) - np.array(ref["pose"]))
         out = {
             "metric": METRIC, "value": round(value, 1), "unit": "iters/s", "n_gpus": 1,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
@@ -565,16 +568,17 @@ def main():
                        "gn_iterations_per_step": K_GN, "hessian": "gauss-newton"},
             "roofline": roofline,
             "grid_build_ms": round(grid_ms, 4),
-            "converged_align": {"ms_per_call": None if conv_ms is None else round(conv_ms, 4), "iterations": rc.iterations,
+            "converged_align": None if rc is None else {"ms_per_call": None if conv_ms is None else round(conv_ms, 4), "iterations": rc.iterations,
                                 "note": "ndt2d_align_dev in converged mode, host call to result in host memory "
                                         "(8-launch chunks, progress and done flag written to pinned host memory); median of 20",
                                 "relaxed": relaxed},
             "scaling_note": "N=1 times the single-pair config 3 named by BASELINE.json's metric; N>1 lines time "
                             "the sharded loop-closure batch (config 4).  Read multi-GPU scaling against this "
                             "line's batch.value (same workload, one GPU), not against value.",
-            "pose_err_vs_cpu_ref": {"dx_m": float(perr[0]), "dy_m": float(perr[1]), "dtheta_rad": float(perr[2]),
-                                    "gpu_iterations": rc.iterations, "cpu_iterations": ref["iterations"],
-                                    "cpu_ref": "oracle/ndt2d.py float64 (reference implementation unavailable)"},
+            "pose_err_vs_cpu_ref": None if perr is None else {
+                "dx_m": float(perr[0]), "dy_m": float(perr[1]), "dtheta_rad": float(perr[2]),
+                "gpu_iterations": rc.iterations, "cpu_iterations": ref["iterations"],
+                "cpu_ref": "oracle/ndt2d.py float64 (reference implementation unavailable)"},
         }
         m.close()
         if not a.headline_only:

@@ -73,7 +73,7 @@ ba = traffic("BatchCfg<1024")          # the 1024-thread variant does the config
 i3 = traffic("k_iterate3")
 summary = {
     "source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes "
-              "(--kernel-trace only) of `bench.py --no-cpu-baseline --headline-only --with-3d --steps 10 --warmup 2` on one MI355X",
+              "(--kernel-trace only) of `bench.py --no-cpu-baseline --headline-only --steps 10 --warmup 2` on one MI355X",
     "units": "counter values are KiB; FETCH_SIZE scaled by the factor measured on the 1 GiB calibration reads "
              f"(tools/pmc_calib.hip): {fetch_scale:.4f} (MI355X_MICROARCH.md: gfx950 reports half of streamed "
              "reads); WRITE_SIZE taken as is (calibration: 1 GiB of stores reads 1048576 KiB)",
@@ -91,6 +91,31 @@ if ba:
     summary["batch_bytes_per_launch"] = ba["read_bytes"] + ba["write_bytes"]
 with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
     json.dump(summary, f, indent=1)
+
+# SQ pass: per kernel, the mean of each counter over its dispatches and two ratios the design notes quote
+sq_path = find("sq", "*counter_collection.csv")
+if sq_path:
+    per = defaultdict(lambda: defaultdict(list))
+    with open(sq_path, newline="") as f:
+        for row in csv.DictReader(f):
+            per[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    sq = {}
+    for k, cs in per.items():
+        if not any(t in k for t in ("k_iterate", "k_batch", "k_align_small", "k_tile")):
+            continue
+        e = {c: sum(v) / len(v) for c, v in cs.items()}
+        e["dispatches"] = len(next(iter(cs.values())))
+        if e.get("SQ_WAVE_CYCLES"):
+            e["valu_active_share_of_wave_cycles"] = e.get("SQ_ACTIVE_INST_VALU", 0.0) / e["SQ_WAVE_CYCLES"]
+            e["wait_any_share_of_wave_cycles"] = e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"]
+        if e.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_bank_conflict_share_of_lds_cycles"] = e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"]
+        if e.get("SQ_BUSY_CYCLES"):
+            e["lds_active_share_of_busy_cycles"] = e.get("SQ_LDS_IDX_ACTIVE", 0.0) / e["SQ_BUSY_CYCLES"]
+        sq[k] = e
+    with open(os.path.join(out, "sq_summary.json"), "w") as f:
+        json.dump({"source": "tools/profile_round.sh pass 5 (rocprofv3 --pmc SQ_*, --kernel-trace only); SQ_WAVE_CYCLES / SQ_WAIT_* / "
+                             "SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)", "kernels": sq}, f, indent=1)
 
 stats = find("stats", "*kernel_stats.csv")
 if stats:
