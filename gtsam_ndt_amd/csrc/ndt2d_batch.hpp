@@ -208,6 +208,8 @@ __device__ __forceinline__ void for_each_target_point(const float* tx, const flo
 }
 
 constexpr int kStatusCapacity = -5;   // NDT_ERR_CAPACITY: pair needs the global-memory path
+constexpr int kStatusInvalid = -1;    // NDT_ERR_INVALID_ARG
+constexpr int kBatchMaxCloud = 1 << 29;   // points per cloud of a pair: byte offsets into it are 32-bit (x 4 < 2^31)
 
 // One pair, start to finish, on the calling workgroup.  Early outs are plain returns: the
 // caller's queue loop then has a single back edge (with `continue`s inside the loop body
@@ -237,8 +239,17 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     // offsets and sizes are wave-uniform: keep them (and the cloud base pointers) in SGPRs so
     // that every point load is `saddr + 32-bit voffset` instead of a 64-bit VGPR address
     const unsigned long long t0 = uniform64(a.toff[pair]), s0 = uniform64(a.soff[pair]);
-    const int nt = __builtin_amdgcn_readfirstlane((int)(a.toff[pair + 1] - t0));
-    const int ns = __builtin_amdgcn_readfirstlane((int)(a.soff[pair + 1] - s0));
+    const unsigned long long nt64 = uniform64(a.toff[pair + 1]) - t0, ns64 = uniform64(a.soff[pair + 1]) - s0;
+    if (nt64 > (unsigned long long)kBatchMaxCloud || ns64 > (unsigned long long)kBatchMaxCloud) {   // uniform; also offsets out of order
+      if (tid == 0 && Cfg::kMaxPoints == 0) {
+        const double z6[6] = {0, 0, 0, 0, 0, 0};
+        const double p3[3] = {a.init[3 * pair], a.init[3 * pair + 1], a.init[3 * pair + 2]};
+        write_result(a.out + pair, p3, z6, z6, 0.0, 0, 0, kStatusInvalid);
+      }
+      if (tid == 0 && Cfg::kMaxPoints > 0) a.marks[pair] = 1;       // the small variant leaves it to the large one
+      return;
+    }
+    const int nt = (int)nt64, ns = (int)ns64;
     const float* __restrict__ tx = a.tx + t0;
     const float* __restrict__ ty = a.ty + t0;
     const float* __restrict__ sx = a.sx + s0;

@@ -13,12 +13,13 @@ struct ndt2d_batch {
   int n_cu = 0;
   unsigned int* d_queue = nullptr;
   // staging for the host-pointer entry point
+  // (one capacity per buffer: a failed allocation of one must not leave its sibling's capacity standing)
   float *d_tx = nullptr, *d_ty = nullptr, *d_sx = nullptr, *d_sy = nullptr;
-  size_t tcap = 0, scap = 0;
+  size_t cap_tx = 0, cap_ty = 0, cap_sx = 0, cap_sy = 0;
   unsigned long long *d_toff = nullptr, *d_soff = nullptr;
   double* d_init = nullptr;
   ndt2d_result* d_out = nullptr;
-  size_t pcap = 0;
+  size_t cap_toff = 0, cap_soff = 0, cap_init = 0, cap_out = 0;
   std::vector<ndt2d_handle*> fallback;   // global-memory path (one handle per level) for pairs over the LDS capacity
   int* d_marks = nullptr;                // [n_pairs]: pairs the small variant left to the large one
   int* d_fb_list = nullptr;              // [n_pairs]: marks of the pairs the large variant left to the global-table one
@@ -233,24 +234,22 @@ int32_t ndt2d_batch_align(ndt2d_batch* b, const float* tx, const float* ty, cons
                           const float* sx, const float* sy, const uint64_t* soff, const double* init,
                           size_t n_pairs, ndt2d_result* results) {
   if (!b || !tx || !ty || !toff || !sx || !sy || !soff || !init || !results || n_pairs == 0) return NDT_ERR_INVALID_ARG;
+  if (n_pairs > 0x7fffffffull) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(b->device));
   const size_t nt = toff[n_pairs], ns = soff[n_pairs];
-  for (size_t k = 0; k < n_pairs; ++k) {
-    if (toff[k + 1] < toff[k] || soff[k + 1] < soff[k] || toff[k + 1] - toff[k] > 0x7fffffffull ||
-        soff[k + 1] - soff[k] > 0x7fffffffull) return NDT_ERR_INVALID_ARG;
+  for (size_t k = 0; k < n_pairs; ++k) {      // a cloud of a pair is indexed with 32-bit byte offsets on the device
+    if (toff[k + 1] < toff[k] || soff[k + 1] < soff[k] || toff[k + 1] - toff[k] > (size_t)ndt::kBatchMaxCloud ||
+        soff[k + 1] - soff[k] > (size_t)ndt::kBatchMaxCloud) return NDT_ERR_INVALID_ARG;
   }
   int32_t st;
-  size_t c2 = b->tcap;
-  if ((st = ensure_dev(&b->d_tx, &b->tcap, nt)) != NDT_OK) return st;
-  if ((st = ensure_dev(&b->d_ty, &c2, nt)) != NDT_OK) return st;
-  c2 = b->scap;
-  if ((st = ensure_dev(&b->d_sx, &b->scap, ns)) != NDT_OK) return st;
-  if ((st = ensure_dev(&b->d_sy, &c2, ns)) != NDT_OK) return st;
-  size_t c3 = b->pcap, c4 = b->pcap, c5 = b->pcap;
-  if ((st = ensure_dev(&b->d_toff, &b->pcap, n_pairs + 1)) != NDT_OK) return st;
-  if ((st = ensure_dev(&b->d_soff, &c3, n_pairs + 1)) != NDT_OK) return st;
-  if ((st = ensure_dev(&b->d_init, &c4, 3 * (n_pairs + 1))) != NDT_OK) return st;
-  if ((st = ensure_dev(&b->d_out, &c5, n_pairs + 1)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_tx, &b->cap_tx, nt)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_ty, &b->cap_ty, nt)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_sx, &b->cap_sx, ns)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_sy, &b->cap_sy, ns)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_toff, &b->cap_toff, n_pairs + 1)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_soff, &b->cap_soff, n_pairs + 1)) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_init, &b->cap_init, 3 * (n_pairs + 1))) != NDT_OK) return st;
+  if ((st = ensure_dev(&b->d_out, &b->cap_out, n_pairs + 1)) != NDT_OK) return st;
   hipStream_t s = b->stream;
   HIP_TRY(hipMemcpyAsync(b->d_tx, tx, nt * sizeof(float), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(b->d_ty, ty, nt * sizeof(float), hipMemcpyHostToDevice, s));

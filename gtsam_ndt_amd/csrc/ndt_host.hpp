@@ -149,10 +149,11 @@ inline hipError_t spin_until(hipStream_t stream, Ready&& ready, bool* ok) {
   int syncs = 0;
   for (;;) {
     if (ready()) { *ok = true; return hipSuccess; }
+    __builtin_ia32_pause();                              // a polite spin: yields the core's issue slots to its sibling thread
     if ((++spins & 0xfffff) != 0) continue;
     const hipError_t q = hipStreamQuery(stream);
     if (q != hipSuccess && q != hipErrorNotReady) { *ok = false; return q; }
-    if ((spins >> 20) % 512 == 0) {                     // roughly every second of spinning: a real sync
+    if ((spins >> 20) % 48 == 0) {                      // roughly every second of (paused) spinning: a real sync
       const hipError_t es = hipStreamSynchronize(stream);
       if (es != hipSuccess) { *ok = false; return es; }
       if (ready()) { *ok = true; return hipSuccess; }
