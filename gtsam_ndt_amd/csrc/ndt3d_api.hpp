@@ -52,7 +52,7 @@ int32_t upload_static3(ndt3d_handle* h) {
   c->grid = h->grid;
   ndt::SolveParams& p = c->prm;
   p.d1 = (float)h->prm.d1; p.d2 = (float)h->prm.d2;
-  p.hessian_mode = 0; p.max_iterations = h->prm.max_iterations; p.min_hits = h->prm.min_hits; p.line_search = h->prm.line_search;
+  p.hessian_mode = h->prm.hessian_mode; p.max_iterations = h->prm.max_iterations; p.min_hits = h->prm.min_hits; p.line_search = h->prm.line_search;
   p.eps_trans = h->prm.eps_trans; p.eps_rot = h->prm.eps_rot;
   p.step_max_trans = h->prm.step_max_trans; p.step_max_rot = h->prm.step_max_rot;
   p.step_scale = h->prm.step_scale > 0.0 ? h->prm.step_scale : 1.0;
@@ -169,8 +169,10 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
 
 int32_t ensure_graph3(ndt3d_handle* h, int launches) {
   using namespace ndt;
-  HIP_TRY(h->graphs.get((const void*)&k_iterate3, dim3(kMaxBlocks), dim3(kBlock), (void*)h->d_static, (void*)h->d_call,
-                        (void*)h->d_dyn, launches, 0, h->stream, &h->graph_exec));
+  const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON;
+  HIP_TRY(h->graphs.get(newton ? (const void*)&k_iterate3<1> : (const void*)&k_iterate3<0>, dim3(kMaxBlocks), dim3(kBlock),
+                        (void*)h->d_static, (void*)h->d_call, (void*)h->d_dyn, launches, h->prm.hessian_mode, h->stream,
+                        &h->graph_exec));
   return NDT_OK;
 }
 
@@ -264,7 +266,6 @@ int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** ou
   const int32_t st = check_params(p);
   if (st != NDT_OK) return st;
   if (p->overlap_grids == 4) { set_error("overlapping grids are a 2D option"); return NDT_ERR_INVALID_ARG; }
-  if (p->hessian_mode != NDT_HESSIAN_GAUSS_NEWTON) { set_error("3D path implements the Gauss-Newton Hessian only"); return NDT_ERR_INVALID_ARG; }
   const int ndev = ndt_device_count();
   if (ndev <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }
   if (device_id < 0 || device_id >= ndev) return NDT_ERR_INVALID_ARG;

@@ -9,7 +9,13 @@
 namespace ndt {
 
 constexpr int kSum3RowStride = 66;
-constexpr int kNumAcc3 = 32;   // 29 used: Htt(6) Htr(9) Hrr(6) g(6) score nhit
+constexpr int kNumAcc3 = 40;   // rows of the partials table.  Gauss-Newton uses 29: Htt(6) Htr(9) Hrr(6) g(6) score nhit
+                               // (its waves own rows 8w .. 8w+7); Newton 38: + M(9) = sum w v p' (rows 10w .. 10w+9)
+template <int MODE> struct Acc3 {
+  static constexpr int kUsed = MODE == 1 ? 38 : 29;     // sums per thread
+  static constexpr int kRows = MODE == 1 ? 40 : 32;     // partial rows read back (a multiple of the 4 waves)
+  static constexpr int kRowsPerWave = kRows / 4;
+};
 
 struct CellAcc3 {   // 88 B
   long long s[3];
@@ -333,12 +339,18 @@ __device__ __forceinline__ void copy_state3(IterState3* dst, const IterState3* s
 }
 
 // ---------------------------------------------------------------------------- iterate
+// MODE 0: Gauss-Newton Hessian.  MODE 1: full Newton Hessian (Magnusson 2009, eq. 6.13): per point
+// - d2 (J'v)(J'v)' on all 21 entries, and on the rotation block v' d2p'/dp_k dp_l, which is linear in the
+// 3x3 matrix M = sum w v p' (p = the untransformed source point) - nine more sums per thread; the
+// contraction with the six second-derivative matrices of R happens once per launch, in the prologue.
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restrict__ st,
                                                       const AlignCall3* __restrict__ call,
                                                       AlignDyn3* __restrict__ dyn, int parity) {
+  constexpr int NA = Acc3<MODE>::kUsed, RPW = Acc3<MODE>::kRowsPerWave;
   __shared__ double s_red[kNumAcc3];
   __shared__ float s_wave[kBlock / 64][kNumAcc3];
-  __shared__ float s_t[kBlock / 64][29 * kSum3RowStride];
+  __shared__ float s_t[kBlock / 64][NA * kSum3RowStride];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const IterState3* prev = &dyn->state[parity ^ 1];
   IterState3* cur = &dyn->state[parity];
@@ -357,12 +369,12 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
   const float* __restrict__ sz = call->sz;
   IterState3* const host_state = call->host_state;
   int* const host_flag = call->host_flag;
-  float4 pv[8];
+  float4 pv[RPW];
   {
     const float* part = &dyn->partials[parity ^ 1][0][0];
 #pragma unroll
-    for (int v = 0; v < 8; ++v)
-      pv[v] = *reinterpret_cast<const float4*>(part + (wave * 8 + v) * kMaxBlocks + lane * 4);
+    for (int v = 0; v < RPW; ++v)
+      pv[v] = *reinterpret_cast<const float4*>(part + (wave * RPW + v) * kMaxBlocks + lane * 4);
   }
   asm volatile("" ::"s"(G.ox), "s"(G.oy), "s"(G.oz), "s"(G.inv_c), "s"(G.W), "s"(G.H), "s"(G.D), "s"(G.rec),
                "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations),
@@ -382,22 +394,30 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
   }
   int iter = ps_iter;
   if (ps_have) {
-    // this wave's 8 rows of 256 block partials -> 8 totals.  Each lane folds its 4 blocks per row in
-    // float64 and parks the 8 values in LDS ([row][lane], stride 66); lane 8v+q then adds the 8
+    // this wave's rows of 256 block partials -> their totals.  Each lane folds its 4 blocks per row in
+    // float64 and parks the values in LDS ([row][lane], stride 66); lane 8v+q then adds the 8
     // values of row v whose lane index is q mod 8 and three DPP steps fold the 8 lanes - instead of
-    // 8 float64 DPP trees (each 6 steps x 3 instructions) on the iteration's critical path.
+    // float64 DPP trees (each 6 steps x 3 instructions) on the iteration's critical path.  Eight
+    // rows per round (Gauss-Newton: one round; Newton: 10 rows, a second round of two).
     {
-      double* t = reinterpret_cast<double*>(s_t[wave]);       // 8 x 66 doubles fit in the epilogue's buffer
+      double* t = reinterpret_cast<double*>(s_t[wave]);       // RPW x 66 doubles fit in the epilogue's buffer
 #pragma unroll
-      for (int v = 0; v < 8; ++v)
+      for (int v = 0; v < RPW; ++v)
         t[v * kSum3RowStride + lane] = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
       __builtin_amdgcn_wave_barrier();
-      const double* row = t + (lane >> 3) * kSum3RowStride + (lane & 7);
-      double a = ((row[0] + row[8]) + (row[16] + row[24])) + ((row[32] + row[40]) + (row[48] + row[56]));
-      a += dpp_mov<0xB1, 0xf>(a);
-      a += dpp_mov<0x4E, 0xf>(a);
-      a += dpp_mov<0x124, 0xf>(a);                               // row_ror:4 moves data up: lane 8v+4 gets lane 8v
-      if ((lane & 7) == 4) s_red[wave * 8 + (lane >> 3)] = a;
+#pragma unroll
+      for (int base = 0; base < RPW; base += 8) {
+        const int v = base + (lane >> 3);
+        double a = 0.0;
+        if (v < RPW) {
+          const double* row = t + v * kSum3RowStride + (lane & 7);
+          a = ((row[0] + row[8]) + (row[16] + row[24])) + ((row[32] + row[40]) + (row[48] + row[56]));
+        }
+        a += dpp_mov<0xB1, 0xf>(a);
+        a += dpp_mov<0x4E, 0xf>(a);
+        a += dpp_mov<0x124, 0xf>(a);                             // row_ror:4 moves data up: lane 8v+4 gets lane 8v
+        if ((lane & 7) == 4 && v < RPW) s_red[wave * RPW + v] = a;
+      }
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -417,6 +437,51 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     for (int j = 0; j < 6; ++j) g[j] = s_red[21 + j];
     const double score = s_red[27];
     const int n_hit = (int)(s_red[28] + 0.5);
+    if (MODE == 1) {
+      // rotation block: + sum_ab (d2R / dk dl)[a][b] M[a][b], M = rows 29..37, at the pose the sums were
+      // taken at (still in `pose`).  The six second derivatives follow from R and its first derivatives:
+      // a roll derivative maps columns (1, 2) -> (col 2, -col 1), a yaw derivative rows (0, 1) ->
+      // (-row 1, row 0), and d2Ry = -Ry + e_y e_y' (oracle/ndt3d.py rot_second_derivs states the products).
+      double sa, ca, sb, cb, sg, cg;
+      sincos_wrapped(pose[3], &sa, &ca);
+      sincos_wrapped(pose[4], &sb, &cb);
+      sincos_wrapped(pose[5], &sg, &cg);
+      const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
+                           sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
+                           -sb, cb * sa, cb * ca};
+      const double Rb[9] = {-cg * sb, cg * cb * sa, cg * cb * ca, -sg * sb, sg * cb * sa, sg * cb * ca, -cb, -sb * sa, -sb * ca};
+      const double* M = &s_red[29];                            // M[3a + b] = sum w v_a p_b
+      auto cols = [&](const double* X) {                       // roll derivative of X: (0, X[:,2], -X[:,1]) . M
+        double t2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t2 += X[3 * a + 2] * M[3 * a + 1] - X[3 * a + 1] * M[3 * a + 2];
+        return t2;
+      };
+      auto rows = [&](const double* X) {                       // yaw derivative of X: (-X[1,:], X[0,:], 0) . M
+        double t2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) t2 += -X[3 + b] * M[b] + X[b] * M[3 + b];
+        return t2;
+      };
+      const double Ra[9] = {0.0, R[2], -R[1], 0.0, R[5], -R[4], 0.0, R[8], -R[7]};
+      double h_aa = 0.0, h_gg = 0.0, h_bb = 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) h_aa -= R[3 * a + 1] * M[3 * a + 1] + R[3 * a + 2] * M[3 * a + 2];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) h_gg -= R[b] * M[b] + R[3 + b] * M[3 + b];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) h_bb -= R[k] * M[k];
+      {
+        const double u[3] = {-sg, cg, 0.0}, w3[3] = {0.0, ca, -sa};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) h_bb += u[a] * w3[b] * M[3 * a + b];
+      }
+      const double h_ab = cols(Rb), h_ag = rows(Ra), h_bg = rows(Rb);
+      A[21] += h_aa; A[22] += h_ab; A[23] += h_ag; A[28] += h_bb; A[29] += h_bg; A[35] += h_gg;
+      A[27] = A[22]; A[33] = A[23]; A[34] = A[29];
+    }
     int status = 0;
     const bool done = gn_update3(pose, A, g, n_hit, iter, status, prm, fixed_iterations, score, &dyn->ls[parity ^ 1],
                                  &dyn->ls[parity], writer);
@@ -426,6 +491,9 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
         for (int j = 0; j < 6; ++j) { o->pose[j] = pose[j]; o->g[j] = g[j]; }
 #pragma unroll
         for (int j = 0; j < 21; ++j) o->H[j] = s_red[j];
+        if (MODE == 1) {                 // the stored rotation block is the full one (s_red holds it without the second derivatives)
+          o->H[15] = A[21]; o->H[16] = A[22]; o->H[17] = A[23]; o->H[18] = A[28]; o->H[19] = A[29]; o->H[20] = A[35];
+        }
         o->score = score;
         o->n_hit = n_hit; o->iter = iter; o->status = status;
         o->done = done ? 1 : 0; o->have_partials = 1; o->pad = ps_launch + 1;   // index of this launch
@@ -479,9 +547,9 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
   const float d1 = prm.d1, d2 = prm.d2;
   const float nhd2 = -0.5f * d2 * 1.44269504088896340736f;
 
-  float acc[kNumAcc3];
+  float acc[NA];
 #pragma unroll
-  for (int j = 0; j < kNumAcc3; ++j) acc[j] = 0.f;
+  for (int j = 0; j < NA; ++j) acc[j] = 0.f;
 
   while (i < n) {
     const int inext = i + stride;
@@ -517,12 +585,30 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
       U[k][1] = fmaf(cxy, J[k][0], fmaf(cyy, J[k][1], cyz * J[k][2]));
       U[k][2] = fmaf(cxz, J[k][0], fmaf(cyz, J[k][1], czz * J[k][2]));
     }
-    acc[0] = fmaf(w, cxx, acc[0]); acc[1] = fmaf(w, cxy, acc[1]); acc[2] = fmaf(w, cxz, acc[2]);
-    acc[3] = fmaf(w, cyy, acc[3]); acc[4] = fmaf(w, cyz, acc[4]); acc[5] = fmaf(w, czz, acc[5]);
+    const float v3[3] = {vx, vy, vz};
+    float tk[3];                                               // v' J_k
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tk[k] = fmaf(vx, J[k][0], fmaf(vy, J[k][1], vz * J[k][2]));
+    const float wd = MODE == 1 ? -d2 * w : 0.f;                // Newton: - d2 w (J'v)(J'v)' on every entry
+    {
+      const float cc[6] = {cxx, cxy, cxz, cyy, cyz, czz};
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) {
+          acc[q] = fmaf(w, cc[q], acc[q]);
+          if (MODE == 1) acc[q] = fmaf(wd * v3[i], v3[j], acc[q]);
+          ++q;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) acc[6 + 3 * r + k] = fmaf(w, U[k][r], acc[6 + 3 * r + k]);
+      for (int k = 0; k < 3; ++k) {
+        acc[6 + 3 * r + k] = fmaf(w, U[k][r], acc[6 + 3 * r + k]);
+        if (MODE == 1) acc[6 + 3 * r + k] = fmaf(wd * v3[r], tk[k], acc[6 + 3 * r + k]);
+      }
     {
       int q = 15;
 #pragma unroll
@@ -531,39 +617,50 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
         for (int l = k; l < 3; ++l) {
           const float h = fmaf(J[k][0], U[l][0], fmaf(J[k][1], U[l][1], J[k][2] * U[l][2]));
           acc[q] = fmaf(w, h, acc[q]);
+          if (MODE == 1) acc[q] = fmaf(wd * tk[k], tk[l], acc[q]);
           ++q;
         }
     }
     acc[21] = fmaf(w, vx, acc[21]); acc[22] = fmaf(w, vy, acc[22]); acc[23] = fmaf(w, vz, acc[23]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      acc[24 + k] = fmaf(w, fmaf(vx, J[k][0], fmaf(vy, J[k][1], vz * J[k][2])), acc[24 + k]);
+    for (int k = 0; k < 3; ++k) acc[24 + k] = fmaf(w, tk[k], acc[24 + k]);
+    if (MODE == 1) {                                           // M[a][b] += w v_a p_b (x, y, z are zero for a miss)
+      const float p3[3] = {x, y, z};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[29 + 3 * a + b] = fmaf(w * v3[a], p3[b], acc[29 + 3 * a + b]);
+    }
     acc[27] += s;
     acc[28] += hit ? 1.f : 0.f;
     x = xn; y = yn; z = zn; i = inext;
   }
 
-  // the wave's 29 sums through LDS instead of 29 DPP trees (wave_reduce11_lds of the 2D path):
+  // the wave's sums through LDS instead of one DPP tree each (wave_reduce11_lds of the 2D path):
   // park [j][lane] (row stride 66 floats), lane 2j+q adds the 32 values of accumulator j whose
-  // lane index is q mod 2 in two chains, one quad DPP step folds the pair
+  // lane index is q mod 2 in two chains, one quad DPP step folds the pair; 32 accumulators per round
   {
     float* t = s_t[wave];
 #pragma unroll
-    for (int j = 0; j < 29; ++j) t[j * kSum3RowStride + lane] = acc[j];
+    for (int j = 0; j < NA; ++j) t[j * kSum3RowStride + lane] = acc[j];
     __builtin_amdgcn_wave_barrier();
-    float a = 0.f, b = 0.f;
-    if (lane < 58) {
-      const float* row = t + (lane >> 1) * kSum3RowStride + (lane & 1);
 #pragma unroll
-      for (int k = 0; k < 32; k += 2) { a += row[2 * k]; b += row[2 * k + 2]; }
+    for (int base = 0; base < NA; base += 32) {
+      const int j = base + (lane >> 1);
+      float a = 0.f, b = 0.f;
+      if (j < NA) {
+        const float* row = t + j * kSum3RowStride + (lane & 1);
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) { a += row[2 * k]; b += row[2 * k + 2]; }
+      }
+      float v = a + b;
+      v += dpp_mov<0xB1, 0xf>(v);
+      if ((lane & 1) == 0 && j < NA) s_wave[wave][j] = v;
     }
-    float v = a + b;
-    v += dpp_mov<0xB1, 0xf>(v);
-    if ((lane & 1) == 0 && lane < 58) s_wave[wave][lane >> 1] = v;
   }
   __syncthreads();
-  if (tid < kNumAcc3) {
-    const float r = tid < 29 ? ((s_wave[0][tid] + s_wave[1][tid]) + s_wave[2][tid]) + s_wave[3][tid] : 0.f;
+  if (tid < Acc3<MODE>::kRows) {
+    const float r = tid < NA ? ((s_wave[0][tid] + s_wave[1][tid]) + s_wave[2][tid]) + s_wave[3][tid] : 0.f;
     dyn->partials[parity][tid][blockIdx.x] = r;
   }
 }

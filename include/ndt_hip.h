@@ -334,13 +334,14 @@ int32_t ndt2d_multi_plan(int32_t n_shards, const uint64_t* toff, const uint64_t*
 /* ---- 3D NDT, SE(3) (BASELINE config 5) ----------------------- */
 /* Same pipeline in 3D: dense voxel grid with per-cell mean / 3x3 covariance (eigenvalue clamp
  * by a fixed-sweep Jacobi), pose = (tx, ty, tz, roll, pitch, yaw) with R = Rz(yaw) Ry(pitch)
- * Rx(roll), 6x6 Gauss-Newton Hessian, 6-vector gradient.  ndt3d_params has the layout and
- * meaning of ndt2d_params; hessian_mode must be NDT_HESSIAN_GAUSS_NEWTON. */
+ * Rx(roll), 6x6 Hessian (Gauss-Newton, or the full Newton form of Magnusson 2009 eq. 6.13 with
+ * hessian_mode = NDT_HESSIAN_NEWTON), 6-vector gradient.  ndt3d_params has the layout and
+ * meaning of ndt2d_params (overlap_grids is a 2D option). */
 typedef ndt2d_params ndt3d_params;
 
 typedef struct ndt3d_result {
   double pose[6];     /* tx ty tz roll pitch yaw                                  */
-  double H[36];       /* row-major 6x6 Gauss-Newton Hessian at the last evaluation */
+  double H[36];       /* row-major 6x6 Hessian (the form hessian_mode selects) at the last evaluation */
   double g[6];
   double score;
   int32_t iterations, n_hit, status, reserved;

@@ -40,6 +40,7 @@ class Ndt3Params:
     min_hits: int = 6
     line_search: int = 0               # as NdtParams.line_search (oracle/ndt2d.py gn_update)
     step_scale: float = 1.0            # as NdtParams.step_scale
+    hessian_mode: int = 0              # 0: Gauss-Newton; 1: full Newton Hessian (Magnusson 2009, eq. 6.13)
 
 
 @dataclass
@@ -170,8 +171,27 @@ def rot_and_derivs(roll, pitch, yaw):
     return Rz @ Ry @ Rx, Rz @ Ry @ dRx, Rz @ dRy @ Rx, dRz @ Ry @ Rx
 
 
+def rot_second_derivs(roll, pitch, yaw):
+    """The six second derivatives of R = Rz Ry Rx: {(a, b): d2R / da db}, a <= b over (0 roll, 1 pitch, 2 yaw)."""
+    ca, sa = math.cos(roll), math.sin(roll)
+    cb, sb = math.cos(pitch), math.sin(pitch)
+    cg, sg = math.cos(yaw), math.sin(yaw)
+    Rx = np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
+    Ry = np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+    Rz = np.array([[cg, -sg, 0], [sg, cg, 0], [0, 0, 1]])
+    dRx = np.array([[0, 0, 0], [0, -sa, -ca], [0, ca, -sa]])
+    dRy = np.array([[-sb, 0, cb], [0, 0, 0], [-cb, 0, -sb]])
+    dRz = np.array([[-sg, -cg, 0], [cg, -sg, 0], [0, 0, 0]])
+    ddRx = np.array([[0, 0, 0], [0, -ca, sa], [0, -sa, -ca]])
+    ddRy = np.array([[-cb, 0, -sb], [0, 0, 0], [sb, 0, -cb]])
+    ddRz = np.array([[-cg, sg, 0], [-sg, -cg, 0], [0, 0, 0]])
+    return {(0, 0): Rz @ Ry @ ddRx, (0, 1): Rz @ dRy @ dRx, (0, 2): dRz @ Ry @ dRx,
+            (1, 1): Rz @ ddRy @ Rx, (1, 2): dRz @ dRy @ Rx, (2, 2): ddRz @ Ry @ Rx}
+
+
 def evaluate3(grid: Grid3D, sx, sy, sz, pose, prm: Ndt3Params, mirror32: bool = False):
-    """H (6x6, Gauss-Newton), g (6), score, n_hit of f = -sum d1 exp(-d2/2 q'S^-1 q)."""
+    """H (6x6; Gauss-Newton, or the full Newton Hessian with prm.hessian_mode = 1), g (6), score, n_hit
+    of f = -sum d1 exp(-d2/2 q'S^-1 q)."""
     P = np.stack([np.asarray(sx), np.asarray(sy), np.asarray(sz)], axis=1)
     R, Ra, Rb, Rg = rot_and_derivs(*pose[3:])
     t = np.array(pose[:3], dtype=np.float64)
@@ -210,6 +230,20 @@ def evaluate3(grid: Grid3D, sx, sy, sz, pose, prm: Ndt3Params, mirror32: bool = 
     J[:, :, 5] = p @ Rg.T
     g = np.einsum("n,nik,ni->k", w, J, v)
     H = np.einsum("n,nik,nij,njl->kl", w, J, C, J)
+    if prm.hessian_mode == 1:
+        # Newton: - d2 (J'v)(J'v)' per point, and v' d2p'/dp_k dp_l on the rotation block.  The latter is
+        # linear in M = sum w v p' (3x3), which is what the device accumulates: sum_ab R_kl[a,b] M[a,b].
+        Jv = np.einsum("nik,ni->nk", J, v)
+        H = H - prm.d2 * np.einsum("n,nk,nl->kl", w, Jv, Jv)
+        M = np.einsum("n,na,nb->ab", w, v, p)
+        dd = rot_second_derivs(*pose[3:])
+        if mirror32:
+            dd = {k_: m_.astype(np.float64) for k_, m_ in dd.items()}
+        for (a, b), Rab in dd.items():
+            t2 = float(np.sum(Rab * M))
+            H[3 + a, 3 + b] += t2
+            if a != b:
+                H[3 + b, 3 + a] += t2
     return H, g, float(s.sum()), int(hit.sum())
 
 

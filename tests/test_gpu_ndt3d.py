@@ -161,3 +161,41 @@ def test_async_entry_point_equals_the_synchronous_one(gpu_lib):
             m.align_async(*s, d["init"])
             m.set_target(d["tx"], d["ty"], d["tz"])          # any other call finishes the loop in flight first
             assert m.align(*s, d["init"]).pose == want.pose
+
+
+def test_newton_hessian_3d(gpu_lib, small):
+    """hessian_mode = NDT_HESSIAN_NEWTON in 3D: the evaluation against the oracle's Newton form (float32
+    mirror: tight) at poses near and 3 cm off the optimum, and Newton iterations from a start inside
+    their basin - which is millimetres wide on this score (at 1 cm the Hessian is indefinite and the
+    oracle's own Newton run wanders off), so the start is the Gauss-Newton optimum displaced by 2 mm:
+    the "polish the converged pose" use."""
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    from oracle import ndt3d as o
+    d, _, g = small
+    prm = o.Ndt3Params(hessian_mode=1)
+    gn = o.align3(g, d["sx"], d["sy"], d["sz"], d["init"], o.Ndt3Params())
+    off3 = tuple(np.array(d["pose"]) + np.array([0.03, -0.02, 0.01, 0.002, -0.002, 0.004]))
+    start = tuple(np.array(gn["pose"]) + 0.002 * np.array([1.0, -1.0, 0.5, 0.1, -0.1, 0.2]))
+    with NdtMatcher3D(hessian_mode=1) as m:
+        m.set_target(d["tx"], d["ty"], d["tz"])
+        for pose in (gn["pose"], off3):
+            H, gr, s, nh = m.evaluate(d["sx"], d["sy"], d["sz"], pose)
+            Hm, gm, sm, nm = o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose, prm, mirror32=True)
+            Hgn = o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose, o.Ndt3Params(), mirror32=True)[0]
+            assert abs(nh - nm) <= 3
+            sc = np.sqrt(np.outer(np.diag(Hgn), np.diag(Hgn)))
+            assert np.max(np.abs(H - Hm) / sc) < 3e-4
+            assert np.max(np.abs(Hm - Hgn) / sc) > 0.05                      # and it is not the Gauss-Newton one
+            assert abs(s - sm) / sm < 2e-4
+        r = m.align(d["sx"], d["sy"], d["sz"], start)
+    ref = o.align3(g, d["sx"], d["sy"], d["sz"], start, prm)
+    assert r.status == 0 == ref["status"] and ref["iterations"] <= 8 and abs(r.iterations - ref["iterations"]) <= 2
+    e = np.abs(np.array(r.pose) - np.array(ref["pose"]))
+    assert e[:3].max() < 1e-4 and e[3:].max() < 1e-4
+    assert np.abs(np.array(r.pose) - np.array(gn["pose"]))[:3].max() < 1e-4          # the same optimum as Gauss-Newton's
+    prm3 = o.Ndt3Params(hessian_mode=1, fixed_iterations=3)
+    ref3 = o.align3(g, d["sx"], d["sy"], d["sz"], start, prm3)
+    with NdtMatcher3D(hessian_mode=1, fixed_iterations=3) as m:
+        m.set_target(d["tx"], d["ty"], d["tz"])
+        r3 = m.align(d["sx"], d["sy"], d["sz"], start)
+    assert r3.iterations == 3 and np.abs(np.array(r3.pose) - np.array(ref3["pose"])).max() < 1e-4

@@ -68,3 +68,32 @@ def test_known_transform_recovery(small):
     assert e[:3].max() < 2e-2 and e[3:].max() < 3e-3
     m = o.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm, mirror32=True)
     assert np.abs(np.array(m["pose"]) - np.array(r["pose"])).max() < 1e-4
+
+
+def test_newton_hessian_matches_finite_differences_of_the_gradient(small):
+    """hessian_mode = 1: the full Newton Hessian (second derivatives of R through M = sum w v p') is the
+    derivative of the gradient; the Gauss-Newton form is not."""
+    d, _, g = small
+    prm = o.Ndt3Params(hessian_mode=1)
+    pose = np.array(d["pose"]) + np.array([0.01, -0.01, 0.005, 0.001, -0.001, 0.002])
+    H = o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose, prm)[0]
+    Hgn = o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose, o.Ndt3Params())[0]
+    h = 1e-6
+    fd = np.zeros((6, 6))
+    for k in range(6):
+        e = np.zeros(6); e[k] = h
+        fd[:, k] = (o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose + e, prm)[1]
+                    - o.evaluate3(g, d["sx"], d["sy"], d["sz"], pose - e, prm)[1]) / (2 * h)
+    assert np.allclose(H, H.T)
+    assert np.abs(H - fd).max() / np.abs(H).max() < 1e-5
+    assert np.abs(Hgn - fd).max() / np.abs(H).max() > 1e-2
+    # the structural rules the device uses for the six second derivatives of R
+    ang = (0.3, -0.2, 0.7)
+    R, Ra, Rb, Rg = o.rot_and_derivs(*ang)
+    dd = o.rot_second_derivs(*ang)
+    col = lambda M: np.stack([np.zeros(3), M[:, 2], -M[:, 1]], axis=1)
+    row = lambda M: np.stack([-M[1], M[0], np.zeros(3)], axis=0)
+    import math
+    u, w = np.array([-math.sin(ang[2]), math.cos(ang[2]), 0.0]), np.array([0.0, math.cos(ang[0]), -math.sin(ang[0])])
+    assert np.allclose(dd[(0, 0)], col(Ra)) and np.allclose(dd[(0, 1)], col(Rb)) and np.allclose(dd[(0, 2)], row(Ra))
+    assert np.allclose(dd[(1, 1)], -R + np.outer(u, w)) and np.allclose(dd[(1, 2)], row(Rb)) and np.allclose(dd[(2, 2)], row(Rg))
