@@ -197,6 +197,11 @@ int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const fl
  *   NDT_TUNE_SHORT_SCAN_KERNEL  1 (default): scans of <= 4096 points run the whole loop in one workgroup
  *   NDT_TUNE_CHUNK_LAUNCHES     converged mode: launches per graph replay, 2..128 (default 8)
  *   NDT_TUNE_BINNED_BUILD       1 (default): LDS-binned grid build; 0: scattered global atomics
+ *   NDT_TUNE_TEAM_KERNEL        0 (default): one launch per iteration (k_iterate).  1: scans between 4097 points
+ *                               and the wide threshold run the whole loop in one launch of 32-workgroup teams
+ *                               that synchronise through one XCD's L2 (a start per team in multi-start calls).
+ *                               Measured: 7.9 us per iteration against 4.6 for one start (32 CUs are too few
+ *                               for 100k points), 16 % faster than the chain at 8 starts; DESIGN.md section 5.1d
  *   NDT_TUNE_BATCH_SMALL_VARIANT (batch contexts) 1 (default): lidar-sized pairs run on the 256-thread
  *                               variant of the batch kernel first; 0: every pair on the 1024-thread one */
 enum {
@@ -205,9 +210,13 @@ enum {
   NDT_TUNE_SHORT_SCAN_KERNEL = 3,
   NDT_TUNE_CHUNK_LAUNCHES = 4,
   NDT_TUNE_BINNED_BUILD = 5,
-  NDT_TUNE_BATCH_SMALL_VARIANT = 6
+  NDT_TUNE_BATCH_SMALL_VARIANT = 6,
+  NDT_TUNE_TEAM_KERNEL = 7
 };
 int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value);
+/* Diagnostic: calls on this handle whose team kernel could not assemble its 32-workgroup teams (the GPU
+ * was busy with other work) and that were run through the launch-per-iteration path instead. */
+int64_t ndt2d_team_fallback_count(const ndt2d_handle* h);
 /* hipStream_t the handle enqueues on (as void*), for event timing by the caller */
 void* ndt2d_stream(ndt2d_handle* h);
 /* Stream ordering of the device-pointer entry points.  A handle enqueues on its own non-blocking
