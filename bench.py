@@ -65,7 +65,7 @@ def parse():
                     help="N=1: also time the host-pointer entry points (PCIe-inclusive; reported beside value)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--with-3d", action="store_true", help="(default now) kept for old command lines")
-    ap.add_argument("--multi-starts", type=str, default="6,8,16", help="N=1: start counts of the multi-start figures")
+    ap.add_argument("--multi-starts", type=str, default="8,16,64", help="N=1: start counts of the multi-start figures")
     ap.add_argument("--no-3d", action="store_true", help="N=1: skip BASELINE config 5 (3D SE(3), 131072-point pair)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the N>1 flow on a 1-GPU box: every rank uses cuda:0 and the result "

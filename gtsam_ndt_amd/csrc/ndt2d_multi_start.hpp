@@ -20,7 +20,7 @@
 
 namespace ndt {
 
-constexpr int kMaxStarts = 16;
+constexpr int kMaxStarts = 64;
 
 struct AlignDynMulti {
   IterState state[2][kMaxStarts];

@@ -210,7 +210,7 @@ class NdtMatcher2D:
         return _to_result(r)
 
     def align_multi_start(self, sx, sy, init_poses):
-        """Up to 8 alignments of the same device scan from different initial poses in one launch chain
+        """Up to 64 alignments of the same device scan from different initial poses in one launch chain
         (ndt2d_align_multi_start_dev).  Returns a list of AlignResult, one per start."""
         poses = np.ascontiguousarray(init_poses, dtype=np.float64).reshape(-1, 3)
         m = poses.shape[0]

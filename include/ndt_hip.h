@@ -178,11 +178,12 @@ int32_t ndt2d_align_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, s
 int32_t ndt2d_align_dev_async(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
                               const double init_pose[3]);
 int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out);
-/* Multi-start: m (1..16) independent alignments of the SAME scan against the cached grid from m
+/* Multi-start: m (1..64) independent alignments of the SAME scan against the cached grid from m
  * initial poses (init_poses is [m][3], host memory), carried by ONE launch chain - the source points
  * are read once per launch and every point scores against every live pose, so m alignments cost little
- * more than one (the single alignment is bound by launch latency).  For a
- * loop-closure candidate with a poor guess: several starts around it, keep the best score.
+ * more than one (the single alignment is bound by launch latency, DESIGN.md section 5.1: 8 starts cost
+ * 1.8x one, 64 starts 8x).  For a loop-closure candidate with a poor guess: a grid of starts around
+ * it, keep the best score.
  * results[k] is bit for bit what ndt2d_align_dev returns for init_poses[k] on the
  * launch-per-iteration path; a start that has finished is frozen while the others go on.
  * Synchronous in the results (host memory).  Single grid only (overlap_grids must not be 4). */

@@ -152,7 +152,7 @@ class NdtMatcherHip {
     check(ndt2d_align_dev(h_, d_sx, d_sy, n, init, &r), "ndt2d_align_dev");
     return to_match_result(r, mode_);
   }
-  // Several starts around a poor guess in one launch chain (ndt2d_align_multi_start_dev, at most 16):
+  // Several starts around a poor guess in one launch chain (ndt2d_align_multi_start_dev, at most 64):
   // result k is what alignDev(guesses[k]) returns; pick e.g. the best score among the converged ones.
   std::vector<MatchResult> alignMultiStartDev(const float* d_sx, const float* d_sy, size_t n, const std::vector<Pose2>& guesses,
                                               void* producer_stream, bool complete = false) {

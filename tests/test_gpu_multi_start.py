@@ -83,6 +83,22 @@ def test_starts_agree_with_the_oracle(gpu_lib, pair2):
         assert abs(r.iterations - ref["iterations"]) <= 3
 
 
+def test_sixty_four_starts_in_one_chain(gpu_lib, pair2):
+    """The largest call: 64 starts on a 4 x 4 x 4 lattice around the guess (16 subsets of 4 per launch);
+    a sample of them against their single-start alignments, bit for bit."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = pair2
+    sx, sy = _dev(d)
+    starts = [(d["init"][0] + 0.02 * (i - 1.5), d["init"][1] + 0.02 * (j - 1.5), 0.002 * (k - 1.5))
+              for i in range(4) for j in range(4) for k in range(4)]
+    with NdtMatcher2D(fixed_iterations=12) as mm:
+        mm.set_target(d["tx"], d["ty"])
+        multi = mm.align_multi_start(sx, sy, starts)
+        assert len(multi) == 64 and all(r.status == 0 and r.iterations == 12 for r in multi)
+        for k in (0, 7, 21, 42, 63):
+            assert _same(multi[k], mm.align(sx, sy, starts[k]))
+
+
 def test_a_start_that_misses_the_map_does_not_disturb_the_others(gpu_lib, pair2):
     from gtsam_ndt_amd import _lib as L
     from gtsam_ndt_amd.matcher import NdtMatcher2D
@@ -134,7 +150,7 @@ def test_argument_checks(gpu_lib, pair2):
         assert e.value.code == L.NDT_ERR_NO_TARGET
         mm.set_target(d["tx"], d["ty"])
         with pytest.raises(L.NdtError) as e:
-            mm.align_multi_start(sx, sy, [d["init"]] * 17)
+            mm.align_multi_start(sx, sy, [d["init"]] * 65)
         assert e.value.code == L.NDT_ERR_INVALID_ARG
     with NdtMatcher2D(overlap_grids=4) as mm:
         mm.set_target(d["tx"], d["ty"])

@@ -18,7 +18,7 @@ with NdtMatcher2D(fixed_iterations=K) as m:
     t1 = (time.perf_counter() - t0) / 50
     print(f"single: {1e6 * t1:.1f} us/call, {K / t1:.0f} it/s, {1e6 * t1 / (K + 1):.2f} us/launch")
     n = sx.numel()
-    for M in (1, 2, 4, 6, 8, 12, 16):
+    for M in (1, 2, 4, 6, 8, 16, 32, 64):
         starts = [(d["init"][0] + 0.01 * k, d["init"][1] - 0.01 * k, 0.001 * k) for k in range(M)]
         for _ in range(5):
             m.align_multi_start(sx, sy, starts)
