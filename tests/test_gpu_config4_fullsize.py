@@ -105,3 +105,36 @@ def test_batch_grid_equals_single_pair_grid_at_full_size(gpu_lib, pairs):
             assert abs(r.score - sm) / sm < 2e-5
             assert np.abs(r.H - H).max() / np.abs(H).max() < 1e-5
             assert np.abs(r.H - Hm).max() / np.abs(Hm).max() < 2e-5
+
+
+def test_wide_start_through_the_pyramid_at_full_size(gpu_lib, pairs):
+    """SURVEY.md section 8d's proposed offset, (0.30 m, -0.20 m, 0.05 rad) off the truth - outside the 0.5 m
+    grid's own basin - on full-size 100k/100k pairs: the coarse-to-fine schedule (4c, 2c, c) through the batch
+    kernel (one launch per level, poses chained on the device) and through the single-pair handles recovers
+    the pose, and both agree with the oracle running the same schedule."""
+    import torch
+    from gtsam_ndt_amd import dist as nd
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtPyramid2D, PYRAMID_LEVELS, pyramid_params
+    from oracle import ndt2d as o
+    sel = pairs[:3]
+    inits = [(p["pose"][0] - 0.30, p["pose"][1] + 0.20, p["pose"][2] - 0.05) for p in sel]
+    h = nd.pack_pairs(sel)
+    h["init"] = np.array(inits, dtype=np.float64)
+    t = {k: torch.from_numpy(v).cuda() for k, v in h.items()}
+    with NdtBatch2D(levels=pyramid_params()) as b:
+        rows = b.decode(b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"]))
+    with NdtPyramid2D() as pyr:
+        for p, init, r in zip(sel, inits, rows):
+            cur = init
+            for mult, er in PYRAMID_LEVELS:
+                prm = o.NdtParams(cell_size=0.5 * mult, eig_ratio=er, eps_trans=1e-3, eps_rot=1e-4, max_iterations=30,
+                                  step_max_trans=0.5 * mult)
+                cur = o.align(o.build_grid(p["tx"], p["ty"], prm), p["sx"], p["sy"], cur, prm)["pose"]
+            prm = o.NdtParams()
+            ref = o.align(o.build_grid(p["tx"], p["ty"], prm), p["sx"], p["sy"], cur, prm)
+            pyr.set_target(p["tx"], p["ty"])
+            s = pyr.align(p["sx"], p["sy"], init)
+            assert ref["status"] == 0 == r.status == s.status
+            assert np.abs(np.array(ref["pose"]) - np.array(p["pose"])).max() < 3e-3            # the right answer
+            assert np.abs(np.array(r.pose) - np.array(ref["pose"])).max() < 1e-4                # BASELINE.json tolerance
+            assert np.abs(np.array(s.pose) - np.array(ref["pose"])).max() < 1e-4
