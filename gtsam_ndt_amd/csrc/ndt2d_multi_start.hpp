@@ -139,7 +139,12 @@ __global__ __launch_bounds__(THREADS) void k_iterate_multi(const AlignStatic* __
 
   if (herald) {
     dyn->launch[parity] = launch;
-    if (host_flag) __hip_atomic_store(host_flag + 1, launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // progress
+    // progress, while anything is still running.  Not from the launches past the end: they may execute
+    // after the host has reset the flags for its NEXT call, and a stale progress number there makes that
+    // call's feeding loop run ahead of its own chain (found by tools/soak_round2.py: one call in a few
+    // thousand hit the loop's launch cap).
+    if (host_flag && subsets_done != (int)gridDim.y)
+      __hip_atomic_store(host_flag + 1, launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   bool sub_prev_done = true;
 #pragma unroll
