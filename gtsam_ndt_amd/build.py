@@ -25,7 +25,8 @@ HIP_SOURCES = ["ndt2d_api.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
              "-Wno-unused-function", "-fno-slp-vectorize"]
 # the multi-device gather of ndt2d_multi_align_dev calls RCCL directly (ncclCommInitAll / ncclAllGather)
-HIP_LIBS = ["-L/opt/rocm/lib", "-lrccl"]
+# ... and marks its API calls with roctx ranges (rocprofv3 --marker-trace)
+HIP_LIBS = ["-L/opt/rocm/lib", "-lrccl", "-lrocprofiler-sdk-roctx"]
 
 
 def _newer(target: str, deps: list[str]) -> bool:

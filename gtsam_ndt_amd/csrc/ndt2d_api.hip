@@ -160,6 +160,7 @@ int32_t finalise_grid(ndt2d_handle* h) {
 // the cached sums (incremental submap update) instead of starting from zero.
 int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n, bool merge,
                                 unsigned long long* h_outside) {
+  TraceRange range(merge ? "ndt2d: submap update (moments + finalise)" : "ndt2d: moments + finalise");
   GridDev& g = h->grid;
   const size_t ncell1 = (size_t)g.W * g.H, ncell = ncell1 * g.ngrid;
   const int ntx = (g.W + kTile - 1) >> kTileShift, nty = (g.H + kTile - 1) >> kTileShift;
@@ -266,6 +267,7 @@ int32_t setup_geometry(ndt2d_handle* h, float xmin, float xmax, float ymin, floa
 }
 
 int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n) {
+  TraceRange range("ndt2d_set_target: grid build");
   h->has_target = false;
   if (n == 0) return NDT_ERR_INVALID_ARG;
   // a1: bounding box on the device, geometry on the host (oracle/ndt2d.py grid_geometry)
@@ -473,6 +475,7 @@ int32_t finish_chunk_run(ndt2d_handle* h) {
 
 int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n, const double pose[3],
                   int fixed_override, int check_every, bool wait = true, bool own_source = false, bool allow_xcd = true) {
+  TraceRange range("ndt2d_align: Gauss-Newton loop");
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   const bool team = allow_xcd && n > (size_t)kSmallMaxPoints && xcd_eligible(h, n);
   if (h->xcd_run.active && team) {
@@ -584,6 +587,16 @@ void sym6_to_9(const double* s, double* H) {
   H[0] = s[0]; H[1] = s[1]; H[2] = s[3];
   H[3] = s[1]; H[4] = s[2]; H[5] = s[4];
   H[6] = s[3]; H[7] = s[4]; H[8] = s[5];
+}
+
+void state_to_result(const IterState& s, ndt2d_result* out) {
+  std::memset(out, 0, sizeof(*out));
+  for (int j = 0; j < 3; ++j) { out->pose[j] = s.pose[j]; out->g[j] = s.g[j]; }
+  sym6_to_9(s.H, out->H);
+  out->score = s.score;
+  out->iterations = s.iter;
+  out->n_hit = s.n_hit;
+  out->status = s.status;
 }
 
 }  // namespace
@@ -905,6 +918,48 @@ int32_t ndt2d_evaluate(ndt2d_handle* h, const float* sx, const float* sy, size_t
   return NDT_OK;
 }
 
+int32_t ndt2d_align_trace(ndt2d_handle* h, const float* sx, const float* sy, size_t n, const double init_pose[3],
+                          ndt2d_result* rows, int32_t capacity, int32_t* n_rows, ndt2d_result* out) {
+  if (!h || !sx || !sy || !init_pose || !rows || capacity < 1 || !n_rows || n == 0 || n > kMaxSourcePoints)
+    return NDT_ERR_INVALID_ARG;
+  *n_rows = 0;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  TraceRange range("ndt2d_align_trace");
+  HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
+  if (h->n_valid < 1) {
+    std::memset(&rows[0], 0, sizeof(ndt2d_result));
+    for (int j = 0; j < 3; ++j) rows[0].pose[j] = init_pose[j];
+    rows[0].status = NDT_TOO_FEW_CELLS;
+    if (out) *out = rows[0];
+    return NDT_OK;
+  }
+  const int32_t st = ensure_points(&h->d_sx, &h->d_sy, &h->scap, n);
+  if (st != NDT_OK) return st;
+  HIP_TRY(hipMemcpyAsync(h->d_sx, sx, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_sy, sy, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  // the launch-per-iteration kernels, one plain launch and one state fetch per iteration
+  const int fixed = h->prm.fixed_iterations;
+  const int K = fixed > 0 ? fixed : h->prm.max_iterations;
+  h->wide = h->use_wide && n >= h->wide_threshold;
+  h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, h->d_sx, h->d_sy, (int)n, init_pose[0],
+                     init_pose[1], init_pose[2], fixed, (IterState*)nullptr, (int*)nullptr, h->call_seq);
+  for (int k = 0; k <= K; ++k) {
+    launch_iter(h, blocks_for(n), k);
+    HIP_TRY(hipGetLastError());
+    if (k == 0) continue;                                  // launch 0 only evaluates
+    HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[k & 1], sizeof(IterState), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (*n_rows < capacity) state_to_result(*h->h_state, &rows[(*n_rows)++]);
+    if (h->h_state->done) break;
+  }
+  h->pending = false;
+  h->h_state->done = 2;                                     // the final state is in h_state
+  if (out) state_to_result(*h->h_state, out);
+  return NDT_OK;
+}
+
 int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out) {
   if (!h || !out) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
@@ -967,16 +1022,6 @@ const void* multi_kernel(int nh) {
   return (const void*)&k_iterate_multi<MODE, 1, THREADS>;
 }
 
-void state_to_result(const IterState& s, ndt2d_result* out) {
-  std::memset(out, 0, sizeof(*out));
-  for (int j = 0; j < 3; ++j) { out->pose[j] = s.pose[j]; out->g[j] = s.g[j]; }
-  sym6_to_9(s.H, out->H);
-  out->score = s.score;
-  out->iterations = s.iter;
-  out->n_hit = s.n_hit;
-  out->status = s.status;
-}
-
 }  // namespace
 
 extern "C" int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
@@ -985,6 +1030,7 @@ extern "C" int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_s
   if (n == 0 || n > kMaxSourcePoints) return NDT_ERR_INVALID_ARG;
   if (h->prm.overlap_grids == 4) { set_error("multi-start runs on the single grid only"); return NDT_ERR_INVALID_ARG; }
   if (!h->has_target) return NDT_ERR_NO_TARGET;
+  TraceRange range("ndt2d_align_multi_start");
   HIP_TRY(hipSetDevice(h->device));
   { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   if (h->n_valid < 1) {

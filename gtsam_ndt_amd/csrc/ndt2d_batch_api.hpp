@@ -38,6 +38,7 @@ namespace {
 int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const unsigned long long* d_toff,
                      const float* d_sx, const float* d_sy, const unsigned long long* d_soff,
                      const double* d_init, size_t n_pairs, ndt2d_result* d_out, hipStream_t st) {
+  ndt::TraceRange range("ndt2d_batch: grid build + Gauss-Newton loops on chip");
   ndt::BatchArgs a{};
   a.tx = d_tx; a.ty = d_ty; a.toff = d_toff;
   a.sx = d_sx; a.sy = d_sy; a.soff = d_soff;

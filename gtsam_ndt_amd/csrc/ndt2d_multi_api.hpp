@@ -196,6 +196,7 @@ int32_t ndt2d_multi_align_dev(ndt2d_multi* m, const float* const* d_tx, const fl
       if (bs != NDT_OK) return bs;
     }
   }
+  ndt::TraceRange range("ndt2d_multi: RCCL all-gather of the result rows");
   static_assert(sizeof(ndt2d_result) % sizeof(double) == 0, "rows travel as doubles");
   const size_t count = stride * (sizeof(ndt2d_result) / sizeof(double));
   RCCL_TRY(ncclGroupStart());

@@ -121,6 +121,7 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
 
 int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
   using namespace ndt;
+  TraceRange range("ndt3d_set_target: voxel grid build");
   h->has_target = false;
   unsigned int* hb = (unsigned int*)h->h_small;
   for (int a = 0; a < 3; ++a) { hb[2 * a] = 0xFFFFFFFFu; hb[2 * a + 1] = 0u; }
@@ -196,6 +197,7 @@ int32_t finish_align3(ndt3d_handle* h) {
 int32_t begin_align3(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n, const double* pose,
                      int fixed_override) {
   using namespace ndt;
+  TraceRange range("ndt3d_align: Gauss-Newton loop");
   if (!h->has_target) return NDT_ERR_NO_TARGET;
   // a converged-mode loop needs the host to keep it fed: finish it.  A fixed-K chain in flight is
   // simply followed on the stream (the caller gave up its result by not fetching it).

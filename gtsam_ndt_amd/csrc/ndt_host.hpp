@@ -3,6 +3,7 @@
 // cache, and the host half of the converged-mode protocol (flags in pinned host memory).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <string>
 
@@ -17,6 +18,15 @@ inline void set_error(const char* msg) { last_error() = msg ? msg : ""; }
 }  // namespace ndt
 
 namespace ndt {
+
+// roctx range over an API call (SURVEY.md section 5 "tracing"): shows up in rocprofv3 --marker-trace around
+// the kernels the call enqueues; a few nanoseconds when no profiler is attached.
+struct TraceRange {
+  explicit TraceRange(const char* name) { (void)roctxRangePushA(name); }
+  ~TraceRange() { (void)roctxRangePop(); }
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
 
 // Orders everything enqueued on `consumer` from now on behind the work that is in `producer` now
 // (event record + stream wait; the host does not block).

@@ -209,6 +209,17 @@ class NdtMatcher2D:
         L.check(st, "ndt2d_align")
         return _to_result(r)
 
+    def align_trace(self, sx, sy, init_pose=(0.0, 0.0, 0.0), capacity: int = 256):
+        """Per-iteration trace (ndt2d_align_trace; host arrays): a list of AlignResult, entry j = the state
+        after j + 1 updates (H, g, score, n_hit of the evaluation behind that update)."""
+        sx, sy = _host_f32(sx), _host_f32(sy)
+        p = (C.c_double * 3)(*[float(v) for v in init_pose])
+        rows = (L.Result2D * capacity)()
+        n_rows = C.c_int32(0)
+        L.check(self._lib.ndt2d_align_trace(self._h, sx.ctypes.data, sy.ctypes.data, sx.size, p, C.cast(rows, C.c_void_p),
+                                            capacity, C.byref(n_rows), None), "ndt2d_align_trace")
+        return [_to_result(rows[j]) for j in range(n_rows.value)]
+
     def align_multi_start(self, sx, sy, init_poses):
         """Up to 64 alignments of the same device scan from different initial poses in one launch chain
         (ndt2d_align_multi_start_dev).  Returns a list of AlignResult, one per start."""

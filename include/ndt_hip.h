@@ -178,6 +178,14 @@ int32_t ndt2d_align_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, s
 int32_t ndt2d_align_dev_async(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
                               const double init_pose[3]);
 int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out);
+/* Per-iteration trace, for debugging and stage-by-stage parity checks ("optional
+ * per-iteration trace ... copied back on request"; never on a timed path: one plain launch and one state
+ * fetch per iteration, always through the launch-per-iteration kernels).  rows[j], j < *n_rows <= capacity,
+ * is the state after j + 1 updates: pose after them, H / g / score / n_hit of the evaluation that
+ * produced the (j+1)-th update (taken at rows[j-1].pose, the initial pose for j = 0), iterations = j + 1,
+ * status.  out (may be NULL) receives the final result, as ndt2d_align returns it.  Host arrays. */
+int32_t ndt2d_align_trace(ndt2d_handle* h, const float* sx, const float* sy, size_t n, const double init_pose[3],
+                          ndt2d_result* rows, int32_t capacity, int32_t* n_rows, ndt2d_result* out);
 /* Multi-start: m (1..64) independent alignments of the SAME scan against the cached grid from m
  * initial poses (init_poses is [m][3], host memory), carried by ONE launch chain - the source points
  * are read once per launch and every point scores against every live pose, so m alignments cost little

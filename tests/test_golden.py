@@ -165,3 +165,28 @@ def test_hip_path_matches_option_golden(gold, gpu_lib):
         e = np.abs(np.array(r.pose) - opt[name + "_pose"])
         assert e.max() < 1e-4, (name, r.pose, opt[name + "_pose"])              # 1e-4 m / 1e-4 rad
         assert abs(r.iterations - its) <= 3, (name, r.iterations, its)
+
+
+@pytest.mark.gpu
+def test_hip_per_iteration_trace_follows_the_golden_trace(gold, gpu_lib):
+    """ndt2d_align_trace against the committed oracle trace of the config-1 pair, iteration by iteration:
+    hits, score, H and g of every evaluation, and the pose after every update."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    with NdtMatcher2D() as m:
+        m.set_target(gold["tx"], gold["ty"])
+        rows = m.align_trace(gold["sx"], gold["sy"], tuple(gold["init"]))
+        final = m.align(gold["sx"], gold["sy"], tuple(gold["init"]))
+    tp, tH, tg, ts, tn = gold["trace_pose"], gold["trace_H"], gold["trace_g"], gold["trace_score"], gold["trace_n_hit"]
+    assert abs(len(rows) - len(tp)) <= 3 and rows[-1].status == int(gold["final_status"])
+    # the device path (k_iterate) and the one-workgroup kernel the default call uses end at the same pose
+    assert np.abs(np.array(rows[-1].pose) - np.array(final.pose)).max() < 2e-6
+    k = min(len(rows), len(tp)) - 1
+    for j in range(k):
+        r = rows[j]
+        assert r.iterations == j + 1
+        assert abs(r.n_hit - int(tn[j])) <= 2, j                       # a boundary point may change cell in float32
+        assert abs(r.score - ts[j]) / ts[j] < 5e-3, j
+        assert np.abs(r.H - tH[j]).max() / np.abs(tH[j]).max() < 5e-3, j
+        gs = np.sqrt(np.abs(np.diag(tH[j])) * max(ts[j], 1.0))
+        assert np.max(np.abs(r.g - tg[j]) / gs) < 5e-3, j
+        assert np.abs(np.array(r.pose) - tp[j + 1]).max() < 1e-4, j    # pose after update j+1 = pose of evaluation j+1

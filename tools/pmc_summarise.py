@@ -117,6 +117,11 @@ if sq_path:
         json.dump({"source": "tools/profile_round.sh pass 5 (rocprofv3 --pmc SQ_*, --kernel-trace only); SQ_WAVE_CYCLES / SQ_WAIT_* / "
                              "SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)", "kernels": sq}, f, indent=1)
 
+mk = find("markers", "*marker_api_stats.csv") or find("markers", "*marker*stats.csv")
+if mk:
+    with open(mk) as f, open(os.path.join(out, "marker_stats.csv"), "w") as g:
+        g.write(f.read())
+
 stats = find("stats", "*kernel_stats.csv")
 if stats:
     with open(stats) as f, open(os.path.join(out, "kernel_stats.csv"), "w") as g:
