@@ -166,6 +166,45 @@ def multi_start_rate(dev_index, tx, ty, sx, sy, init, m: int, steps: int, warmup
             "achieved_GBps": round(alg / us / 1e3, 1), "frac_of_8TBps": round(alg / us / 1e3 / HBM_PEAK_GBS, 4)}
 
 
+def multi_scan_rate(dev, dev_index, tx, ty, m: int, steps: int, warmup: int, n_pts: int = 100_000):
+    """ndt2d_align_multi_scan_dev: m DIFFERENT 100k-point scans (room (2,1) of the config-3 submap, own sampling
+    seeds and poses, generated on the device) against the 1M-point target in one launch chain, fixed K
+    iterations each.  Algorithmic bytes per launch = m x N x 32 B (every scan's points and
+    records are its own).  One call = k_begin + a graph of K + 1 launches + the result fetch."""
+    from gtsam_ndt_amd import synth, synth_dev
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    L, S, tiles = 50.0, 3, 4
+    half = 0.5 * tiles * L
+    room = synth.room_scene(S + 1000 * (1 * tiles + 2), L, 2 * L - half, 1 * L - half)
+    centre = (2 * L - half + 0.5 * L, 1 * L - half + 0.5 * L)
+    scans, inits, truth = [], [], []
+    for k in range(m):
+        pose = (centre[0] + 0.10 - 0.002 * k, centre[1] - 0.08 + 0.002 * k, 0.01 - 0.0002 * k)
+        scans.append(synth_dev.sample_scene(room, n_pts, seed=40_000 + k, sigma=synth.SIGMA, pose=pose, device=dev))
+        inits.append((centre[0], centre[1], 0.0))
+        truth.append(pose)
+    with NdtMatcher2D(device=dev_index, fixed_iterations=K_GN) as mm:
+        mm.set_target(tx, ty)
+        for _ in range(max(1, warmup)):
+            mm.align_multi_scan(scans, inits)
+        torch.cuda.synchronize()
+        per_call = []
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            r = mm.align_multi_scan(scans, inits)
+            per_call.append(time.perf_counter() - t1)
+    assert all(q.iterations == K_GN and q.status == 0 for q in r)
+    err = max(float(np.abs(np.array(q.pose) - np.array(t)).max()) for q, t in zip(r, truth))
+    med = float(np.median(per_call))
+    us = 1e6 * med / (K_GN + 1)
+    alg = m * n_pts * BYTES_PER_POINT_ITER
+    return {"scans": m, "points_per_scan": n_pts, "iters_per_s_aggregate": round(m * K_GN / med, 1),
+            "ms_per_call": round(1e3 * med, 4), "timing": f"median of {steps} calls, host call to results on the host",
+            "us_per_launch_incl_call_overhead": round(us, 3), "algorithmic_bytes_per_launch": alg,
+            "achieved_GBps": round(alg / us / 1e3, 1), "frac_of_8TBps": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
+            "pose_err_vs_truth_max": err}
+
+
 def lidar_batch_rate(dev, dev_index, n_pairs: int = 4096, npts: int = 1000, unique: int = 64):
     """Loop-closure batch of lidar-sized pairs (the 256-thread variant of the batch kernel, two pairs
     per CU): `unique` different synthetic pairs repeated to n_pairs, fixed K iterations each."""
@@ -587,6 +626,11 @@ def main():
                         "reported beside the single-start headline, never instead of it; bytes = N x (8 + 24 m)",
                 "runs": [multi_start_rate(dev_index, tx, ty, sx, sy, d["init"], mm_, max(5, a.steps // 2), a.warmup)
                          for mm_ in [int(v) for v in a.multi_starts.split(",") if v]]}
+        if not a.headline_only:
+            out["multi_scan"] = {
+                "note": "the same 1M-point target, m different 100k-point scans per launch chain (ndt2d_align_multi_scan_dev); "
+                        "beside the single-scan headline, never instead of it; bytes = m x N x 32 B",
+                "runs": [multi_scan_rate(dev, dev_index, tx, ty, mm_, max(5, a.steps // 2), a.warmup) for mm_ in (8, 64)]}
         if a.host_path:
             mh = NdtMatcher2D(device=dev_index, fixed_iterations=K_GN)
             lt, la = [], []

@@ -128,6 +128,7 @@ SIGNATURES = {
     "ndt2d_align_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp]),
     "ndt2d_align_finish": (C.c_int32, [_vp, C.POINTER(Result2D)]),
     "ndt2d_align_trace": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, _vp, C.c_int32, C.POINTER(C.c_int32), _vp]),
+    "ndt2d_align_multi_scan_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "ndt2d_align_multi_start_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int32, _vp]),
     "ndt2d_stream": (_vp, [_vp]),
     "ndt2d_set_tuning": (C.c_int32, [_vp, C.c_int32, C.c_int64]),

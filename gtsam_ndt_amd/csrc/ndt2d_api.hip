@@ -1013,24 +1013,22 @@ int32_t ndt2d_align(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
 // ---- multi-start alignment (ndt2d_multi_start.hpp) ---------------------------------------------
 namespace {
 
-template <int MODE, int THREADS>
+template <int MODE, int THREADS, bool SHARED>
 const void* multi_kernel(int nh) {
   if constexpr (THREADS <= 256) {           // a 1024-thread workgroup fills its CU with one start
-    if (nh == 2) return (const void*)&k_iterate_multi<MODE, 2, THREADS>;
-    if (nh == 4) return (const void*)&k_iterate_multi<MODE, 4, THREADS>;
+    if (nh == 2) return (const void*)&k_iterate_multi<MODE, 2, THREADS, SHARED>;
+    if (nh == 4) return (const void*)&k_iterate_multi<MODE, 4, THREADS, SHARED>;
   }
-  return (const void*)&k_iterate_multi<MODE, 1, THREADS>;
+  return (const void*)&k_iterate_multi<MODE, 1, THREADS, SHARED>;
 }
 
-}  // namespace
-
-extern "C" int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
-                                               const double* init_poses, int32_t m, ndt2d_result* results) {
-  if (!h || !d_sx || !d_sy || !init_poses || !results || m < 1 || m > kMaxStarts) return NDT_ERR_INVALID_ARG;
-  if (n == 0 || n > kMaxSourcePoints) return NDT_ERR_INVALID_ARG;
-  if (h->prm.overlap_grids == 4) { set_error("multi-start runs on the single grid only"); return NDT_ERR_INVALID_ARG; }
+// m alignments against the cached grid in one launch chain: of one scan from m initial poses (shared), or
+// of m scans (each with its initial pose).  sxs / sys / ns have one entry when shared, m otherwise.
+int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const* sys, const size_t* ns, bool shared,
+                    const double* init_poses, int32_t m, ndt2d_result* results) {
+  if (h->prm.overlap_grids == 4) { set_error("multi-start / multi-scan run on the single grid only"); return NDT_ERR_INVALID_ARG; }
   if (!h->has_target) return NDT_ERR_NO_TARGET;
-  TraceRange range("ndt2d_align_multi_start");
+  TraceRange range(shared ? "ndt2d_align_multi_start" : "ndt2d_align_multi_scan");
   HIP_TRY(hipSetDevice(h->device));
   { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   if (h->n_valid < 1) {
@@ -1042,9 +1040,11 @@ extern "C" int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_s
     return NDT_OK;
   }
   { const int32_t st = ensure_multi_buffers(h); if (st != NDT_OK) return st; }
-  if (xcd_eligible(h, n)) {
+  size_t n_max = 0;
+  for (int32_t k = 0; k < (shared ? 1 : m); ++k) n_max = ns[k] > n_max ? ns[k] : n_max;
+  if (shared && xcd_eligible(h, n_max)) {
     // one launch: team t (the 32 workgroups of one XCD) runs start t to the end (ndt2d_xcd.hpp)
-    const int32_t bs = begin_xcd(h, d_sx, d_sy, n, init_poses, m, h->prm.fixed_iterations);
+    const int32_t bs = begin_xcd(h, sxs[0], sys[0], ns[0], init_poses, m, h->prm.fixed_iterations);
     if (bs != NDT_OK) return bs;
     bool gave_up = false;
     const int32_t fs = finish_xcd(h, &gave_up);
@@ -1059,48 +1059,71 @@ extern "C" int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_s
     HIP_TRY(hipMemsetAsync(h->d_dyn_multi, 0, sizeof(AlignDynMulti), h->stream));
   }
   const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON;
-  const bool wide = h->use_wide && n >= h->wide_threshold;
+  const bool wide = h->use_wide && n_max >= h->wide_threshold;
   const int fixed = h->prm.fixed_iterations;
   const int K = fixed > 0 ? fixed : h->prm.max_iterations;
   const bool converged_mode = fixed == 0;
-  // grid = (256 workgroups) x (subsets of nh starts): up to four workgroups per CU carry one start
+  // grid = (256 workgroups) x (subsets of nh starts): up to six workgroups per CU carry one start
   // each, more starts double up inside the workgroups; a 1024-thread workgroup fills a CU alone
-  const int group_max = kMaxStarts;
-  for (int32_t first = 0; first < m; first += group_max) {
-    const int mg = m - first < group_max ? m - first : group_max;
-    const int nh = (wide || mg <= 6) ? 1 : (mg <= 12 ? 2 : 4);     // six one-start workgroups fit a CU (78 VGPRs)
-    const int subsets = (mg + nh - 1) / nh;
-    const void* func = wide ? (newton ? multi_kernel<1, kIterThreadsWide>(nh) : multi_kernel<0, kIterThreadsWide>(nh))
-                            : (newton ? multi_kernel<1, kIterThreads>(nh) : multi_kernel<0, kIterThreads>(nh));
-    __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
-    __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
-    h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
-    StartPoses sp{};
-    for (int k = 0; k < mg; ++k)
-      for (int j = 0; j < 3; ++j) sp.p[k][j] = init_poses[3 * (first + k) + j];
-    hipLaunchKernelGGL(k_begin_multi, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn_multi, d_sx, d_sy, (int)n, sp, mg,
-                       fixed, converged_mode ? h->h_state_multi : (IterState*)nullptr,
-                       converged_mode ? h->h_flag : (int*)nullptr, h->call_seq);
-    HIP_TRY(hipGetLastError());
-    const int launches = converged_mode ? h->check_every + (h->check_every & 1) : K + 1;
-    hipGraphExec_t exec = nullptr;
-    HIP_TRY(h->graphs.get(func, dim3(kMaxBlocks, subsets), dim3(wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static,
-                          (void*)h->d_call, (void*)h->d_dyn_multi, launches,
-                          0x1000 | (nh << 5) | (subsets << 8) | h->prm.hessian_mode | (wide ? 16 : 0), h->stream, &exec));
-    if (converged_mode) {
-      bool seen = false;
-      HIP_TRY(run_chunks_until_flag(exec, h->stream, h->h_flag, launches, K + 1, h->call_seq, &seen));
-      HIP_TRY(hipGetLastError());
-      if (!seen) { set_error("the multi-start loop did not report its end"); return NDT_ERR_HIP; }
-    } else {
-      HIP_TRY(hipGraphLaunch(exec, h->stream));
-      HIP_TRY(hipMemcpyAsync(h->h_state_multi, h->d_dyn_multi->state[K & 1], kMaxStarts * sizeof(IterState),
-                             hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-    }
-    for (int k = 0; k < mg; ++k) state_to_result(h->h_state_multi[k], &results[first + k]);
+  const int nh = (wide || m <= 6) ? 1 : (m <= 12 ? 2 : 4);     // six one-start workgroups fit a CU (78 VGPRs)
+  const int subsets = (m + nh - 1) / nh;
+  const void* func;
+  if (shared)
+    func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, true>(nh) : multi_kernel<0, kIterThreadsWide, true>(nh))
+                : (newton ? multi_kernel<1, kIterThreads, true>(nh) : multi_kernel<0, kIterThreads, true>(nh));
+  else
+    func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, false>(nh) : multi_kernel<0, kIterThreadsWide, false>(nh))
+                : (newton ? multi_kernel<1, kIterThreads, false>(nh) : multi_kernel<0, kIterThreads, false>(nh));
+  __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
+  h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
+  StartPoses sp{};
+  StartScans sc{};
+  for (int k = 0; k < m; ++k) {
+    for (int j = 0; j < 3; ++j) sp.p[k][j] = init_poses[3 * k + j];
+    sc.sx[k] = sxs[shared ? 0 : k]; sc.sy[k] = sys[shared ? 0 : k]; sc.n[k] = (int)ns[shared ? 0 : k];
   }
+  // AlignCall.n doubles as the "armed" word of the chain: the scan size when shared, any non-zero value otherwise
+  hipLaunchKernelGGL(k_begin_multi, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn_multi, sxs[0], sys[0], (int)n_max, sp, sc,
+                     (int)m, fixed, converged_mode ? h->h_state_multi : (IterState*)nullptr,
+                     converged_mode ? h->h_flag : (int*)nullptr, h->call_seq);
+  HIP_TRY(hipGetLastError());
+  const int launches = converged_mode ? h->check_every + (h->check_every & 1) : K + 1;
+  hipGraphExec_t exec = nullptr;
+  HIP_TRY(h->graphs.get(func, dim3(kMaxBlocks, subsets), dim3(wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static,
+                        (void*)h->d_call, (void*)h->d_dyn_multi, launches,
+                        0x10000 | (shared ? 0 : 0x20000) | (nh << 5) | (subsets << 8) | h->prm.hessian_mode | (wide ? 16 : 0),
+                        h->stream, &exec));
+  if (converged_mode) {
+    bool seen = false;
+    HIP_TRY(run_chunks_until_flag(exec, h->stream, h->h_flag, launches, K + 1, h->call_seq, &seen));
+    HIP_TRY(hipGetLastError());
+    if (!seen) { set_error("the multi-start loop did not report its end"); return NDT_ERR_HIP; }
+  } else {
+    HIP_TRY(hipGraphLaunch(exec, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_state_multi, h->d_dyn_multi->state[K & 1], kMaxStarts * sizeof(IterState),
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  for (int k = 0; k < m; ++k) state_to_result(h->h_state_multi[k], &results[k]);
   return NDT_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
+                                               const double* init_poses, int32_t m, ndt2d_result* results) {
+  if (!h || !d_sx || !d_sy || !init_poses || !results || m < 1 || m > kMaxStarts) return NDT_ERR_INVALID_ARG;
+  if (n == 0 || n > kMaxSourcePoints) return NDT_ERR_INVALID_ARG;
+  return multi_align(h, &d_sx, &d_sy, &n, /*shared=*/true, init_poses, m, results);
+}
+
+extern "C" int32_t ndt2d_align_multi_scan_dev(ndt2d_handle* h, const float* const* d_sx, const float* const* d_sy,
+                                              const size_t* n, const double* init_poses, int32_t m, ndt2d_result* results) {
+  if (!h || !d_sx || !d_sy || !n || !init_poses || !results || m < 1 || m > kMaxStarts) return NDT_ERR_INVALID_ARG;
+  for (int32_t k = 0; k < m; ++k)
+    if (!d_sx[k] || !d_sy[k] || n[k] == 0 || n[k] > kMaxSourcePoints) return NDT_ERR_INVALID_ARG;
+  return multi_align(h, d_sx, d_sy, n, /*shared=*/false, init_poses, m, results);
 }
 
 #include "ndt2d_batch_api.hpp"

@@ -29,18 +29,28 @@ struct AlignDynMulti {
   int launch[2];          // ping-pong launch counter (what the host sees as progress)
   int subsets_done;       // subsets (blockIdx.y) all of whose starts have finished
   int pad;
+  // multi-scan calls (ndt2d_align_multi_scan_dev): every start has its own source scan
+  const float* sx[kMaxStarts];
+  const float* sy[kMaxStarts];
+  int n[kMaxStarts];
 };
 
 struct StartPoses {
   double p[kMaxStarts][3];
 };
+struct StartScans {
+  const float* sx[kMaxStarts];
+  const float* sy[kMaxStarts];
+  int n[kMaxStarts];
+};
 
 // Per-call part of the context, written from kernel arguments; slots >= m never run.
 __global__ void k_begin_multi(AlignCall* __restrict__ call, AlignDynMulti* __restrict__ dyn, const float* sx,
-                              const float* sy, int n, StartPoses poses, int m, int fixed_iterations, IterState* host_state,
-                              int* host_flag, int seq) {
+                              const float* sy, int n, StartPoses poses, StartScans scans, int m, int fixed_iterations,
+                              IterState* host_state, int* host_flag, int seq) {
   const int h = threadIdx.x;
   if (blockIdx.x != 0 || h >= kMaxStarts) return;
+  dyn->sx[h] = scans.sx[h]; dyn->sy[h] = scans.sy[h]; dyn->n[h] = h < m ? scans.n[h] : 0;
   if (h == 0) {
     call->seq = seq;
     call->pad = m;
@@ -73,7 +83,9 @@ struct StartPose {
 // Launch k (parity = k & 1) consumes state[parity ^ 1][*] and partials[parity ^ 1][*] and produces
 // state[parity][*], partials[parity][*] - the scheme of k_iterate, per start.  Workgroup
 // (blockIdx.x, blockIdx.y) owns starts blockIdx.y * NH .. + NH - 1 on block blockIdx.x's points.
-template <int MODE, int NH, int THREADS>
+// SHARED: every start aligns the same scan (multi-start: the points are loaded once per workgroup and
+// looked up under NH poses); otherwise every start has its own scan (multi-scan: one point loop per start).
+template <int MODE, int NH, int THREADS, bool SHARED = true>
 __global__ __launch_bounds__(THREADS) void k_iterate_multi(const AlignStatic* __restrict__ st,
                                                            const AlignCall* __restrict__ call,
                                                            AlignDynMulti* __restrict__ dyn, int parity) {
@@ -94,10 +106,21 @@ __global__ __launch_bounds__(THREADS) void k_iterate_multi(const AlignStatic* __
   // ---- batch 1 of loads: read-only scalars, the previous `done` flags, partial rows, first points
   const SolveParams prm = st->prm;
   const GridDev G = st->grid;
-  const int n = call->n;
+  const int armed = call->n;                   // 0: the call is over, no launch reads a source array any more
   const int fixed_iterations = call->fixed_iterations;
-  const float* __restrict__ sx = call->sx;
-  const float* __restrict__ sy = call->sy;
+  // this subset's scans (SHARED: the one scan of the call)
+  const float* __restrict__ sxs[NH];
+  const float* __restrict__ sys[NH];
+  int ns[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    sxs[h] = SHARED ? call->sx : dyn->sx[hb + h];
+    sys[h] = SHARED ? call->sy : dyn->sy[hb + h];
+    ns[h] = armed ? (SHARED ? armed : dyn->n[hb + h]) : 0;
+  }
+  const int n = ns[0];
+  const float* __restrict__ sx = sxs[0];
+  const float* __restrict__ sy = sys[0];
   IterState* const host_state = call->host_state;
   int* const host_flag = call->host_flag;
   const int launch = dyn->launch[parity ^ 1] + 1;
@@ -155,7 +178,7 @@ __global__ __launch_bounds__(THREADS) void k_iterate_multi(const AlignStatic* __
       // Every start had finished (and written its final state to the host) before this launch began.
       // First such launch: stop the launches behind it from loading points, then raise the flag.
       // Second: the first one is complete, nothing reads the source arrays any more.
-      if (n != 0) {
+      if (armed != 0) {
         const_cast<AlignCall*>(call)->n = 0;
         __threadfence_system();
         __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -267,28 +290,60 @@ __global__ __launch_bounds__(THREADS) void k_iterate_multi(const AlignStatic* __
                      G.H, prm.d1, prm.d2);
     acc_zero(A[h]);
   }
-  while (i < n) {
-    const int i2 = i + 2 * stride;
-    float xn0 = 0.f, yn0 = 0.f, xn1 = 0.f, yn1 = 0.f;
-    if (i2 < n) { xn0 = sx[i2]; yn0 = sy[i2]; }
-    if (i2 + stride < n) { xn1 = sx[i2 + stride]; yn1 = sy[i2 + stride]; }
-    const bool two = (i + stride) < n;
-    PointRec r0[NH], r1[NH];
+  if constexpr (SHARED) {
+    while (i < n) {
+      const int i2 = i + 2 * stride;
+      float xn0 = 0.f, yn0 = 0.f, xn1 = 0.f, yn1 = 0.f;
+      if (i2 < n) { xn0 = sx[i2]; yn0 = sy[i2]; }
+      if (i2 + stride < n) { xn1 = sx[i2 + stride]; yn1 = sy[i2 + stride]; }
+      const bool two = (i + stride) < n;
+      PointRec r0[NH], r1[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if (!done[h]) {                                       // uniform
+          lookup_point(P[h], rec, x, y, true, r0[h]);
+          lookup_point(P[h], rec, x1, y1, two, r1[h]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if (!done[h]) {
+          accumulate_point<MODE>(P[h], r0[h], A[h]);
+          accumulate_point<MODE>(P[h], r1[h], A[h]);
+        }
+      }
+      x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
+    }
+  } else {
+    // one point loop per live start, each over its own scan, in k_iterate's order
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       if (!done[h]) {                                         // uniform
-        lookup_point(P[h], rec, x, y, true, r0[h]);
-        lookup_point(P[h], rec, x1, y1, two, r1[h]);
+        const float* __restrict__ px = sxs[h];
+        const float* __restrict__ py = sys[h];
+        const int nn = ns[h];
+        int ii = blockIdx.x * THREADS + tid;
+        float u = x, v = y, u1 = x1, v1 = y1;                 // start 0's first points were requested at the top
+        if (h > 0) {
+          u = v = u1 = v1 = 0.f;
+          if (ii < nn) { u = px[ii]; v = py[ii]; }
+          if (ii + stride < nn) { u1 = px[ii + stride]; v1 = py[ii + stride]; }
+        }
+        while (ii < nn) {
+          const int i2 = ii + 2 * stride;
+          float xn0 = 0.f, yn0 = 0.f, xn1 = 0.f, yn1 = 0.f;
+          if (i2 < nn) { xn0 = px[i2]; yn0 = py[i2]; }
+          if (i2 + stride < nn) { xn1 = px[i2 + stride]; yn1 = py[i2 + stride]; }
+          PointRec r0, r1;
+          const bool two = (ii + stride) < nn;
+          lookup_point(P[h], rec, u, v, true, r0);
+          lookup_point(P[h], rec, u1, v1, two, r1);
+          accumulate_point<MODE>(P[h], r0, A[h]);
+          accumulate_point<MODE>(P[h], r1, A[h]);
+          u = xn0; v = yn0; u1 = xn1; v1 = yn1; ii = i2;
+        }
       }
     }
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      if (!done[h]) {
-        accumulate_point<MODE>(P[h], r0[h], A[h]);
-        accumulate_point<MODE>(P[h], r1[h], A[h]);
-      }
-    }
-    x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
   }
 
   // ---- epilogue: per start, the 11 sums of the wave through LDS, then one partial row per block

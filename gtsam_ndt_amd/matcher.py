@@ -232,6 +232,22 @@ class NdtMatcher2D:
                                                       C.cast(out, C.c_void_p)), "ndt2d_align_multi_start_dev")
         return [_to_result(r) for r in out]
 
+    def align_multi_scan(self, scans, init_poses):
+        """Up to 64 different device scans, each from its own initial pose, in one launch chain
+        (ndt2d_align_multi_scan_dev).  scans: list of (sx, sy) CUDA tensors.  Returns a list of AlignResult."""
+        m = len(scans)
+        poses = np.ascontiguousarray(init_poses, dtype=np.float64).reshape(m, 3)
+        px, py, nn = (C.c_void_p * m)(), (C.c_void_p * m)(), (C.c_size_t * m)()
+        for k, (sx, sy) in enumerate(scans):
+            nn[k] = sx.numel()
+            px[k] = _dev_ptr(sx, nn[k]).value
+            py[k] = _dev_ptr(sy, nn[k]).value
+        out = (L.Result2D * m)()
+        self.wait_stream()
+        L.check(self._lib.ndt2d_align_multi_scan_dev(self._h, px, py, nn, poses.ctypes.data, m, C.cast(out, C.c_void_p)),
+                "ndt2d_align_multi_scan_dev")
+        return [_to_result(r) for r in out]
+
     def align_async(self, sx, sy, init_pose=(0.0, 0.0, 0.0), producer_complete: bool = False):
         """Enqueue the whole loop on the handle's stream (device tensors only).  producer_complete=True:
         the caller knows the tensors are complete (their stream was synchronised), no ordering needed."""

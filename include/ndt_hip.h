@@ -178,6 +178,14 @@ int32_t ndt2d_align_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, s
 int32_t ndt2d_align_dev_async(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
                               const double init_pose[3]);
 int32_t ndt2d_align_finish(ndt2d_handle* h, ndt2d_result* out);
+/* Multi-scan: m (1..64) DIFFERENT scans against the cached grid, each from its own initial pose, in one
+ * launch chain - several robots', or several recent, scans relocalised in one submap.  d_sx / d_sy / n
+ * are host arrays of m device pointers / sizes; results[k] is bit for bit what ndt2d_align_dev returns for
+ * scan k on the launch-per-iteration path.  This is the call that takes the 1M-point-target configuration
+ * off the launch-latency floor with distinct data: 64 scans of 100k points move 64 x 3.2 MB of algorithmic
+ * traffic per launch. */
+int32_t ndt2d_align_multi_scan_dev(ndt2d_handle* h, const float* const* d_sx, const float* const* d_sy, const size_t* n,
+                                   const double* init_poses, int32_t m, ndt2d_result* results);
 /* Per-iteration trace, for debugging and stage-by-stage parity checks ("optional
  * per-iteration trace ... copied back on request"; never on a timed path: one plain launch and one state
  * fetch per iteration, always through the launch-per-iteration kernels).  rows[j], j < *n_rows <= capacity,

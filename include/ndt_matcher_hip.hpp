@@ -166,6 +166,28 @@ class NdtMatcherHip {
     for (const ndt2d_result& q : r) out.push_back(to_match_result(q, mode_));
     return out;
   }
+  // Several different device scans against the cached grid in one launch chain (ndt2d_align_multi_scan_dev,
+  // at most 64): scans[k] = {d_x, d_y, n}; result k is what alignDev(scans[k], guesses[k]) returns.
+  struct DeviceScan { const float* x; const float* y; size_t n; };
+  std::vector<MatchResult> alignMultiScanDev(const std::vector<DeviceScan>& scans, const std::vector<Pose2>& guesses,
+                                             void* producer_stream, bool complete = false) {
+    if (scans.size() != guesses.size() || scans.empty()) throw NdtError(NDT_ERR_INVALID_ARG, "alignMultiScanDev");
+    if (!complete) check(ndt2d_wait_stream(h_, producer_stream), "ndt2d_wait_stream");
+    const size_t m = scans.size();
+    std::vector<const float*> px(m), py(m);
+    std::vector<size_t> n(m);
+    std::vector<double> init(3 * m);
+    for (size_t k = 0; k < m; ++k) {
+      px[k] = scans[k].x; py[k] = scans[k].y; n[k] = scans[k].n;
+      init[3 * k] = guesses[k].x; init[3 * k + 1] = guesses[k].y; init[3 * k + 2] = guesses[k].theta;
+    }
+    std::vector<ndt2d_result> r(m);
+    check(ndt2d_align_multi_scan_dev(h_, px.data(), py.data(), n.data(), init.data(), (int32_t)m, r.data()),
+          "ndt2d_align_multi_scan_dev");
+    std::vector<MatchResult> out;
+    for (const ndt2d_result& q : r) out.push_back(to_match_result(q, mode_));
+    return out;
+  }
   // one evaluation at a fixed pose, for callers with their own optimiser
   ndt2d_eval evaluate(const float* sx, const float* sy, size_t n, const Pose2& at) {
     const double p[3] = {at.x, at.y, at.theta};

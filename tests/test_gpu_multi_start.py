@@ -157,3 +157,39 @@ def test_argument_checks(gpu_lib, pair2):
         with pytest.raises(L.NdtError) as e:
             mm.align_multi_start(sx, sy, _starts(d["init"], 2))
         assert e.value.code == L.NDT_ERR_INVALID_ARG
+
+
+def _scans_of_config3(n_scans, n_pts, ragged=False):
+    """Distinct scans taken in room (2,1) of the config-3 submap: other sampling seeds, slightly other poses."""
+    import torch
+    L, S, tiles = 50.0, 3, 4
+    half = 0.5 * tiles * L
+    room = synth.room_scene(S + 1000 * (1 * tiles + 2), L, 2 * L - half, 1 * L - half)
+    centre = (2 * L - half + 0.5 * L, 1 * L - half + 0.5 * L)
+    scans, inits, truth = [], [], []
+    for k in range(n_scans):
+        pose = (centre[0] + 0.1 - 0.01 * k, centre[1] - 0.08 + 0.005 * k, 0.01 - 0.001 * k)
+        n = n_pts - 997 * k if ragged else n_pts
+        x, y = synth.sample_scene(room, n, seed=40_000 + k, sigma=synth.SIGMA)
+        x, y = synth.to_source_frame(x, y, pose)
+        scans.append((torch.from_numpy(x.astype(np.float32)).cuda(), torch.from_numpy(y.astype(np.float32)).cuda()))
+        inits.append((centre[0], centre[1], 0.0))
+        truth.append(pose)
+    return scans, inits, truth
+
+
+@pytest.mark.parametrize("m,kw", [(3, {}), (7, {}), (13, dict(fixed_iterations=9)), (5, dict(hessian_mode=1))])
+def test_multi_scan_every_scan_equals_its_own_alignment_bitwise(gpu_lib, m, kw):
+    """ndt2d_align_multi_scan_dev: m different scans (ragged sizes) against one submap in one chain; scan k's
+    result is bit for bit its own ndt2d_align_dev result, and the pose is the one the scan was taken at."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(3, n_tgt=400_000, n_src=1000)
+    scans, inits, truth = _scans_of_config3(m, 30_000, ragged=True)
+    with NdtMatcher2D(**kw) as mm:
+        mm.set_target(d["tx"], d["ty"])
+        multi = mm.align_multi_scan(scans, inits)
+        for k, (a, (sx, sy)) in enumerate(zip(multi, scans)):
+            b = mm.align(sx, sy, inits[k])
+            assert _same(a, b), (k, a, b)
+            if not kw:
+                assert a.status == 0 and np.abs(np.array(a.pose) - np.array(truth[k])).max() < 5e-3
