@@ -63,6 +63,7 @@ struct ndt2d_handle {
   XcdShared* d_xcd = nullptr;              // barrier words and partial rows
   IterState* d_xcd_state = nullptr;        // [kMaxStarts]
   int* h_xcd_flag = nullptr;               // pinned [kMaxStarts]: +seq done, -seq the team gave up
+  int split_from = 12;                     // multi-start / multi-scan calls of this many starts use the split chain (NDT_TUNE_SPLIT_FROM)
   bool use_xcd = false;                    // NDT_TUNE_TEAM_KERNEL (off by default: measured slower than k_iterate for one start)
   int home_xcd = 0;                        // team 0's workgroups are those with blockIdx % 8 == home_xcd
   long long xcd_fallbacks = 0;             // calls whose team could not assemble and that ran on the other path
@@ -762,6 +763,7 @@ int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value) {
     case NDT_TUNE_CHUNK_LAUNCHES: if (value < 2 || value > 128) return NDT_ERR_INVALID_ARG; h->check_every = (int)value; return NDT_OK;
     case NDT_TUNE_BINNED_BUILD: h->use_binned_build = value != 0; return NDT_OK;
     case NDT_TUNE_TEAM_KERNEL: h->use_xcd = value != 0; return NDT_OK;
+    case NDT_TUNE_SPLIT_FROM: if (value < 1 || value > 1000) return NDT_ERR_INVALID_ARG; h->split_from = (int)value; return NDT_OK;
     default: return NDT_ERR_INVALID_ARG;
   }
 }
@@ -1022,6 +1024,11 @@ const void* multi_kernel(int nh) {
   return (const void*)&k_iterate_multi<MODE, 1, THREADS, SHARED>;
 }
 
+template <int MODE, int THREADS, bool SHARED>
+const void* body_kernel(int) {              // the split chain evaluates one start per workgroup
+  return (const void*)&k_multi_body<MODE, 1, THREADS, SHARED>;
+}
+
 // m alignments against the cached grid in one launch chain: of one scan from m initial poses (shared), or
 // of m scans (each with its initial pose).  sxs / sys / ns have one entry when shared, m otherwise.
 int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const* sys, const size_t* ns, bool shared,
@@ -1065,15 +1072,30 @@ int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const
   const bool converged_mode = fixed == 0;
   // grid = (256 workgroups) x (subsets of nh starts): up to six workgroups per CU carry one start
   // each, more starts double up inside the workgroups; a 1024-thread workgroup fills a CU alone
-  const int nh = (wide || m <= 6) ? 1 : (m <= 12 ? 2 : 4);     // six one-start workgroups fit a CU (78 VGPRs)
+  const bool split = m >= h->split_from;
+  // fused chain: six one-start workgroups fit a CU (78 VGPRs), more starts double up inside the workgroups;
+  // split chain: one start per evaluation workgroup (measured best: 31.8 us per step at 64 starts, 33.0 with four)
+  const int nh = (split || wide || m <= 6) ? 1 : (m <= 12 ? 2 : 4);
   const int subsets = (m + nh - 1) / nh;
+  // From kSplitFrom starts on the chain alternates two kernels per iteration (one workgroup per start solves,
+  // then everybody evaluates): the 256-fold redundant prologues of the fused kernel cost more than the
+  // second kernel boundary there.
   const void* func;
-  if (shared)
-    func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, true>(nh) : multi_kernel<0, kIterThreadsWide, true>(nh))
-                : (newton ? multi_kernel<1, kIterThreads, true>(nh) : multi_kernel<0, kIterThreads, true>(nh));
-  else
-    func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, false>(nh) : multi_kernel<0, kIterThreadsWide, false>(nh))
-                : (newton ? multi_kernel<1, kIterThreads, false>(nh) : multi_kernel<0, kIterThreads, false>(nh));
+  if (!split) {
+    if (shared)
+      func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, true>(nh) : multi_kernel<0, kIterThreadsWide, true>(nh))
+                  : (newton ? multi_kernel<1, kIterThreads, true>(nh) : multi_kernel<0, kIterThreads, true>(nh));
+    else
+      func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, false>(nh) : multi_kernel<0, kIterThreadsWide, false>(nh))
+                  : (newton ? multi_kernel<1, kIterThreads, false>(nh) : multi_kernel<0, kIterThreads, false>(nh));
+  } else {
+    if (shared)
+      func = wide ? (newton ? body_kernel<1, kIterThreadsWide, true>(nh) : body_kernel<0, kIterThreadsWide, true>(nh))
+                  : (newton ? body_kernel<1, kIterThreads, true>(nh) : body_kernel<0, kIterThreads, true>(nh));
+    else
+      func = wide ? (newton ? body_kernel<1, kIterThreadsWide, false>(nh) : body_kernel<0, kIterThreadsWide, false>(nh))
+                  : (newton ? body_kernel<1, kIterThreads, false>(nh) : body_kernel<0, kIterThreads, false>(nh));
+  }
   __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
   __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
   h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
@@ -1090,10 +1112,14 @@ int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const
   HIP_TRY(hipGetLastError());
   const int launches = converged_mode ? h->check_every + (h->check_every & 1) : K + 1;
   hipGraphExec_t exec = nullptr;
-  HIP_TRY(h->graphs.get(func, dim3(kMaxBlocks, subsets), dim3(wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static,
-                        (void*)h->d_call, (void*)h->d_dyn_multi, launches,
-                        0x10000 | (shared ? 0 : 0x20000) | (nh << 5) | (subsets << 8) | h->prm.hessian_mode | (wide ? 16 : 0),
-                        h->stream, &exec));
+  const int key = 0x10000 | (shared ? 0 : 0x20000) | (split ? 0x40000 : 0) | (nh << 5) | (subsets << 8) | h->prm.hessian_mode | (wide ? 16 : 0);
+  if (!split)
+    HIP_TRY(h->graphs.get(func, dim3(kMaxBlocks, subsets), dim3(wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static,
+                          (void*)h->d_call, (void*)h->d_dyn_multi, launches, key, h->stream, &exec));
+  else
+    HIP_TRY(h->graphs.get2((const void*)&k_multi_solve, dim3(m), dim3(kBlock), func, dim3(kMaxBlocks, subsets),
+                           dim3(wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static, (void*)h->d_call,
+                           (void*)h->d_dyn_multi, launches, key | (m << 20), h->stream, &exec));
   if (converged_mode) {
     bool seen = false;
     HIP_TRY(run_chunks_until_flag(exec, h->stream, h->h_flag, launches, K + 1, h->call_seq, &seen));

@@ -33,6 +33,10 @@ struct AlignDynMulti {
   const float* sx[kMaxStarts];
   const float* sy[kMaxStarts];
   int n[kMaxStarts];
+  // split chains (k_multi_solve + k_multi_body): the pose each start's body uses, and how many starts are through
+  struct BodyPose { float cs, sn, tx, ty; int done; int pad[3]; } posef[2][kMaxStarts];
+  int starts_done;
+  int pad2[3];
 };
 
 struct StartPoses {
@@ -51,6 +55,7 @@ __global__ void k_begin_multi(AlignCall* __restrict__ call, AlignDynMulti* __res
   const int h = threadIdx.x;
   if (blockIdx.x != 0 || h >= kMaxStarts) return;
   dyn->sx[h] = scans.sx[h]; dyn->sy[h] = scans.sy[h]; dyn->n[h] = h < m ? scans.n[h] : 0;
+  dyn->posef[0][h].done = dyn->posef[1][h].done = h < m ? 0 : 1;     // split chains: slots >= m are never evaluated
   if (h == 0) {
     call->seq = seq;
     call->pad = m;
@@ -62,6 +67,7 @@ __global__ void k_begin_multi(AlignCall* __restrict__ call, AlignDynMulti* __res
     call->host_flag = host_flag;
     dyn->launch[0] = 0; dyn->launch[1] = 0;
     dyn->subsets_done = 0;
+    dyn->starts_done = 0;
   }
   IterState s = {};
   if (h < m) {
@@ -347,6 +353,247 @@ __global__ __launch_bounds__(THREADS) void k_iterate_multi(const AlignStatic* __
   }
 
   // ---- epilogue: per start, the 11 sums of the wave through LDS, then one partial row per block
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    if (!done[h]) {
+      float acc[kNumAcc];
+      acc_store(A[h], prm.d2, acc);
+      acc[11] = 0.f;
+      const float r = wave_reduce11_lds(acc, s_t[wave], lane);
+      if ((lane & 3) == 0 && lane < 4 * (kNumAcc - 1)) s_wave[wave][h][lane >> 2] = r;
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < NH * kNumAcc; k += THREADS) {
+    const int h = k / kNumAcc, j = k - h * kNumAcc;
+    if (!s_done[h]) {
+      float r = 0.f;
+      if (j < kNumAcc - 1) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) r += s_wave[w][h][j];        // fixed order
+      }
+      dyn->partials[parity][hb + h][j][blockIdx.x] = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Split chain for many starts: per iteration one launch of k_multi_solve (one workgroup per start: the
+// reduction of that start's partial rows and its update - k_iterate's prologue, once instead of in every
+// one of the 256 workgroups that evaluate the start) and one of k_multi_body (the evaluation).  In the
+// fused kernel above the redundant prologues cost as much as the evaluation from a few dozen starts on
+// (64 starts: 16384 solves per launch); here a second kernel boundary (1.7 us) buys them back.  Same
+// arithmetic, same order: results are bit-identical to the fused chain and to the single-start path.
+// Launch pair k: solve reads state[p^1], partials[p^1], writes state[p], posef[p]; body reads posef[p],
+// writes partials[p]  (p = k & 1).
+__global__ __launch_bounds__(kBlock) void k_multi_solve(const AlignStatic* __restrict__ st, const AlignCall* __restrict__ call,
+                                                         AlignDynMulti* __restrict__ dyn, int parity) {
+  __shared__ double s_red[kNumAcc];
+  __shared__ double s_t[4][3 * 66];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, m = call->pad;
+  const IterState* prev = &dyn->state[parity ^ 1][h];
+  IterState* cur = &dyn->state[parity][h];
+  const bool writer = tid == 0;
+  const bool herald = writer && h == 0;
+  const double ps_pose0 = prev->pose[0], ps_pose1 = prev->pose[1], ps_pose2 = prev->pose[2];
+  const int ps_iter = prev->iter, ps_done = prev->done, ps_have = prev->have_partials;
+  const SolveParams prm = st->prm;
+  const int armed = call->n;
+  const int fixed_iterations = call->fixed_iterations;
+  IterState* const host_state = call->host_state;
+  int* const host_flag = call->host_flag;
+  const int launch = dyn->launch[parity ^ 1] + 1;
+  const int starts_done = dyn->starts_done;           // as of the previous launches
+  float4 pv[3];
+  {
+    const float* part = &dyn->partials[parity ^ 1][h][0][0];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+      pv[v] = *reinterpret_cast<const float4*>(part + (wave * 3 + v) * kMaxBlocks + lane * 4);
+  }
+  if (herald) {
+    dyn->launch[parity] = launch;
+    if (host_flag) {
+      if (starts_done != m) {                           // progress, while anything is still running
+        __hip_atomic_store(host_flag + 1, launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else if (armed != 0) {                          // every start had finished before this launch: end of the call
+        const_cast<AlignCall*>(call)->n = 0;            // the launches behind load no points
+        __threadfence_system();
+        __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {                                          // ... and that launch is complete: the sources are free
+        __hip_atomic_store(host_flag + 2, call->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  AlignDynMulti::BodyPose* bp = &dyn->posef[parity][h];
+  if (ps_done) {                                        // uniform: a finished start carries its state
+    if (writer) { copy_state(cur, prev, -1); bp->done = 1; }
+    return;
+  }
+  double pose[3] = {ps_pose0, ps_pose1, ps_pose2};
+  int done = 0;
+  if (ps_have) {
+    // k_iterate's prologue: wave w owns rows 3w .. 3w+2
+    double* t = s_t[wave];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+      t[v * 66 + lane] = (((double)pv[v].x + (double)pv[v].y) + (double)pv[v].z) + (double)pv[v].w;
+    __builtin_amdgcn_wave_barrier();
+    double a = 0.0;
+    if (lane < 48) {
+      const double* row = t + (lane >> 4) * 66 + (lane & 15);
+      a = (row[0] + row[16]) + (row[32] + row[48]);
+    }
+    a += dpp_mov<0xB1, 0xf>(a);
+    a += dpp_mov<0x4E, 0xf>(a);
+    a += dpp_mov<0x124, 0xf>(a);
+    a += dpp_mov<0x128, 0xf>(a);
+    if ((lane & 15) == 0 && lane < 48) s_red[wave * 3 + (lane >> 4)] = a;
+    __syncthreads();
+    if (wave == 0) {
+      double H[6], g[3];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) H[j] = s_red[j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) g[j] = s_red[6 + j];
+      const double score = s_red[9];
+      const int n_hit = (int)(s_red[10] + 0.5);
+      int iter = ps_iter, status = 0;
+      done = gn_update(pose, H, g, n_hit, iter, status, prm, fixed_iterations, score, &dyn->ls[parity ^ 1][h], &dyn->ls[parity][h],
+                       writer) ? 1 : 0;
+      if (writer) {
+        IterState o;
+        o.pose[0] = pose[0]; o.pose[1] = pose[1]; o.pose[2] = pose[2];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) o.H[j] = H[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o.g[j] = g[j];
+        o.score = score;
+        o.n_hit = n_hit;
+        o.iter = iter;
+        o.status = status;
+        o.done = done;
+        o.have_partials = 1;
+        o.pad = launch;
+        *cur = o;
+        if (done) {
+          if (host_flag) { host_state[h] = o; __threadfence_system(); }
+          atomicAdd(&dyn->starts_done, 1);
+        }
+      }
+    }
+  } else if (writer) {
+    copy_state(cur, prev, 1);
+  }
+  if (writer) {
+    double sn_d, cs_d;
+    sincos_wrapped(pose[2], &sn_d, &cs_d);
+    bp->cs = (float)cs_d; bp->sn = (float)sn_d; bp->tx = (float)pose[0]; bp->ty = (float)pose[1];
+    bp->done = done;
+  }
+}
+
+template <int MODE, int NH, int THREADS, bool SHARED>
+__global__ __launch_bounds__(THREADS) void k_multi_body(const AlignStatic* __restrict__ st, const AlignCall* __restrict__ call,
+                                                        AlignDynMulti* __restrict__ dyn, int parity) {
+  constexpr int kWaves = THREADS / 64;
+  __shared__ float s_wave[kWaves][NH][kNumAcc];
+  __shared__ float s_t[kWaves][(kNumAcc - 1) * kSumRowStride];
+  __shared__ int s_done[NH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hb = blockIdx.y * NH;
+  const SolveParams prm = st->prm;
+  const GridDev G = st->grid;
+  const int armed = call->n;
+  const float* __restrict__ sxs[NH];
+  const float* __restrict__ sys[NH];
+  int ns[NH], done[NH];
+  float pcs[NH], psn[NH], ptx[NH], pty[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    sxs[h] = SHARED ? call->sx : dyn->sx[hb + h];
+    sys[h] = SHARED ? call->sy : dyn->sy[hb + h];
+    ns[h] = armed ? (SHARED ? armed : dyn->n[hb + h]) : 0;
+    const AlignDynMulti::BodyPose* bp = &dyn->posef[parity][hb + h];
+    pcs[h] = bp->cs; psn[h] = bp->sn; ptx[h] = bp->tx; pty[h] = bp->ty; done[h] = bp->done;
+  }
+  const int n = ns[0];
+  const float* __restrict__ sx = sxs[0];
+  const float* __restrict__ sy = sys[0];
+  const int stride = kMaxBlocks * THREADS;
+  int i = blockIdx.x * THREADS + tid;
+  float x = 0.f, y = 0.f, x1 = 0.f, y1 = 0.f;
+  if (i < n) { x = sx[i]; y = sy[i]; }
+  if (i + stride < n) { x1 = sx[i + stride]; y1 = sy[i + stride]; }
+  bool all_done = true;
+#pragma unroll
+  for (int h = 0; h < NH; ++h) all_done = all_done && done[h];
+  if (all_done) return;                                       // uniform
+  if (tid < NH) s_done[tid] = dyn->posef[parity][hb + tid].done;   // for the runtime-indexed tail (read after a barrier)
+
+  const float4* __restrict__ rec = G.rec;
+  PoseF P[NH];
+  Acc2D A[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    P[h] = make_pose(pcs[h], psn[h], ptx[h], pty[h], G.ox, G.oy, G.inv_c, G.W, G.H, prm.d1, prm.d2);
+    acc_zero(A[h]);
+  }
+  if constexpr (SHARED) {
+    while (i < n) {
+      const int i2 = i + 2 * stride;
+      float xn0 = 0.f, yn0 = 0.f, xn1 = 0.f, yn1 = 0.f;
+      if (i2 < n) { xn0 = sx[i2]; yn0 = sy[i2]; }
+      if (i2 + stride < n) { xn1 = sx[i2 + stride]; yn1 = sy[i2 + stride]; }
+      const bool two = (i + stride) < n;
+      PointRec r0[NH], r1[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if (!done[h]) {                                       // uniform
+          lookup_point(P[h], rec, x, y, true, r0[h]);
+          lookup_point(P[h], rec, x1, y1, two, r1[h]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if (!done[h]) {
+          accumulate_point<MODE>(P[h], r0[h], A[h]);
+          accumulate_point<MODE>(P[h], r1[h], A[h]);
+        }
+      }
+      x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      if (!done[h]) {                                         // uniform
+        const float* __restrict__ px = sxs[h];
+        const float* __restrict__ py = sys[h];
+        const int nn = ns[h];
+        int ii = blockIdx.x * THREADS + tid;
+        float u = x, v = y, u1 = x1, v1 = y1;
+        if (h > 0) {
+          u = v = u1 = v1 = 0.f;
+          if (ii < nn) { u = px[ii]; v = py[ii]; }
+          if (ii + stride < nn) { u1 = px[ii + stride]; v1 = py[ii + stride]; }
+        }
+        while (ii < nn) {
+          const int i2 = ii + 2 * stride;
+          float xn0 = 0.f, yn0 = 0.f, xn1 = 0.f, yn1 = 0.f;
+          if (i2 < nn) { xn0 = px[i2]; yn0 = py[i2]; }
+          if (i2 + stride < nn) { xn1 = px[i2 + stride]; yn1 = py[i2 + stride]; }
+          PointRec r0, r1;
+          const bool two = (ii + stride) < nn;
+          lookup_point(P[h], rec, u, v, true, r0);
+          lookup_point(P[h], rec, u1, v1, two, r1);
+          accumulate_point<MODE>(P[h], r0, A[h]);
+          accumulate_point<MODE>(P[h], r1, A[h]);
+          u = xn0; v = yn0; u1 = xn1; v1 = yn1; ii = i2;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     if (!done[h]) {

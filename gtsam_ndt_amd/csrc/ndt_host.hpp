@@ -76,6 +76,33 @@ inline hipError_t build_chain_graph(const void* func, dim3 grid, dim3 block, voi
   return hipSuccess;
 }
 
+// The same for chains that alternate two kernels per step (A then B, both taking the step's parity).
+inline hipError_t build_chain_graph2(const void* fa, dim3 ga, dim3 ba, const void* fb, dim3 gb, dim3 bb, void* a0, void* a1,
+                                     void* a2, int steps, hipGraph_t* graph_out, hipGraphExec_t* exec_out) {
+  hipGraph_t g = nullptr;
+  hipError_t e = hipGraphCreate(&g, 0);
+  if (e != hipSuccess) return e;
+  hipGraphNode_t prev = nullptr;
+  for (int k = 0; k < 2 * steps && e == hipSuccess; ++k) {
+    int parity = (k >> 1) & 1;
+    void* args[4] = {&a0, &a1, &a2, &parity};
+    hipKernelNodeParams p{};
+    p.func = const_cast<void*>((k & 1) ? fb : fa);
+    p.gridDim = (k & 1) ? gb : ga;
+    p.blockDim = (k & 1) ? bb : ba;
+    p.sharedMemBytes = 0;
+    p.kernelParams = args;
+    p.extra = nullptr;
+    hipGraphNode_t node = nullptr;
+    e = hipGraphAddKernelNode(&node, g, prev ? &prev : nullptr, prev ? 1 : 0, &p);
+    prev = node;
+  }
+  if (e == hipSuccess) e = hipGraphInstantiate(exec_out, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); return e; }
+  *graph_out = g;
+  return hipSuccess;
+}
+
 // A handle alternates between a few chain lengths (the converged-mode chunk, the fixed-K chain of a
 // timing run, the 2-launch chain of an evaluation): keep the last few instantiated graphs instead
 // of rebuilding one on every change.
@@ -116,6 +143,17 @@ struct ChainGraphCache {
     const hipError_t err = build_chain_graph(func, grid, block, a0, a1, a2, launches, &s->graph, &s->exec);
     if (err != hipSuccess) { *s = Slot{}; return err; }
     s->launches = launches; s->blocks = (int)grid.x; s->mode = mode; s->stamp = ++clock;
+    *out = s->exec;
+    return hipSuccess;
+  }
+  // two-kernel chains (build_chain_graph2); `blocks` of the key is the first kernel's grid
+  hipError_t get2(const void* fa, dim3 ga, dim3 ba, const void* fb, dim3 gb, dim3 bb, void* a0, void* a1, void* a2, int steps,
+                  int mode, hipStream_t stream, hipGraphExec_t* out) {
+    if (hipGraphExec_t e = find(steps, (int)ga.x, mode)) { *out = e; return hipSuccess; }
+    Slot* s = victim(stream);
+    const hipError_t err = build_chain_graph2(fa, ga, ba, fb, gb, bb, a0, a1, a2, steps, &s->graph, &s->exec);
+    if (err != hipSuccess) { *s = Slot{}; return err; }
+    s->launches = steps; s->blocks = (int)ga.x; s->mode = mode; s->stamp = ++clock;
     *out = s->exec;
     return hipSuccess;
   }

@@ -198,7 +198,7 @@ int32_t ndt2d_align_trace(ndt2d_handle* h, const float* sx, const float* sy, siz
  * initial poses (init_poses is [m][3], host memory), carried by ONE launch chain - the source points
  * are read once per launch and every point scores against every live pose, so m alignments cost little
  * more than one (the single alignment is bound by launch latency, DESIGN.md section 5.1: 8 starts cost
- * 1.8x one, 64 starts 8x).  For a loop-closure candidate with a poor guess: a grid of starts around
+ * 1.9x one, 64 starts 6x).  For a loop-closure candidate with a poor guess: a grid of starts around
  * it, keep the best score.
  * results[k] is bit for bit what ndt2d_align_dev returns for init_poses[k] on the
  * launch-per-iteration path; a start that has finished is frozen while the others go on.
@@ -219,6 +219,9 @@ int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const fl
  *                               that synchronise through one XCD's L2 (a start per team in multi-start calls).
  *                               Measured: 7.9 us per iteration against 4.6 for one start (32 CUs are too few
  *                               for 100k points), 16 % faster than the chain at 8 starts; DESIGN.md section 5.1d
+ *   NDT_TUNE_SPLIT_FROM         multi-start / multi-scan calls of at least this many starts run two kernels per
+ *                               iteration (one workgroup per start solves, then everybody evaluates) instead of
+ *                               the fused kernel whose every workgroup repeats its starts' solves (default 12)
  *   NDT_TUNE_BATCH_SMALL_VARIANT (batch contexts) 1 (default): lidar-sized pairs run on the 256-thread
  *                               variant of the batch kernel first; 0: every pair on the 1024-thread one */
 enum {
@@ -228,7 +231,8 @@ enum {
   NDT_TUNE_CHUNK_LAUNCHES = 4,
   NDT_TUNE_BINNED_BUILD = 5,
   NDT_TUNE_BATCH_SMALL_VARIANT = 6,
-  NDT_TUNE_TEAM_KERNEL = 7
+  NDT_TUNE_TEAM_KERNEL = 7,
+  NDT_TUNE_SPLIT_FROM = 8
 };
 int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value);
 /* Diagnostic: calls on this handle whose team kernel could not assemble its 32-workgroup teams (the GPU

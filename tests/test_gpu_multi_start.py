@@ -193,3 +193,29 @@ def test_multi_scan_every_scan_equals_its_own_alignment_bitwise(gpu_lib, m, kw):
             assert _same(a, b), (k, a, b)
             if not kw:
                 assert a.status == 0 and np.abs(np.array(a.pose) - np.array(truth[k])).max() < 5e-3
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(fixed_iterations=11), dict(hessian_mode=1), dict(line_search=3)])
+def test_split_chain_equals_fused_chain_bitwise(gpu_lib, pair2, kw):
+    """From 12 starts on a call runs two kernels per iteration (one workgroup per start solves, then everybody
+    evaluates) instead of the fused kernel; both chains, forced for every size, give the same bits - the single-
+    start alignment's - for shared and for per-start scans."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = pair2
+    sx, sy = _dev(d)
+    scans = [(sx[: 100_000 - 1111 * k].contiguous(), sy[: 100_000 - 1111 * k].contiguous()) for k in range(13)]
+    res = {}
+    for name, split_from in (("split", 1), ("fused", 1000)):
+        with NdtMatcher2D(tuning={"split_from": split_from}, **kw) as mm:
+            mm.set_target(d["tx"], d["ty"])
+            res[name] = [mm.align_multi_start(sx, sy, _starts(d["init"], m)) for m in (2, 5, 8)]
+            res[name].append(mm.align_multi_start(sx, sy, [OFFSETS[k % 8] for k in range(40)]))
+            res[name].append(mm.align_multi_scan(scans, [d["init"]] * 13))
+            if name == "split":
+                single = [mm.align(sx, sy, s) for s in _starts(d["init"], 8)]
+    for a_list, b_list in zip(res["split"], res["fused"]):
+        assert len(a_list) == len(b_list)
+        for a, b in zip(a_list, b_list):
+            assert _same(a, b)
+    for a, b in zip(res["split"][2], single):
+        assert _same(a, b)
