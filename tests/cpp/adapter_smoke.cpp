@@ -8,6 +8,24 @@
 
 #include "ndt_matcher_hip.hpp"
 
+// Device-pointer entry points: the program owns a few device buffers itself.  Only the C API of the HIP
+// runtime is needed for that (no device code here: this file is compiled by plain g++).
+extern "C" {
+int hipMalloc(void** ptr, size_t size);
+int hipFree(void* ptr);
+int hipMemcpy(void* dst, const void* src, size_t size, int kind);   // kind 1 = host to device
+int hipDeviceSynchronize(void);
+}
+template <class T>
+static T* to_device(const std::vector<T>& v) {
+  void* d = nullptr;
+  if (hipMalloc(&d, v.size() * sizeof(T)) != 0 || hipMemcpy(d, v.data(), v.size() * sizeof(T), 1) != 0) {
+    std::fprintf(stderr, "device upload failed\n");
+    std::exit(2);
+  }
+  return static_cast<T*>(d);
+}
+
 // A box room sampled on a lattice with a deterministic jitter, and the same surfaces seen from a
 // frame displaced by a known rigid motion: the 3D adapter must recover that motion.
 static void room3d(std::vector<float>& x, std::vector<float>& y, std::vector<float>& z, unsigned seed) {
@@ -64,6 +82,38 @@ int main(int argc, char** argv) {
     ndt::NdtMultiHip mm(ndt::NdtMatcherHip::defaultParams(), {0, 0});   // two contexts on device 0
     const auto rm = mm.align({t, t, t}, {s, s, s}, {guess, guess, guess});
     std::printf("multi %.17g %.17g %.17g %d %d\n", rm[2].pose.x, rm[2].pose.y, rm[2].pose.theta, rm[2].iterations, rm[2].status);
+    {
+      // the device-pointer forms: the scan uploaded once, aligned where it lies (the upload above is complete:
+      // hipMemcpy is synchronous), several starts in one chain, and the multi-device context with the RCCL
+      // gather (one device here: a one-rank communicator)
+      float* d_sx = to_device(sx); float* d_sy = to_device(sy);
+      float* d_tx = to_device(tx); float* d_ty = to_device(ty);
+      const ndt::MatchResult rd = m.alignDev(d_sx, d_sy, sx.size(), guess, nullptr, /*complete=*/true);
+      std::printf("dev %.17g %.17g %.17g %d %d\n", rd.pose.x, rd.pose.y, rd.pose.theta, rd.iterations, rd.status);
+      const std::vector<ndt::Pose2> starts = {guess, ndt::Pose2{guess.x + 0.02, guess.y - 0.01, guess.theta + 0.001},
+                                              ndt::Pose2{guess.x - 0.02, guess.y + 0.02, guess.theta - 0.002}};
+      const auto rmulti = m.alignMultiStartDev(d_sx, d_sy, sx.size(), starts, nullptr, true);
+      std::printf("multistart %.17g %.17g %.17g %d %d %d\n", rmulti[0].pose.x, rmulti[0].pose.y, rmulti[0].pose.theta,
+                  rmulti[0].iterations, rmulti[0].status, (int)rmulti.size());
+      const auto rscan = m.alignMultiScanDev({{d_sx, d_sy, sx.size()}, {d_sx, d_sy, sx.size() - 100}}, {guess, guess}, nullptr, true);
+      std::printf("multiscan %.17g %.17g %.17g %d %d\n", rscan[0].pose.x, rscan[0].pose.y, rscan[0].pose.theta,
+                  rscan[0].iterations, rscan[0].status);
+      const std::vector<uint64_t> toff = {0, tx.size(), 2 * tx.size()}, soff = {0, sx.size(), 2 * sx.size()};
+      std::vector<float> tx2(tx), ty2(ty), sx2(sx), sy2(sy);
+      tx2.insert(tx2.end(), tx.begin(), tx.end()); ty2.insert(ty2.end(), ty.begin(), ty.end());
+      sx2.insert(sx2.end(), sx.begin(), sx.end()); sy2.insert(sy2.end(), sy.begin(), sy.end());
+      const std::vector<double> init2 = {guess.x, guess.y, guess.theta, guess.x, guess.y, guess.theta};
+      ndt::NdtMultiHip one(ndt::NdtMatcherHip::defaultParams(), {0});
+      ndt::NdtMultiHip::DeviceShard sh;
+      sh.tx = to_device(tx2); sh.ty = to_device(ty2); sh.toff = to_device(toff);
+      sh.sx = to_device(sx2); sh.sy = to_device(sy2); sh.soff = to_device(soff);
+      sh.init = to_device(init2); sh.n_pairs = 2;
+      const auto rg = one.alignDev({sh});
+      std::printf("rccl %.17g %.17g %.17g %d %d\n", rg[1].pose.x, rg[1].pose.y, rg[1].pose.theta, rg[1].iterations, rg[1].status);
+      (void)hipDeviceSynchronize();
+      void* bufs[] = {d_sx, d_sy, d_tx, d_ty, (void*)sh.tx, (void*)sh.ty, (void*)sh.toff, (void*)sh.sx, (void*)sh.sy, (void*)sh.soff, (void*)sh.init};
+      for (void* b2 : bufs) (void)hipFree(b2);
+    }
     {
       std::vector<float> x, y, z, qx, qy, qz;
       room3d(x, y, z, 1u);

@@ -18,7 +18,8 @@ def exe(tmp_path_factory, ndt_lib):
     libdir = os.path.join(ROOT, "gtsam_ndt_amd", "lib")
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                     os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp"), "-o", str(out),
-                    "-L", libdir, "-lndt_hip", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"],
+                    "-L", libdir, "-lndt_hip", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+                    "-lamdhip64"],
                    check=True)
     return str(out)
 
@@ -61,6 +62,14 @@ def test_adapter_matches_oracle(exe, tmp_path, gpu_lib):
         assert np.abs(pose - np.array(ref["pose"])).max() < 1e-4
         assert int(lines[key][-1]) == 0
     assert lines["multi"] == lines["batch"]          # same kernel, same pair: bit-identical
+    # device-pointer forms through the C++ adapter: the resident scan, several starts / scans per chain (start 0
+    # and scan 0 are the plain alignment: bit-identical to it), the RCCL gather of the multi-device context
+    assert lines["dev"][:5] == lines["single"][:3] + [lines["single"][3], lines["single"][5]]
+    one = np.array([float(v) for v in lines["single"][:3]])      # (1000-point scan: the single call runs the one-workgroup
+    for key in ("multistart", "multiscan"):                       #  kernel, the chains k_iterate's order: equal to rounding)
+        assert np.abs(np.array([float(v) for v in lines[key][:3]]) - one).max() < 2e-6 and int(lines[key][4]) == 0
+    assert lines["multistart"][5] == "3"
+    assert lines["rccl"] == lines["batch"]
     # the coarse-to-fine batch through the adapter = the same call through the ctypes binding
     from gtsam_ndt_amd.matcher import NdtBatch2D, pyramid_params
     guess = (d["init"][0] + 0.5, d["init"][1] - 0.4, d["init"][2] + 0.04)
