@@ -199,3 +199,33 @@ def test_newton_hessian_3d(gpu_lib, small):
         m.set_target(d["tx"], d["ty"], d["tz"])
         r3 = m.align(d["sx"], d["sy"], d["sz"], start)
     assert r3.iterations == 3 and np.abs(np.array(r3.pose) - np.array(ref3["pose"])).max() < 1e-4
+
+
+def test_3d_kernels_reduce_to_the_2d_kernels_on_planar_data(gpu_lib):
+    """The 3D path (k_iterate3, 3D voxel build with Jacobi) and the 2D path (k_iterate, closed-form finalise)
+    are separate kernels; on clouds in the plane z = 0 they must describe the same problem: same valid cells,
+    the same (x, y, yaw) Hessian block and score, and the same converged pose (both within 1e-4 of the oracle)."""
+    from gtsam_ndt_amd import synth
+    from gtsam_ndt_amd.matcher import NdtMatcher2D, NdtMatcher3D
+    from oracle import ndt2d as o2
+    d = synth.make_pair(2, n_tgt=30000, n_src=20000)
+    z, zs = np.zeros_like(d["tx"]), np.zeros_like(d["sx"])
+    idx, other = [0, 1, 5], [2, 3, 4]
+    with NdtMatcher2D(min_points=5, tuning={"team_kernel": 0}) as m2, \
+            NdtMatcher3D(cell_size=0.5, min_points=5, step_max_trans=0.5, min_hits=3) as m3:
+        i2 = m2.set_target(d["tx"], d["ty"])
+        i3 = m3.set_target(d["tx"], d["ty"], z)
+        assert i3.n_valid == i2.n_valid and (i3.width, i3.height, i3.depth) == (i2.width, i2.height, 3)
+        for pose in (d["init"], d["pose"]):
+            H2, g2, s2, n2 = m2.evaluate(d["sx"], d["sy"], pose)
+            H3, g3, s3, n3 = m3.evaluate(d["sx"], d["sy"], zs, (pose[0], pose[1], 0.0, 0.0, 0.0, pose[2]))
+            assert n3 == n2 and abs(s3 - s2) <= 2e-5 * s2
+            assert np.abs(H3[np.ix_(idx, idx)] - H2).max() <= 2e-5 * np.abs(H2).max()
+            assert np.abs(H3[np.ix_(idx, other)]).max() <= 1e-6 * np.abs(H2).max() and np.abs(g3[other]).max() <= 1e-3
+        r2 = m2.align(d["sx"], d["sy"], d["init"])
+        r3 = m3.align(d["sx"], d["sy"], zs, (d["init"][0], d["init"][1], 0.0, 0.0, 0.0, d["init"][2]))
+    prm = o2.NdtParams(min_points=5)
+    ref = o2.align(o2.build_grid(d["tx"], d["ty"], prm), d["sx"], d["sy"], d["init"], prm)
+    assert r2.status == r3.status == ref["status"] == 0
+    assert np.abs(np.array(r3.pose)[idx] - np.array(r2.pose)).max() < 2e-5
+    assert np.abs(np.array(r3.pose)[idx] - np.array(ref["pose"])).max() < 1e-4 and np.abs(np.array(r3.pose)[other]).max() < 1e-6

@@ -97,3 +97,31 @@ def test_newton_hessian_matches_finite_differences_of_the_gradient(small):
     u, w = np.array([-math.sin(ang[2]), math.cos(ang[2]), 0.0]), np.array([0.0, math.cos(ang[0]), -math.sin(ang[0])])
     assert np.allclose(dd[(0, 0)], col(Ra)) and np.allclose(dd[(0, 1)], col(Rb)) and np.allclose(dd[(0, 2)], row(Ra))
     assert np.allclose(dd[(1, 1)], -R + np.outer(u, w)) and np.allclose(dd[(1, 2)], row(Rb)) and np.allclose(dd[(2, 2)], row(Rg))
+
+
+def test_3d_oracle_reduces_to_the_2d_oracle_on_planar_data():
+    """Two independently written restatements (2D: closed-form eigen-decomposition, 2x3 Jacobian; 3D: cyclic
+    Jacobi, 3x6 Jacobian, Euler angles) must agree when the clouds lie in the plane z = 0: the (x, y, yaw)
+    block of the 3D Hessian and gradient equals the 2D ones, the other block is zero, and the alignments
+    take the same steps."""
+    from gtsam_ndt_amd import synth
+    from oracle import ndt2d as o2
+    d = synth.make_pair(2, n_tgt=30000, n_src=20000)
+    z, zs = np.zeros_like(d["tx"]), np.zeros_like(d["sx"])
+    p2 = o2.NdtParams(min_points=5)
+    p3 = o.Ndt3Params(cell_size=0.5, min_points=5, step_max_trans=0.5, min_hits=3)
+    g2 = o2.build_grid(d["tx"], d["ty"], p2)
+    g3 = o.build_grid3(d["tx"], d["ty"], z, p3)
+    assert g3.n_valid == g2.n_valid and g3.dims[:2] == (g2.W, g2.H)
+    idx, other = [0, 1, 5], [2, 3, 4]
+    for pose in (d["init"], d["pose"]):
+        H2, gr2, s2, n2 = o2.evaluate(g2, d["sx"], d["sy"], pose, p2)
+        H3, gr3, s3, n3 = o.evaluate3(g3, d["sx"], d["sy"], zs, (pose[0], pose[1], 0.0, 0.0, 0.0, pose[2]), p3)
+        assert n3 == n2 and abs(s3 - s2) <= 1e-12 * s2
+        assert np.abs(H3[np.ix_(idx, idx)] - H2).max() <= 1e-12 * np.abs(H2).max()
+        assert np.abs(gr3[idx] - gr2).max() <= 1e-11 * np.sqrt(np.abs(np.diag(H2)) * s2).max()
+        assert np.abs(H3[np.ix_(idx, other)]).max() == 0.0 and np.abs(gr3[other]).max() == 0.0
+    r2 = o2.align(g2, d["sx"], d["sy"], d["init"], p2)
+    r3 = o.align3(g3, d["sx"], d["sy"], zs, (d["init"][0], d["init"][1], 0.0, 0.0, 0.0, d["init"][2]), p3)
+    assert r2["status"] == r3["status"] == 0 and r2["iterations"] == r3["iterations"]
+    assert np.abs(np.array(r3["pose"])[idx] - np.array(r2["pose"])).max() < 1e-12 and np.abs(np.array(r3["pose"])[other]).max() == 0.0
