@@ -169,6 +169,13 @@ SIGNATURES = {
     "ndt3d_align_finish": (C.c_int32, [_vp, C.POINTER(Result3D)]),
     "ndt3d_stream": (_vp, [_vp]),
     "ndt3d_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result3D)]),
+    "ndt3d_batch_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),
+    "ndt3d_batch_create_pyramid": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "ndt3d_batch_destroy": (C.c_int32, [_vp]),
+    "ndt3d_batch_align": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ndt3d_batch_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "ndt3d_batch_stream": (_vp, [_vp]),
+    "ndt3d_batch_wait_stream": (C.c_int32, [_vp, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,461 @@
+// 3D loop-closure candidate batch: the 3D twin of ndt2d_batch.hpp.  Persistent 1024-thread workgroups
+// (one per CU) pull scan pairs from a queue and run the whole alignment of a pair on chip:
+//   - the pair's voxel grid lives in LDS for the Gauss-Newton loop: a dense u16 voxel -> slot table
+//     and 40-byte records (mean, n | Sigma^-1) per occupied voxel.  The carve is per pair: the
+//     table takes 2 bytes per voxel, the records get the rest (config 5: 44 x 44 x 9 = 17 424
+//     voxels, 2 706 occupied: 35 KB + 108 KB of the 160 KB);
+//   - the nine exact fixed-point sums of a voxel (72 bytes per slot) do not fit next to the table,
+//     so the build adds them up in LDS three at a time (three passes over the target, which is
+//     L2-resident after the first) and parks each pass in a per-workgroup slab of global memory;
+//     the finalise reads them back once and writes the records into LDS;
+//   - source points stream from HBM/L2 once per iteration; the 29 (Newton: 38) sums are reduced
+//     per wave (DPP) -> LDS -> wave 0, which also does the 6x6 solve: two workgroup barriers per
+//     iteration, no kernel boundary.
+// Same arithmetic as the single-pair 3D path: finalise_sums3, accumulate_point3, gn_update3 are
+// the functions k_finalise3 / k_iterate3 use, and the slab sums are the integers k_accumulate3 forms.
+#pragma once
+#include "ndt2d_batch.hpp"
+#include "ndt3d_kernels.hpp"
+
+namespace ndt {
+
+struct Result3Dev {   // layout of ndt3d_result (include/ndt_hip.h); static_assert in the API file
+  double pose[6];
+  double H[36];
+  double g[6];
+  double score;
+  int iterations, n_hit, status, reserved;
+};
+
+struct Batch3Args {
+  const float* tx; const float* ty; const float* tz; const unsigned long long* toff;   // targets, concatenated SoA
+  const float* sx; const float* sy; const float* sz; const unsigned long long* soff;   // sources
+  const double* init;        // [n_pairs][6]
+  Result3Dev* out;           // [n_pairs]
+  unsigned int* queue;       // zeroed before the launch
+  unsigned char* slab;       // [gridDim.x][kB3SlabBytes]
+  int n_pairs;
+  int min_points;
+  int fixed_iterations;
+  int chain;                 // as BatchArgs::chain (a later level of a coarse-to-fine run)
+  double cell;
+  double eig_ratio;
+  SolveParams prm;
+};
+
+constexpr int kB3Threads = 1024;
+constexpr int kB3Waves = kB3Threads / 64;
+constexpr int kB3MaxSlots = 4096;                       // bound of the slab; the LDS carve allows fewer
+// LDS carve (bytes).  Fixed part first, then the voxel table (u16 per voxel), then the records.
+constexpr int kB3Red = 0;                               // float [Waves][kNumAcc3]
+constexpr int kB3Bc = kB3Red + kB3Waves * kNumAcc3 * 4; // double [48]: pose(6) | sums(38)
+constexpr int kB3Misc = kB3Bc + 48 * 8;                 // int [16]
+constexpr int kB3Scan = kB3Misc + 64;                   // int [16]
+constexpr int kB3Ls = kB3Scan + 64;                     // LineSearch3
+constexpr int kB3Idx = kB3Ls + 128;                     // u16 [ncell]
+constexpr int kB3LdsBytes = 160 * 1024;
+constexpr int kB3RecBytes = 40;                         // per slot: float4 (mean, n) + float4 (xx xy xz yy) + float2 (yz zz)
+static_assert(sizeof(LineSearch3) <= 128 && (kB3Idx % 16) == 0 && (kB3Bc % 16) == 0, "carve");
+// slab of one workgroup: u32 slot_n[S], u32 slot_key[S], u64 sums[9][S]
+constexpr int kB3SlabN = 0;
+constexpr int kB3SlabKey = kB3SlabN + kB3MaxSlots * 4;
+constexpr int kB3SlabSums = kB3SlabKey + kB3MaxSlots * 4;
+constexpr int kB3SlabBytes = kB3SlabSums + 9 * kB3MaxSlots * 8;
+
+constexpr int kTgt3Unroll = 4;
+template <typename F>
+__device__ __forceinline__ void for_each_target_point3(const float* tx, const float* ty, const float* tz, int nt, F&& body) {
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)tx, 0, nt * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)ty, 0, nt * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)tz, 0, nt * 4, 0x00020000);
+  for (int i = threadIdx.x; i < nt; i += kTgt3Unroll * kB3Threads) {
+    float x[kTgt3Unroll], y[kTgt3Unroll], z[kTgt3Unroll];
+#pragma unroll
+    for (int u = 0; u < kTgt3Unroll; ++u) {
+      const int off = (i + u * kB3Threads) * 4;
+      x[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+      y[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
+      z[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, off, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < kTgt3Unroll; ++u)
+      if (i + u * kB3Threads < nt) body(x[u], y[u], z[u]);
+  }
+}
+
+struct Cfg1024 { static constexpr int kWaves = kB3Waves; };   // for block_excl_scan
+
+__device__ __forceinline__ void write_result3(Result3Dev* o, const double* pose, const double* s21, const double* g,
+                                              double score, int iter, int n_hit, int status) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { o->pose[j] = pose[j]; o->g[j] = g ? g[j] : 0.0; }
+  double H[36];
+#pragma unroll
+  for (int j = 0; j < 36; ++j) H[j] = 0.0;
+  if (s21) {   // Htt(6) Htr(9) Hrr(6), as unpack_h21 on the host
+    H[0] = s21[0]; H[1] = s21[1]; H[2] = s21[2]; H[7] = s21[3]; H[8] = s21[4]; H[14] = s21[5];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) H[6 * r + 3 + k] = s21[6 + 3 * r + k];
+    H[21] = s21[15]; H[22] = s21[16]; H[23] = s21[17]; H[28] = s21[18]; H[29] = s21[19]; H[35] = s21[20];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < r; ++c) H[6 * r + c] = H[6 * c + r];
+  }
+#pragma unroll
+  for (int j = 0; j < 36; ++j) o->H[j] = H[j];
+  o->score = score;
+  o->iterations = iter; o->n_hit = n_hit; o->status = status; o->reserved = 0;
+}
+
+// One pair, start to finish, on the calling workgroup (plain returns for the early outs: see process_pair).
+template <int MODE>
+__device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pair, unsigned char* smem) {
+  constexpr int NA = Acc3<MODE>::kUsed;
+  float* red = reinterpret_cast<float*>(smem + kB3Red);
+  double* bc = reinterpret_cast<double*>(smem + kB3Bc);
+  int* misc = reinterpret_cast<int*>(smem + kB3Misc);
+  int* s_scan = reinterpret_cast<int*>(smem + kB3Scan);
+  LineSearch3* ls_lds = reinterpret_cast<LineSearch3*>(smem + kB3Ls);
+  unsigned short* idx = reinterpret_cast<unsigned short*>(smem + kB3Idx);
+  unsigned char* slab = a.slab + (size_t)blockIdx.x * kB3SlabBytes;
+  unsigned int* slot_n = reinterpret_cast<unsigned int*>(slab + kB3SlabN);
+  unsigned int* slot_key = reinterpret_cast<unsigned int*>(slab + kB3SlabKey);
+  unsigned long long* gsums = reinterpret_cast<unsigned long long*>(slab + kB3SlabSums);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int minpts = a.min_points < 2 ? 2 : a.min_points;
+
+  const unsigned long long t0 = uniform64(a.toff[pair]), s0 = uniform64(a.soff[pair]);
+  const unsigned long long nt64 = uniform64(a.toff[pair + 1]) - t0, ns64 = uniform64(a.soff[pair + 1]) - s0;
+  double pose[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) pose[j] = a.init[6 * pair + j];
+  Result3Dev* out = a.out + pair;
+  if (nt64 > (unsigned long long)kBatchMaxCloud || ns64 > (unsigned long long)kBatchMaxCloud) {   // uniform; also offsets out of order
+    if (tid == 0) write_result3(out, pose, nullptr, nullptr, 0.0, 0, 0, kStatusInvalid);
+    return;
+  }
+#pragma unroll
+  for (int j = 3; j < 6; ++j) pose[j] = wrap_angle(pose[j]);
+  const int nt = (int)nt64, ns = (int)ns64;
+  const float* __restrict__ tx = a.tx + t0;
+  const float* __restrict__ ty = a.ty + t0;
+  const float* __restrict__ tz = a.tz + t0;
+  const float* __restrict__ sx = a.sx + s0;
+  const float* __restrict__ sy = a.sy + s0;
+  const float* __restrict__ sz = a.sz + s0;
+  int iter_base = 0;
+  if (a.chain) {                                   // uniform
+    const int pst = __builtin_amdgcn_readfirstlane(out->status);
+    if (pst != 0 && pst != 1) return;              // the coarser level's failure is the pair's result
+#pragma unroll
+    for (int j = 0; j < 6; ++j) pose[j] = out->pose[j];
+    iter_base = __builtin_amdgcn_readfirstlane(out->iterations);
+    __syncthreads();                               // every wave has read out[pair] before anyone rewrites it
+  }
+
+  // ---- a1: bounding box of the target and grid geometry (oracle/ndt3d.py grid_geometry3)
+  {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for_each_target_point3(tx, ty, tz, nt, [&](float u, float v, float w) {
+      if (isfinite(u) && isfinite(v) && isfinite(w)) {
+        mn[0] = fminf(mn[0], u); mx[0] = fmaxf(mx[0], u);
+        mn[1] = fminf(mn[1], v); mx[1] = fmaxf(mx[1], v);
+        mn[2] = fminf(mn[2], w); mx[2] = fmaxf(mx[2], w);
+      }
+    });
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]);
+      if (lane == 0) { red[wave * 6 + 2 * c] = mn[c]; red[wave * 6 + 2 * c + 1] = mx[c]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int st = 0, dims[3] = {0, 0, 0};
+      float o[3] = {0.f, 0.f, 0.f};
+      const float inv_c = (float)(1.0 / a.cell);
+      double ncell_d = 1.0;
+      for (int c = 0; c < 3; ++c) {
+        for (int w = 1; w < kB3Waves; ++w) { mn[c] = fminf(mn[c], red[w * 6 + 2 * c]); mx[c] = fmaxf(mx[c], red[w * 6 + 2 * c + 1]); }
+        if (!(mn[c] <= mx[c])) { st = 4; break; }     // no finite target point -> no valid voxel
+        o[c] = (float)((floor((double)mn[c] / a.cell) - 1.0) * a.cell);
+        const float k = floorf((mx[c] - o[c]) * inv_c);
+        if (!(k >= 0.f) || k > 65534.f) { st = kStatusCapacity; break; }
+        dims[c] = (int)k + 2;
+        ncell_d *= (double)dims[c];
+      }
+      // the voxel table (2 B per voxel) and, during the build, the counts (4 B per voxel) behind it
+      if (st == 0 && (ncell_d > 65535.0 || kB3Idx + 16 + 6.0 * ncell_d > (double)kB3LdsBytes)) st = kStatusCapacity;
+      misc[1] = dims[0]; misc[2] = dims[1]; misc[3] = dims[2]; misc[4] = st;
+      reinterpret_cast<float*>(misc)[5] = o[0];
+      reinterpret_cast<float*>(misc)[6] = o[1];
+      reinterpret_cast<float*>(misc)[7] = o[2];
+    }
+    __syncthreads();
+  }
+  const int W = __builtin_amdgcn_readfirstlane(misc[1]), Hh = __builtin_amdgcn_readfirstlane(misc[2]),
+            D = __builtin_amdgcn_readfirstlane(misc[3]);
+  const int st0 = __builtin_amdgcn_readfirstlane(misc[4]);
+  const float ox = uniformf(reinterpret_cast<float*>(misc)[5]), oy = uniformf(reinterpret_cast<float*>(misc)[6]),
+              oz = uniformf(reinterpret_cast<float*>(misc)[7]);
+  const float inv_c = (float)(1.0 / a.cell);
+  const float fW = (float)W, fH = (float)Hh, fD = (float)D;
+  const int ncell = W * Hh * D;
+  const double fix_scale = 4194304.0 / a.cell;     // 2^kFixShift / c
+  static_assert(kFixShift == 22, "fix_scale literal");
+  __syncthreads();                                 // misc is rewritten below
+  if (st0 != 0) {                                  // uniform
+    if (tid == 0) write_result3(out, pose, nullptr, nullptr, 0.0, iter_base, 0, st0);
+    return;
+  }
+  // per-pair carve behind the voxel table
+  const int rec_base = (kB3Idx + 2 * ncell + 15) & ~15;
+  const int slot_cap = (kB3LdsBytes - rec_base) / kB3RecBytes;      // records incl. the dummy record 0
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + rec_base);                   // build: u32 [ncell]
+  unsigned long long* psum = reinterpret_cast<unsigned long long*>(smem + rec_base);      // build: u64 [3][nslot]
+  float4* recA = reinterpret_cast<float4*>(smem + rec_base);
+  float4* recB = reinterpret_cast<float4*>(smem + rec_base + 16 * slot_cap);
+  float2* recC = reinterpret_cast<float2*>(smem + rec_base + 32 * slot_cap);
+
+  auto voxel_of = [&](float px, float py, float pz, int& ix, int& iy, int& iz) -> bool {
+    const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c, fz = (pz - oz) * inv_c;
+    const bool in = (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
+    ix = (int)fx; iy = (int)fy; iz = (int)fz;
+    return in;
+  };
+
+  // ---- a2 (1/2): per-voxel counts
+  for (int k = tid; k < ncell; k += kB3Threads) cnt[k] = 0u;
+  __syncthreads();
+  for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+    int ix, iy, iz;
+    if (voxel_of(px, py, pz, ix, iy, iz)) atomicAdd(&cnt[(iz * Hh + iy) * W + ix], 1u);
+  });
+  __syncthreads();
+
+  // ---- compaction: voxels with n >= min_points get a slot, in voxel order (deterministic)
+  const int chunk = (ncell + kB3Threads - 1) / kB3Threads;
+  const int c0 = tid * chunk < ncell ? tid * chunk : ncell;
+  const int c1 = c0 + chunk < ncell ? c0 + chunk : ncell;
+  int local = 0;
+  for (int k = c0; k < c1; ++k) local += (cnt[k] >= (unsigned)minpts) ? 1 : 0;
+  int nslot = 0;
+  int s = block_excl_scan<Cfg1024>(local, s_scan, &nslot);
+  nslot = __builtin_amdgcn_readfirstlane(nslot);
+  if (nslot + 1 > slot_cap || nslot > kB3MaxSlots || nslot < 1) {   // uniform (record 0 is the dummy)
+    if (tid == 0) write_result3(out, pose, nullptr, nullptr, 0.0, iter_base, 0, nslot < 1 ? 4 : kStatusCapacity);
+    return;
+  }
+  for (int k = c0; k < c1; ++k) {
+    const unsigned int n = cnt[k];
+    if (n >= (unsigned)minpts) {
+      idx[k] = (unsigned short)(s + 1);
+      slot_n[s] = n;
+      slot_key[s] = (unsigned)k;
+      ++s;
+    } else {
+      idx[k] = 0;
+    }
+  }
+  __syncthreads();                                 // cnt is dead; its bytes become the pass sums
+
+  // ---- a2 (2/2): exact fixed-point sums per slot, three of the nine per pass (LDS 64-bit integer atomics)
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int j = tid; j < 3 * nslot; j += kB3Threads) psum[j] = 0ull;
+    __syncthreads();
+    for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+      int ix, iy, iz;
+      if (voxel_of(px, py, pz, ix, iy, iz)) {
+        const int slot = idx[(iz * Hh + iy) * W + ix];
+        if (slot) {
+          const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
+          const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
+          const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
+          unsigned long long* q = psum + (slot - 1);
+          if (pass == 0) {          // s[0..2]
+            atomicAdd(q, (unsigned long long)(long long)ux);
+            atomicAdd(q + nslot, (unsigned long long)(long long)uy);
+            atomicAdd(q + 2 * nslot, (unsigned long long)(long long)uz);
+          } else if (pass == 1) {   // ss[0..2] = xx xy xz
+            atomicAdd(q, prod64(ux, ux));
+            atomicAdd(q + nslot, prod64(ux, uy));
+            atomicAdd(q + 2 * nslot, prod64(ux, uz));
+          } else {                  // ss[3..5] = yy yz zz
+            atomicAdd(q, prod64(uy, uy));
+            atomicAdd(q + nslot, prod64(uy, uz));
+            atomicAdd(q + 2 * nslot, prod64(uz, uz));
+          }
+        }
+      }
+    });
+    __syncthreads();
+    for (int j = tid; j < 3 * nslot; j += kB3Threads)
+      gsums[(size_t)(3 * pass + j / nslot) * kB3MaxSlots + (j % nslot)] = psum[j];
+    __syncthreads();
+  }
+  if (tid == 0) misc[8] = 0;
+  __threadfence();                                 // the slab was written with plain stores by other waves of this workgroup
+  __syncthreads();
+
+  // ---- a3: finalise, records into LDS
+  {
+    int nvalid = 0;
+    for (int sl = tid; sl < nslot; sl += kB3Threads) {
+      CellAcc3 c;
+      c.n = slot_n[sl]; c.pad = 0u;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) c.s[j] = (long long)gsums[(size_t)j * kB3MaxSlots + sl];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) c.ss[j] = (long long)gsums[(size_t)(3 + j) * kB3MaxSlots + sl];
+      const unsigned int key = slot_key[sl], w32 = (unsigned)W, h32 = (unsigned)Hh;
+      const int ix = (int)(key % w32), iy = (int)((key / w32) % h32), iz = (int)(key / (w32 * h32));
+      float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+      bool ok = false;
+      if (c.n <= kMaxCellCount)
+        ok = finalise_sums3(c, cell_centre(ox, ix, a.cell), cell_centre(oy, iy, a.cell), cell_centre(oz, iz, a.cell), fix_scale,
+                            a.min_points, a.eig_ratio, ra, rb, rc);
+      if (!ok) { ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = ra; rc = ra; }
+      recA[sl + 1] = ra; recB[sl + 1] = rb; recC[sl + 1] = make_float2(rc.x, rc.y);
+      nvalid += ok ? 1 : 0;
+    }
+    if (tid == 0) { recA[0] = make_float4(0.f, 0.f, 0.f, 0.f); recB[0] = recA[0]; recC[0] = make_float2(0.f, 0.f); }
+    if (nvalid) atomicAdd(&misc[8], nvalid);
+    __syncthreads();
+  }
+  if (__builtin_amdgcn_readfirstlane(misc[8]) < 1) {   // uniform
+    __syncthreads();
+    if (tid == 0) write_result3(out, pose, nullptr, nullptr, 0.0, iter_base, 0, 4);
+    return;
+  }
+
+  // ---- a4-a8: Gauss-Newton loop, all on this CU
+  if (tid == 0) { misc[9] = 0; misc[10] = 0; ls_lds->valid = 0; ls_lds->trials = 0; }
+  __syncthreads();
+  const float d1 = a.prm.d1, d2 = a.prm.d2;
+  const float nhd2 = -0.5f * d2 * 1.44269504088896340736f;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)sx, 0, ns * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)sy, 0, ns * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)sz, 0, ns * 4, 0x00020000);
+  for (;;) {
+    float acc[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) acc[j] = 0.f;
+    {
+      Rot3F T;
+      make_rot3(pose, T);
+      // the pose is the same in every lane: SGPRs, not 39 VGPRs held across the point loop
+#pragma unroll
+      for (int j = 0; j < 9; ++j) { T.R[j] = uniformf(T.R[j]); T.Ra[j] = uniformf(T.Ra[j]); T.Rb[j] = uniformf(T.Rb[j]); T.Rg[j] = uniformf(T.Rg[j]); }
+      T.tx = uniformf(T.tx); T.ty = uniformf(T.ty); T.tz = uniformf(T.tz);
+      // software-pipelined source stream, as in process_pair: two register sets, one in flight while
+      // the other is consumed
+      float xa, ya, za, xb, yb, zb;
+      auto load_set = [&](int i, float& x, float& y, float& z) {
+        const int off = i * 4;
+        x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+        y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
+        z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, off, 0, 0));
+      };
+      auto consume = [&](int i, float x, float y, float z) {
+        float px = fmaf(T.R[0], x, fmaf(T.R[1], y, fmaf(T.R[2], z, T.tx)));
+        float py = fmaf(T.R[3], x, fmaf(T.R[4], y, fmaf(T.R[5], z, T.ty)));
+        float pz = fmaf(T.R[6], x, fmaf(T.R[7], y, fmaf(T.R[8], z, T.tz)));
+        const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c, fz = (pz - oz) * inv_c;
+        const bool in = (i < ns) & (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
+        const int key = in ? (((int)fz * Hh + (int)fy) * W + (int)fx) : 0;
+        int slot = idx[key];
+        if (!in) { px = py = pz = 0.f; x = y = z = 0.f; slot = 0; }
+        const float4 A4 = recA[slot];
+        const float4 B4 = recB[slot];
+        const float2 c2 = recC[slot];
+        const float4 C2 = make_float4(c2.x, c2.y, 0.f, 0.f);
+        accumulate_point3<MODE>(T, x, y, z, px, py, pz, in, A4, B4, C2, d1, d2, nhd2, acc);
+      };
+      if (ns > 0) {                                  // uniform
+        load_set(tid, xa, ya, za);
+        for (int i = tid; i < ns; i += 2 * kB3Threads) {
+          load_set(i + kB3Threads, xb, yb, zb);
+          consume(i, xa, ya, za);
+          load_set(i + 2 * kB3Threads, xa, ya, za);
+          if (i + kB3Threads < ns) consume(i + kB3Threads, xb, yb, zb);     // wave-uniform except at the tail
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const float rsum = wave_sum_lane63(acc[j]);
+      if (lane == 63) red[wave * kNumAcc3 + j] = rsum;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lane j < NA sums column j over the waves in a fixed order, in float64, and parks it in LDS;
+      // every lane reads the totals back (broadcast reads)
+      if (lane < NA) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < kB3Waves; ++w) tot += (double)red[w * kNumAcc3 + lane];
+        bc[6 + lane] = tot;
+      }
+      __builtin_amdgcn_wave_barrier();               // same wave: LDS executes its operations in order
+      const double* sr = bc + 6;
+      double A[36], g[6];
+      A[0] = sr[0]; A[1] = sr[1]; A[2] = sr[2]; A[7] = sr[3]; A[8] = sr[4]; A[14] = sr[5];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) A[6 * r + 3 + k] = sr[6 + 3 * r + k];
+      A[21] = sr[15]; A[22] = sr[16]; A[23] = sr[17]; A[28] = sr[18]; A[29] = sr[19]; A[35] = sr[20];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < r; ++c) A[6 * r + c] = A[6 * c + r];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) g[j] = sr[21 + j];
+      const double score = sr[27];
+      const int n_hit = (int)(sr[28] + 0.5);
+      if (MODE == 1) newton_rot_block3(pose, sr + 29, A);
+      int iter = misc[9], st = 0;
+      const bool done = gn_update3(pose, A, g, n_hit, iter, st, a.prm, a.fixed_iterations, score, ls_lds, ls_lds, lane == 0);
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bc[j] = pose[j];
+        if (MODE == 1) {                 // the reported rotation block is the full one
+          bc[6 + 15] = A[21]; bc[6 + 16] = A[22]; bc[6 + 17] = A[23]; bc[6 + 18] = A[28]; bc[6 + 19] = A[29]; bc[6 + 20] = A[35];
+        }
+        misc[11] = done ? 1 : 0;
+        misc[9] = iter;
+        misc[10] = st;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 6; ++j) pose[j] = bc[j];
+    const int done = __builtin_amdgcn_readfirstlane(misc[11]);
+    if (done) break;
+    // no third barrier, as in process_pair: the next iteration writes `red` after its point loop and
+    // bc / misc only after its own first barrier
+  }
+  if (tid == 0)
+    write_result3(out, pose, bc + 6, bc + 6 + 21, bc[6 + 27], misc[9] + iter_base, (int)(bc[6 + 28] + 0.5), misc[10]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kB3Threads) void k_batch3(Batch3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* misc = reinterpret_cast<int*>(smem + kB3Misc);
+  for (;;) {
+    if (threadIdx.x == 0) misc[0] = (int)atomicAdd(a.queue, 1u);
+    __syncthreads();
+    const int pair = __builtin_amdgcn_readfirstlane(misc[0]);
+    __syncthreads();
+    if (pair >= a.n_pairs) break;
+    process_pair3<MODE>(a, pair, smem);
+    __syncthreads();                                 // LDS and the slab are rewritten by the next pair
+  }
+}
+
+}  // namespace ndt

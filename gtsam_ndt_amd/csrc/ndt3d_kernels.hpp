@@ -309,6 +309,160 @@ __device__ __forceinline__ bool gn_update3(double* pose, const double* A, const 
   return false;
 }
 
+// Newton form of the rotation block (MODE 1): A[3..5][3..5] += sum_ab (d2R / dk dl)[a][b] M[a][b] with
+// M[3a + b] = sum w v_a p_b (rows 29..37 of the sums), at the pose the sums were taken at.
+__device__ __forceinline__ void newton_rot_block3(const double* pose, const double* M, double* A) {
+  // The six second derivatives follow from R and its first derivatives:
+  // a roll derivative maps columns (1, 2) -> (col 2, -col 1), a yaw derivative rows (0, 1) ->
+  // (-row 1, row 0), and d2Ry = -Ry + e_y e_y' (oracle/ndt3d.py rot_second_derivs states the products).
+  double sa, ca, sb, cb, sg, cg;
+  sincos_wrapped(pose[3], &sa, &ca);
+  sincos_wrapped(pose[4], &sb, &cb);
+  sincos_wrapped(pose[5], &sg, &cg);
+  const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
+                       sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
+                       -sb, cb * sa, cb * ca};
+  const double Rb[9] = {-cg * sb, cg * cb * sa, cg * cb * ca, -sg * sb, sg * cb * sa, sg * cb * ca, -cb, -sb * sa, -sb * ca};
+  auto cols = [&](const double* X) {                       // roll derivative of X: (0, X[:,2], -X[:,1]) . M
+    double t2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) t2 += X[3 * a + 2] * M[3 * a + 1] - X[3 * a + 1] * M[3 * a + 2];
+    return t2;
+  };
+  auto rows = [&](const double* X) {                       // yaw derivative of X: (-X[1,:], X[0,:], 0) . M
+    double t2 = 0.0;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) t2 += -X[3 + b] * M[b] + X[b] * M[3 + b];
+    return t2;
+  };
+  const double Ra[9] = {0.0, R[2], -R[1], 0.0, R[5], -R[4], 0.0, R[8], -R[7]};
+  double h_aa = 0.0, h_gg = 0.0, h_bb = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) h_aa -= R[3 * a + 1] * M[3 * a + 1] + R[3 * a + 2] * M[3 * a + 2];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) h_gg -= R[b] * M[b] + R[3 + b] * M[3 + b];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) h_bb -= R[k] * M[k];
+  {
+    const double u[3] = {-sg, cg, 0.0}, w3[3] = {0.0, ca, -sa};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) h_bb += u[a] * w3[b] * M[3 * a + b];
+  }
+  const double h_ab = cols(Rb), h_ag = rows(Ra), h_bg = rows(Rb);
+  A[21] += h_aa; A[22] += h_ab; A[23] += h_ag; A[28] += h_bb; A[29] += h_bg; A[35] += h_gg;
+  A[27] = A[22]; A[33] = A[23]; A[34] = A[29];
+}
+
+// Rotation, its three first-derivative matrices and the translation of a pose, float64 -> float32.
+struct Rot3F {
+  float R[9], Ra[9], Rb[9], Rg[9];
+  float tx, ty, tz;
+};
+__device__ __forceinline__ void make_rot3(const double* pose, Rot3F& T) {
+  double sa, ca, sb, cb, sg, cg;
+  sincos_wrapped(pose[3], &sa, &ca);
+  sincos_wrapped(pose[4], &sb, &cb);
+  sincos_wrapped(pose[5], &sg, &cg);
+  // R = Rz Ry Rx
+  const double r00 = cg * cb, r01 = cg * sb * sa - sg * ca, r02 = cg * sb * ca + sg * sa;
+  const double r10 = sg * cb, r11 = sg * sb * sa + cg * ca, r12 = sg * sb * ca - cg * sa;
+  const double r20 = -sb, r21 = cb * sa, r22 = cb * ca;
+  T.R[0] = (float)r00; T.R[1] = (float)r01; T.R[2] = (float)r02; T.R[3] = (float)r10; T.R[4] = (float)r11; T.R[5] = (float)r12;
+  T.R[6] = (float)r20; T.R[7] = (float)r21; T.R[8] = (float)r22;
+  // d/droll: columns 1,2 rotate: dR[:,1] = R[:,2], dR[:,2] = -R[:,1], dR[:,0] = 0
+  T.Ra[0] = 0.f; T.Ra[1] = (float)r02; T.Ra[2] = (float)(-r01);
+  T.Ra[3] = 0.f; T.Ra[4] = (float)r12; T.Ra[5] = (float)(-r11);
+  T.Ra[6] = 0.f; T.Ra[7] = (float)r22; T.Ra[8] = (float)(-r21);
+  // d/dpitch = Rz dRy Rx
+  T.Rb[0] = (float)(-cg * sb); T.Rb[1] = (float)(cg * cb * sa); T.Rb[2] = (float)(cg * cb * ca);
+  T.Rb[3] = (float)(-sg * sb); T.Rb[4] = (float)(sg * cb * sa); T.Rb[5] = (float)(sg * cb * ca);
+  T.Rb[6] = (float)(-cb);      T.Rb[7] = (float)(-sb * sa);     T.Rb[8] = (float)(-sb * ca);
+  // d/dyaw: rows rotate: dR[0,:] = -R[1,:], dR[1,:] = R[0,:], dR[2,:] = 0
+  T.Rg[0] = (float)(-r10); T.Rg[1] = (float)(-r11); T.Rg[2] = (float)(-r12);
+  T.Rg[3] = (float)r00;    T.Rg[4] = (float)r01;    T.Rg[5] = (float)r02;
+  T.Rg[6] = 0.f; T.Rg[7] = 0.f; T.Rg[8] = 0.f;
+  T.tx = (float)pose[0]; T.ty = (float)pose[1]; T.tz = (float)pose[2];
+}
+
+// a5 + a6 for one point: p = the untransformed source point, pp = R p + t (both zeroed by the caller when the
+// image lies outside the grid), the voxel record (A4 = mean | n, B4 = Sigma^-1 xx xy xz yy, C2 = yz zz).
+// acc: Htt(6) Htr(9) Hrr(6) g(6) score n_hit [+ M(9) in Newton mode].
+template <int MODE>
+__device__ __forceinline__ void accumulate_point3(const Rot3F& T, float x, float y, float z, float px, float py,
+                                                  float pz, bool in, const float4& A4, const float4& B4,
+                                                  const float4& C2, float d1, float d2, float nhd2, float* acc) {
+  const bool hit = in & (A4.w > 0.f);
+  const float qx = px - A4.x, qy = py - A4.y, qz = pz - A4.z;
+  const float cxx = B4.x, cxy = B4.y, cxz = B4.z, cyy = B4.w, cyz = C2.x, czz = C2.y;
+  const float vx = fmaf(cxx, qx, fmaf(cxy, qy, cxz * qz));
+  const float vy = fmaf(cxy, qx, fmaf(cyy, qy, cyz * qz));
+  const float vz = fmaf(cxz, qx, fmaf(cyz, qy, czz * qz));
+  const float m = fmaf(qx, vx, fmaf(qy, vy, qz * vz));
+  const float s = hit ? d1 * __builtin_amdgcn_exp2f(nhd2 * m) : 0.f;
+  const float w = s * d2;
+  float J[3][3], U[3][3];   // J[k] = dR_k p ; U[k] = Sigma^-1 J[k]
+  const float* Rd[3] = {T.Ra, T.Rb, T.Rg};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    J[k][0] = fmaf(Rd[k][0], x, fmaf(Rd[k][1], y, Rd[k][2] * z));
+    J[k][1] = fmaf(Rd[k][3], x, fmaf(Rd[k][4], y, Rd[k][5] * z));
+    J[k][2] = fmaf(Rd[k][6], x, fmaf(Rd[k][7], y, Rd[k][8] * z));
+    U[k][0] = fmaf(cxx, J[k][0], fmaf(cxy, J[k][1], cxz * J[k][2]));
+    U[k][1] = fmaf(cxy, J[k][0], fmaf(cyy, J[k][1], cyz * J[k][2]));
+    U[k][2] = fmaf(cxz, J[k][0], fmaf(cyz, J[k][1], czz * J[k][2]));
+  }
+  const float v3[3] = {vx, vy, vz};
+  float tk[3];                                               // v' J_k
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tk[k] = fmaf(vx, J[k][0], fmaf(vy, J[k][1], vz * J[k][2]));
+  const float wd = MODE == 1 ? -d2 * w : 0.f;                // Newton: - d2 w (J'v)(J'v)' on every entry
+  {
+    const float cc[6] = {cxx, cxy, cxz, cyy, cyz, czz};
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = i; j < 3; ++j) {
+        acc[q] = fmaf(w, cc[q], acc[q]);
+        if (MODE == 1) acc[q] = fmaf(wd * v3[i], v3[j], acc[q]);
+        ++q;
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      acc[6 + 3 * r + k] = fmaf(w, U[k][r], acc[6 + 3 * r + k]);
+      if (MODE == 1) acc[6 + 3 * r + k] = fmaf(wd * v3[r], tk[k], acc[6 + 3 * r + k]);
+    }
+  {
+    int q = 15;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = k; l < 3; ++l) {
+        const float h = fmaf(J[k][0], U[l][0], fmaf(J[k][1], U[l][1], J[k][2] * U[l][2]));
+        acc[q] = fmaf(w, h, acc[q]);
+        if (MODE == 1) acc[q] = fmaf(wd * tk[k], tk[l], acc[q]);
+        ++q;
+      }
+  }
+  acc[21] = fmaf(w, vx, acc[21]); acc[22] = fmaf(w, vy, acc[22]); acc[23] = fmaf(w, vz, acc[23]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[24 + k] = fmaf(w, tk[k], acc[24 + k]);
+  if (MODE == 1) {                                           // M[a][b] += w v_a p_b (x, y, z are zero for a miss)
+    const float p3[3] = {x, y, z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[29 + 3 * a + b] = fmaf(w * v3[a], p3[b], acc[29 + 3 * a + b]);
+  }
+  acc[27] += s;
+  acc[28] += hit ? 1.f : 0.f;
+}
+
 // Per-call part of the context (k_begin of the 2D path).
 __global__ void k_begin3(AlignCall3* __restrict__ call, AlignDyn3* __restrict__ dyn, const float* sx,
                          const float* sy, const float* sz, int n, double p0, double p1, double p2, double p3,
@@ -437,51 +591,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     for (int j = 0; j < 6; ++j) g[j] = s_red[21 + j];
     const double score = s_red[27];
     const int n_hit = (int)(s_red[28] + 0.5);
-    if (MODE == 1) {
-      // rotation block: + sum_ab (d2R / dk dl)[a][b] M[a][b], M = rows 29..37, at the pose the sums were
-      // taken at (still in `pose`).  The six second derivatives follow from R and its first derivatives:
-      // a roll derivative maps columns (1, 2) -> (col 2, -col 1), a yaw derivative rows (0, 1) ->
-      // (-row 1, row 0), and d2Ry = -Ry + e_y e_y' (oracle/ndt3d.py rot_second_derivs states the products).
-      double sa, ca, sb, cb, sg, cg;
-      sincos_wrapped(pose[3], &sa, &ca);
-      sincos_wrapped(pose[4], &sb, &cb);
-      sincos_wrapped(pose[5], &sg, &cg);
-      const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
-                           sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
-                           -sb, cb * sa, cb * ca};
-      const double Rb[9] = {-cg * sb, cg * cb * sa, cg * cb * ca, -sg * sb, sg * cb * sa, sg * cb * ca, -cb, -sb * sa, -sb * ca};
-      const double* M = &s_red[29];                            // M[3a + b] = sum w v_a p_b
-      auto cols = [&](const double* X) {                       // roll derivative of X: (0, X[:,2], -X[:,1]) . M
-        double t2 = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) t2 += X[3 * a + 2] * M[3 * a + 1] - X[3 * a + 1] * M[3 * a + 2];
-        return t2;
-      };
-      auto rows = [&](const double* X) {                       // yaw derivative of X: (-X[1,:], X[0,:], 0) . M
-        double t2 = 0.0;
-#pragma unroll
-        for (int b = 0; b < 3; ++b) t2 += -X[3 + b] * M[b] + X[b] * M[3 + b];
-        return t2;
-      };
-      const double Ra[9] = {0.0, R[2], -R[1], 0.0, R[5], -R[4], 0.0, R[8], -R[7]};
-      double h_aa = 0.0, h_gg = 0.0, h_bb = 0.0;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) h_aa -= R[3 * a + 1] * M[3 * a + 1] + R[3 * a + 2] * M[3 * a + 2];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) h_gg -= R[b] * M[b] + R[3 + b] * M[3 + b];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) h_bb -= R[k] * M[k];
-      {
-        const double u[3] = {-sg, cg, 0.0}, w3[3] = {0.0, ca, -sa};
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) h_bb += u[a] * w3[b] * M[3 * a + b];
-      }
-      const double h_ab = cols(Rb), h_ag = rows(Ra), h_bg = rows(Rb);
-      A[21] += h_aa; A[22] += h_ab; A[23] += h_ag; A[28] += h_bb; A[29] += h_bg; A[35] += h_gg;
-      A[27] = A[22]; A[33] = A[23]; A[34] = A[29];
-    }
+    if (MODE == 1) newton_rot_block3(pose, &s_red[29], A);
     int status = 0;
     const bool done = gn_update3(pose, A, g, n_hit, iter, status, prm, fixed_iterations, score, &dyn->ls[parity ^ 1],
                                  &dyn->ls[parity], writer);
@@ -516,33 +626,8 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     copy_state3(cur, prev, 1);
   }
 
-  // rotation and its three derivative matrices, float64 -> float32
-  float R[9], Ra[9], Rb[9], Rg[9];
-  {
-    double sa, ca, sb, cb, sg, cg;
-    sincos_wrapped(pose[3], &sa, &ca);
-    sincos_wrapped(pose[4], &sb, &cb);
-    sincos_wrapped(pose[5], &sg, &cg);
-    // R = Rz Ry Rx
-    const double r00 = cg * cb, r01 = cg * sb * sa - sg * ca, r02 = cg * sb * ca + sg * sa;
-    const double r10 = sg * cb, r11 = sg * sb * sa + cg * ca, r12 = sg * sb * ca - cg * sa;
-    const double r20 = -sb, r21 = cb * sa, r22 = cb * ca;
-    R[0] = (float)r00; R[1] = (float)r01; R[2] = (float)r02; R[3] = (float)r10; R[4] = (float)r11; R[5] = (float)r12;
-    R[6] = (float)r20; R[7] = (float)r21; R[8] = (float)r22;
-    // d/droll: columns 1,2 rotate: dR[:,1] = R[:,2], dR[:,2] = -R[:,1], dR[:,0] = 0
-    Ra[0] = 0.f; Ra[1] = (float)r02; Ra[2] = (float)(-r01);
-    Ra[3] = 0.f; Ra[4] = (float)r12; Ra[5] = (float)(-r11);
-    Ra[6] = 0.f; Ra[7] = (float)r22; Ra[8] = (float)(-r21);
-    // d/dpitch = Rz dRy Rx
-    Rb[0] = (float)(-cg * sb); Rb[1] = (float)(cg * cb * sa); Rb[2] = (float)(cg * cb * ca);
-    Rb[3] = (float)(-sg * sb); Rb[4] = (float)(sg * cb * sa); Rb[5] = (float)(sg * cb * ca);
-    Rb[6] = (float)(-cb);      Rb[7] = (float)(-sb * sa);     Rb[8] = (float)(-sb * ca);
-    // d/dyaw: rows rotate: dR[0,:] = -R[1,:], dR[1,:] = R[0,:], dR[2,:] = 0
-    Rg[0] = (float)(-r10); Rg[1] = (float)(-r11); Rg[2] = (float)(-r12);
-    Rg[3] = (float)r00;    Rg[4] = (float)r01;    Rg[5] = (float)r02;
-    Rg[6] = 0.f; Rg[7] = 0.f; Rg[8] = 0.f;
-  }
-  const float tx = (float)pose[0], ty = (float)pose[1], tz = (float)pose[2];
+  Rot3F T;
+  make_rot3(pose, T);
   const float fW = (float)G.W, fH = (float)G.H, fD = (float)G.D;
   const float d1 = prm.d1, d2 = prm.d2;
   const float nhd2 = -0.5f * d2 * 1.44269504088896340736f;
@@ -555,9 +640,9 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     const int inext = i + stride;
     float xn = 0.f, yn = 0.f, zn = 0.f;
     if (inext < n) { xn = sx[inext]; yn = sy[inext]; zn = sz[inext]; }
-    float px = fmaf(R[0], x, fmaf(R[1], y, fmaf(R[2], z, tx)));
-    float py = fmaf(R[3], x, fmaf(R[4], y, fmaf(R[5], z, ty)));
-    float pz = fmaf(R[6], x, fmaf(R[7], y, fmaf(R[8], z, tz)));
+    float px = fmaf(T.R[0], x, fmaf(T.R[1], y, fmaf(T.R[2], z, T.tx)));
+    float py = fmaf(T.R[3], x, fmaf(T.R[4], y, fmaf(T.R[5], z, T.ty)));
+    float pz = fmaf(T.R[6], x, fmaf(T.R[7], y, fmaf(T.R[8], z, T.tz)));
     const float fx = (px - G.ox) * G.inv_c, fy = (py - G.oy) * G.inv_c, fz = (pz - G.oz) * G.inv_c;
     const bool in = (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
     const int key = in ? (((int)fz * G.H + (int)fy) * G.W + (int)fx) : 0;
@@ -565,74 +650,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     const float4 A4 = G.rec[4 * key];
     const float4 B4 = G.rec[4 * key + 1];
     const float4 C2 = G.rec[4 * key + 2];
-    const bool hit = in & (A4.w > 0.f);
-    const float qx = px - A4.x, qy = py - A4.y, qz = pz - A4.z;
-    const float cxx = B4.x, cxy = B4.y, cxz = B4.z, cyy = B4.w, cyz = C2.x, czz = C2.y;
-    const float vx = fmaf(cxx, qx, fmaf(cxy, qy, cxz * qz));
-    const float vy = fmaf(cxy, qx, fmaf(cyy, qy, cyz * qz));
-    const float vz = fmaf(cxz, qx, fmaf(cyz, qy, czz * qz));
-    const float m = fmaf(qx, vx, fmaf(qy, vy, qz * vz));
-    const float s = hit ? d1 * __builtin_amdgcn_exp2f(nhd2 * m) : 0.f;
-    const float w = s * d2;
-    float J[3][3], U[3][3];   // J[k] = dR_k p ; U[k] = Sigma^-1 J[k]
-    const float* Rd[3] = {Ra, Rb, Rg};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      J[k][0] = fmaf(Rd[k][0], x, fmaf(Rd[k][1], y, Rd[k][2] * z));
-      J[k][1] = fmaf(Rd[k][3], x, fmaf(Rd[k][4], y, Rd[k][5] * z));
-      J[k][2] = fmaf(Rd[k][6], x, fmaf(Rd[k][7], y, Rd[k][8] * z));
-      U[k][0] = fmaf(cxx, J[k][0], fmaf(cxy, J[k][1], cxz * J[k][2]));
-      U[k][1] = fmaf(cxy, J[k][0], fmaf(cyy, J[k][1], cyz * J[k][2]));
-      U[k][2] = fmaf(cxz, J[k][0], fmaf(cyz, J[k][1], czz * J[k][2]));
-    }
-    const float v3[3] = {vx, vy, vz};
-    float tk[3];                                               // v' J_k
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tk[k] = fmaf(vx, J[k][0], fmaf(vy, J[k][1], vz * J[k][2]));
-    const float wd = MODE == 1 ? -d2 * w : 0.f;                // Newton: - d2 w (J'v)(J'v)' on every entry
-    {
-      const float cc[6] = {cxx, cxy, cxz, cyy, cyz, czz};
-      int q = 0;
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = i; j < 3; ++j) {
-          acc[q] = fmaf(w, cc[q], acc[q]);
-          if (MODE == 1) acc[q] = fmaf(wd * v3[i], v3[j], acc[q]);
-          ++q;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        acc[6 + 3 * r + k] = fmaf(w, U[k][r], acc[6 + 3 * r + k]);
-        if (MODE == 1) acc[6 + 3 * r + k] = fmaf(wd * v3[r], tk[k], acc[6 + 3 * r + k]);
-      }
-    {
-      int q = 15;
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int l = k; l < 3; ++l) {
-          const float h = fmaf(J[k][0], U[l][0], fmaf(J[k][1], U[l][1], J[k][2] * U[l][2]));
-          acc[q] = fmaf(w, h, acc[q]);
-          if (MODE == 1) acc[q] = fmaf(wd * tk[k], tk[l], acc[q]);
-          ++q;
-        }
-    }
-    acc[21] = fmaf(w, vx, acc[21]); acc[22] = fmaf(w, vy, acc[22]); acc[23] = fmaf(w, vz, acc[23]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) acc[24 + k] = fmaf(w, tk[k], acc[24 + k]);
-    if (MODE == 1) {                                           // M[a][b] += w v_a p_b (x, y, z are zero for a miss)
-      const float p3[3] = {x, y, z};
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) acc[29 + 3 * a + b] = fmaf(w * v3[a], p3[b], acc[29 + 3 * a + b]);
-    }
-    acc[27] += s;
-    acc[28] += hit ? 1.f : 0.f;
+    accumulate_point3<MODE>(T, x, y, z, px, py, pz, in, A4, B4, C2, d1, d2, nhd2, acc);
     x = xn; y = yn; z = zn; i = inext;
   }
 

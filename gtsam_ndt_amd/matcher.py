@@ -646,6 +646,102 @@ class NdtMatcher3D:
         return int(self._lib.ndt3d_stream(self._h) or 0)
 
 
+RESULT3_DOUBLES = C.sizeof(L.Result3D) // 8     # 51: ndt3d_result as float64 words
+
+
+class NdtBatch3D:
+    """3D loop-closure candidate batch (ndt3d_batch_* of include/ndt_hip.h): independent 3D scan pairs
+    aligned concurrently, one persistent workgroup per CU with the pair's voxel grid in LDS."""
+
+    def __init__(self, device: int = 0, levels=None, **overrides):
+        self._lib = L.load()
+        self.params = default_params3d(**overrides)
+        h = C.c_void_p()
+        if levels is not None:
+            self._levels, nl = _as_levels(levels)
+            self.params = self._levels[nl - 1]
+            L.check(self._lib.ndt3d_batch_create_pyramid(self._levels, nl, int(device), C.byref(h)),
+                    "ndt3d_batch_create_pyramid")
+        else:
+            L.check(self._lib.ndt3d_batch_create(C.byref(self.params), int(device), C.byref(h)), "ndt3d_batch_create")
+        self._h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndt3d_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.ndt3d_batch_stream(self._h) or 0)
+
+    @staticmethod
+    def _results(buf: np.ndarray, n: int):
+        arr = (L.Result3D * n).from_buffer_copy(np.ascontiguousarray(buf).tobytes())
+        return [NdtMatcher3D._result(r) for r in arr]
+
+    def align(self, targets, sources, inits):
+        """targets / sources: lists of (x, y, z) numpy triples; inits: [n][6].  Returns a list of
+        AlignResult3D.  Pairs over the on-chip capacity are re-run through the single-pair path."""
+        n = len(targets)
+        toff = np.zeros(n + 1, dtype=np.uint64)
+        soff = np.zeros(n + 1, dtype=np.uint64)
+        toff[1:] = np.cumsum([len(t[0]) for t in targets])
+        soff[1:] = np.cumsum([len(s[0]) for s in sources])
+        t = [np.concatenate([_host_f32(c[a]) for c in targets]) for a in range(3)]
+        s = [np.concatenate([_host_f32(c[a]) for c in sources]) for a in range(3)]
+        init = np.ascontiguousarray(inits, dtype=np.float64).reshape(n, 6)
+        out = np.zeros(n * RESULT3_DOUBLES, dtype=np.float64)
+        L.check(self._lib.ndt3d_batch_align(self._h, t[0].ctypes.data, t[1].ctypes.data, t[2].ctypes.data, toff.ctypes.data,
+                                            s[0].ctypes.data, s[1].ctypes.data, s[2].ctypes.data, soff.ctypes.data,
+                                            init.ctypes.data, n, out.ctypes.data), "ndt3d_batch_align")
+        return self._results(out, n)
+
+    def align_dev(self, t, toff, s, soff, init, out=None, stream=None):
+        """Everything already on the device: t / s = (x, y, z) float32 CUDA tensors (concatenated clouds),
+        int64 offsets [n+1], float64 init [n,6].  Asynchronous; returns the float64 [n,51] result tensor
+        (decode with ``decode``).  Stream semantics as NdtBatch2D.align_dev."""
+        import torch
+        n = int(toff.numel()) - 1
+        if out is None:
+            out = torch.empty((n, RESULT3_DOUBLES), dtype=torch.float64, device=t[0].device)
+        for x, dt in ((t[0], torch.float32), (t[1], torch.float32), (t[2], torch.float32), (s[0], torch.float32),
+                      (s[1], torch.float32), (s[2], torch.float32), (toff, torch.int64), (soff, torch.int64),
+                      (init, torch.float64), (out, torch.float64)):
+            if not (x.is_cuda and x.dtype == dt and x.is_contiguous()):
+                raise ValueError("batch tensors must be contiguous CUDA tensors of the documented dtypes")
+        self._keep = (t, toff, s, soff, init, out)
+        if not stream:
+            L.check(self._lib.ndt3d_batch_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "ndt3d_batch_wait_stream")
+        vp = lambda x: C.c_void_p(x.data_ptr())
+        L.check(self._lib.ndt3d_batch_align_dev(self._h, vp(t[0]), vp(t[1]), vp(t[2]), vp(toff), vp(s[0]), vp(s[1]), vp(s[2]),
+                                                vp(soff), vp(init), n, vp(out),
+                                                C.c_void_p(stream if stream is not None else 0)), "ndt3d_batch_align_dev")
+        if not stream:
+            torch.cuda.current_stream().wait_stream(torch.cuda.ExternalStream(self.stream))
+        return out
+
+    @classmethod
+    def decode(cls, out_tensor):
+        """float64 [n,51] device/host tensor -> list of AlignResult3D (synchronises)."""
+        a = out_tensor.detach().cpu().numpy()
+        return cls._results(a.reshape(-1), a.shape[0])
+
+
 def magnusson_constants(outlier_ratio: float, cell_size: float, dim: int = 2):
     """(d1, d2) of Magnusson's outlier-mixture score for ndt2d_params / ndt3d_params."""
     d1, d2 = C.c_double(), C.c_double()

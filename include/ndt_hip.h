@@ -423,6 +423,31 @@ void* ndt3d_stream(ndt3d_handle* h);
 /* as ndt2d_wait_stream: order the handle's stream behind the producer of the device arrays */
 int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
 
+/* ---- 3D loop-closure candidate batch ------------------------------------------------------------ */
+/* The 3D twin of ndt2d_batch: independent 3D scan pairs aligned concurrently, one persistent
+ * 1024-thread workgroup per CU, the pair's voxel grid (u16 voxel -> slot table + 40-byte records) in
+ * LDS for the whole Gauss-Newton / Newton loop.  Clouds are concatenated SoA arrays; pair k owns
+ * target points [toff[k], toff[k+1]) and source points [soff[k], soff[k+1]); init is [n_pairs][6];
+ * results is [n_pairs].  Every pair's result equals the single-pair path's (ndt3d_set_target +
+ * ndt3d_align) up to float32 summation order: same records bit for bit, same per-point arithmetic.
+ * On-chip capacity per pair: 2 B per voxel + 40 B per occupied voxel <= 157 KB and 6 B per voxel
+ * <= 157 KB during the build (BASELINE config 5: 17 424 voxels, 2 706 occupied = 143 KB).  A pair
+ * beyond it gets status NDT_ERR_CAPACITY from the _dev entry point; the host-pointer entry point
+ * re-runs it through the single-pair path transparently.  Stream semantics as ndt2d_batch_align_dev. */
+typedef struct ndt3d_batch ndt3d_batch;
+int32_t ndt3d_batch_create(const ndt3d_params* p, int32_t device_id, ndt3d_batch** out);
+/* coarse-to-fine over the batch, as ndt2d_batch_create_pyramid (levels coarse to fine, at most 8) */
+int32_t ndt3d_batch_create_pyramid(const ndt3d_params* levels, int32_t n_levels, int32_t device_id, ndt3d_batch** out);
+int32_t ndt3d_batch_destroy(ndt3d_batch* b);
+int32_t ndt3d_batch_align(ndt3d_batch* b, const float* tx, const float* ty, const float* tz, const uint64_t* toff,
+                          const float* sx, const float* sy, const float* sz, const uint64_t* soff, const double* init,
+                          size_t n_pairs, ndt3d_result* results);
+int32_t ndt3d_batch_align_dev(ndt3d_batch* b, const float* d_tx, const float* d_ty, const float* d_tz, const uint64_t* d_toff,
+                              const float* d_sx, const float* d_sy, const float* d_sz, const uint64_t* d_soff,
+                              const double* d_init, size_t n_pairs, ndt3d_result* d_results, void* stream);
+void* ndt3d_batch_stream(ndt3d_batch* b);
+int32_t ndt3d_batch_wait_stream(ndt3d_batch* b, void* producer_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,161 @@
+"""3D loop-closure batch (k_batch3, ndt3d_batch_*) vs the single-pair 3D path and the CPU oracle.
+Parity unpinned: the oracle is this repo's own (the reference holds no code)."""
+import numpy as np
+import pytest
+
+from gtsam_ndt_amd import synth3d
+
+pytestmark = pytest.mark.gpu
+
+POSES = [(0.30, -0.20, 0.05, 0.01, -0.01, 0.03), (-0.25, 0.15, -0.04, -0.008, 0.012, -0.02),
+         (0.10, 0.28, 0.02, 0.0, 0.015, 0.035), (-0.12, -0.22, 0.06, 0.012, 0.0, -0.03),
+         (0.22, 0.05, -0.03, -0.01, -0.012, 0.015), (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)]
+SHAPES = [(16, 256), (32, 512), (16, 512), (24, 384), (32, 256), (16, 300)]     # ragged: 4096 ... 16384 points
+
+
+def _pairs(poses=POSES, shapes=SHAPES):
+    ds = [synth3d.make_pair3d(n_elev=e, n_azim=a, pose=p) for p, (e, a) in zip(poses, shapes)]
+    T = [(d["tx"], d["ty"], d["tz"]) for d in ds]
+    S = [(d["sx"], d["sy"], d["sz"]) for d in ds]
+    return ds, T, S
+
+
+def _single(T, S, inits, **kw):
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    out = []
+    with NdtMatcher3D(**kw) as m:
+        for t, s, i in zip(T, S, inits):
+            m.set_target(*t)
+            out.append(m.align(*s, i))
+    return out
+
+
+def _same(rb, rs, pose_tol=2e-6, h_tol=2e-4):
+    """batch result vs single-pair result: same records and per-point arithmetic, another summation order"""
+    assert rb.status == rs.status and abs(rb.iterations - rs.iterations) <= 1, (rb, rs)
+    assert abs(rb.n_hit - rs.n_hit) <= 2
+    assert np.abs(np.array(rb.pose) - np.array(rs.pose)).max() < pose_tol, (rb.pose, rs.pose)
+    sc = np.sqrt(np.outer(np.abs(np.diag(rs.H)), np.abs(np.diag(rs.H)))) + 1e-30
+    assert np.max(np.abs(rb.H - rs.H) / sc) < h_tol
+    assert abs(rb.score - rs.score) <= 1e-4 * abs(rs.score)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_batch3d_equals_single_pair_and_oracle(gpu_lib, mode):
+    from gtsam_ndt_amd.matcher import NdtBatch3D
+    from oracle import ndt3d as o
+    ds, T, S = _pairs()
+    inits = [d["init"] for d in ds]
+    if mode == 1:          # Newton's basin is small (tests/test_gpu_ndt3d.py): start next to the Gauss-Newton optimum
+        gn = _single(T, S, inits)
+        inits = [tuple(np.array(r.pose) + 2e-3 * np.array([1, -1, 0.5, 0.1, -0.1, 0.2])) for r in gn]
+    with NdtBatch3D(hessian_mode=mode) as b:
+        rb = b.align(T, S, inits)
+        rb2 = b.align(T, S, inits)
+    rs = _single(T, S, inits, hessian_mode=mode)
+    for k, (x, y) in enumerate(zip(rb, rs)):
+        _same(x, y)
+        assert x.pose == rb2[k].pose and np.array_equal(x.H, rb2[k].H)      # deterministic, whichever CU took the pair
+    prm = o.Ndt3Params(hessian_mode=mode)
+    for k in (0, 3):
+        ref = o.align3(o.build_grid3(*T[k], prm), *S[k], inits[k], prm)
+        e = np.abs(np.array(rb[k].pose) - np.array(ref["pose"]))
+        assert rb[k].status == ref["status"] == 0 and e.max() < 1e-4        # BASELINE.json: 1e-4 m / 1e-4 rad
+        assert abs(rb[k].iterations - ref["iterations"]) <= 3
+
+
+def test_batch3d_full_config5_pairs(gpu_lib):
+    """Full-size pairs (131 072 points each, 17 424 voxels, 2 706 occupied: the LDS carve of config 5), fixed 10
+    iterations: oracle parity on one of them, the single-pair path on all."""
+    from gtsam_ndt_amd.matcher import NdtBatch3D
+    from oracle import ndt3d as o
+    ds, T, S = _pairs(POSES[:3], [(64, 2048)] * 3)
+    inits = [d["init"] for d in ds]
+    with NdtBatch3D(fixed_iterations=10) as b:
+        rb = b.align(T, S, inits)
+    rs = _single(T, S, inits, fixed_iterations=10)
+    for x, y in zip(rb, rs):
+        assert x.iterations == 10 and x.status == 0
+        _same(x, y)
+    prm = o.Ndt3Params(fixed_iterations=10)
+    ref = o.align3(o.build_grid3(*T[1], prm), *S[1], inits[1], prm)
+    e = np.abs(np.array(rb[1].pose) - np.array(ref["pose"]))
+    assert e.max() < 1e-4
+    with NdtBatch3D() as b:
+        rc = b.align(T, S, inits)
+    for r, d in zip(rc, ds):
+        e = np.abs(np.array(r.pose) - np.array(d["pose"]))
+        assert r.status == 0 and e[:3].max() < 5e-3 and e[3:].max() < 1e-3   # recovers the generating pose
+
+
+def test_batch3d_options_and_edge_cases(gpu_lib):
+    from gtsam_ndt_amd.matcher import NdtBatch3D
+    ds, T, S = _pairs()
+    inits = [d["init"] for d in ds]
+    # line search and over-relaxation go through the same gn_update3
+    kw = dict(line_search=4, step_scale=1.5)
+    with NdtBatch3D(**kw) as b:
+        rb = b.align(T, S, inits)
+    for x, y in zip(rb, _single(T, S, inits, **kw)):
+        _same(x, y)
+    # edge cases: a source that misses the map, a target with too few points per voxel, an empty source
+    far = tuple(np.asarray(c) + np.float32(500.0) for c in S[0])
+    tiny = tuple(np.asarray(c)[:4] for c in T[1])            # fewer than min_points anywhere
+    empty = tuple(np.zeros(0, np.float32) for _ in range(3))
+    with NdtBatch3D() as b:
+        r = b.align([T[0], tiny, T[2], T[3]], [far, S[1], empty, S[3]], [inits[0], inits[1], inits[2], inits[3]])
+    assert r[0].status == 3 and r[0].n_hit == 0                    # NDT_TOO_FEW_HITS
+    assert r[1].status == 4                                        # NDT_TOO_FEW_CELLS
+    assert r[2].status == 3 and r[2].iterations == 0
+    _same(r[3], _single([T[3]], [S[3]], [inits[3]])[0])            # the pair behind them is untouched by their exits
+
+
+def test_batch3d_capacity_and_fallback(gpu_lib):
+    """0.25 m voxels: 170 x 170 x 30 voxels do not fit the LDS carve.  The device entry point says so per pair,
+    the host entry point re-runs the pair through the single-pair path."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtBatch3D
+    ds, T, S = _pairs(POSES[:2], [(32, 512), (16, 256)])
+    inits = [d["init"] for d in ds]
+    kw = dict(cell_size=0.25, min_points=3, step_max_trans=0.25)
+    with NdtBatch3D(**kw) as b:
+        rb = b.align(T, S, inits)
+        dev = torch.device("cuda:0")
+        cat = lambda cl, a: torch.from_numpy(np.concatenate([np.asarray(c[a], np.float32) for c in cl])).to(dev)
+        off = lambda cl: torch.tensor(np.concatenate([[0], np.cumsum([len(c[0]) for c in cl])]), dtype=torch.int64, device=dev)
+        out = b.align_dev([cat(T, a) for a in range(3)], off(T), [cat(S, a) for a in range(3)], off(S),
+                          torch.tensor(np.array(inits), dtype=torch.float64, device=dev))
+        rd = b.decode(out)
+    assert [r.status for r in rd] == [-5, -5]                      # NDT_ERR_CAPACITY
+    for x, y in zip(rb, _single(T, S, inits, **kw)):
+        assert x.status == y.status and x.pose == y.pose and np.array_equal(x.H, y.H)
+
+
+def test_batch3d_pyramid_and_device_entry(gpu_lib):
+    """Coarse to fine over the batch (4 m -> 2 m -> 1 m voxels, one launch per level) from 1.2 m / 0.08 rad off,
+    through the device-pointer entry point on torch's stream."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtBatch3D, default_params3d, PYRAMID_LEVELS
+    ds, T, S = _pairs(POSES[:3], [(32, 1024)] * 3)
+    true = [np.array(d["pose"]) for d in ds]
+    inits = [tuple(t + np.array([1.2, -0.9, 0.15, 0.0, 0.0, 0.08]) * s) for t, s in zip(true, (1.0, -1.0, 0.7))]
+    fine = default_params3d()
+    levels = []
+    for mult, er in PYRAMID_LEVELS:
+        levels.append(default_params3d(cell_size=fine.cell_size * mult, eig_ratio=er, eps_trans=1e-3, eps_rot=1e-4,
+                                       max_iterations=30, step_max_trans=fine.step_max_trans * mult))
+    levels.append(fine)
+    dev = torch.device("cuda:0")
+    cat = lambda cl, a: torch.from_numpy(np.concatenate([np.asarray(c[a], np.float32) for c in cl])).to(dev)
+    off = lambda cl: torch.tensor(np.concatenate([[0], np.cumsum([len(c[0]) for c in cl])]), dtype=torch.int64, device=dev)
+    with NdtBatch3D(levels=levels) as b, NdtBatch3D() as flat:
+        args = ([cat(T, a) for a in range(3)], off(T), [cat(S, a) for a in range(3)], off(S),
+                torch.tensor(np.array(inits), dtype=torch.float64, device=dev))
+        rp = b.decode(b.align_dev(*args))
+        rf = flat.decode(flat.align_dev(*args))
+        rh = b.align(T, S, inits)                                   # host entry point, same levels
+    for r, h, f, t in zip(rp, rh, rf, true):
+        e = np.abs(np.array(r.pose) - t)
+        assert r.status == 0 and e[:3].max() < 0.03 and e[3:].max() < 5e-3, (r.pose, t)
+        assert r.pose == h.pose and r.iterations == h.iterations
+        assert np.abs(np.array(f.pose) - t)[:3].max() > e[:3].max()       # the 1 m grid alone ends elsewhere
