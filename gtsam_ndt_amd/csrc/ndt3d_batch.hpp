@@ -11,8 +11,10 @@
 //   - source points stream from HBM/L2 once per iteration; the 29 (Newton: 38) sums are reduced
 //     per wave (DPP) -> LDS -> wave 0, which also does the 6x6 solve: two workgroup barriers per
 //     iteration, no kernel boundary.
-// Same arithmetic as the single-pair 3D path: finalise_sums3, accumulate_point3, gn_update3 are
-// the functions k_finalise3 / k_iterate3 use, and the slab sums are the integers k_accumulate3 forms.
+// Records and update rule are the single-pair 3D path's: finalise_sums3 and gn_update3 are the functions
+// k_finalise3 / k_iterate3 use, the slab sums are the integers k_accumulate3 forms.  The per-point sums are
+// taken in the map frame (accumulate_point3_map below: the same Hessian and gradient with a fifth fewer
+// instructions), so a pair agrees with its single-pair alignment to float32 rounding, not bit for bit.
 #pragma once
 #include "ndt2d_batch.hpp"
 #include "ndt3d_kernels.hpp"
@@ -108,6 +110,129 @@ __device__ __forceinline__ void write_result3(Result3Dev* o, const double* pose,
   for (int j = 0; j < 36; ++j) o->H[j] = H[j];
   o->score = score;
   o->iterations = iter; o->n_hit = n_hit; o->status = status; o->reserved = 0;
+}
+
+// a5 + a6 for one point in the MAP frame.  The single-pair kernel forms J_k = (dR/dtheta_k) p per point and
+// sums w C J_k, w J_k' C J_l, w v'J_k (accumulate_point3: 131 arithmetic instructions per point).  With
+// y = R p every rotation column is a cross product, J_k = a_k x y (a_roll = R e_x, a_pitch = Rz e_y,
+// a_yaw = e_z: the same for every point), so with Y = [y]x (Y b = y x b), J = -Y A and
+//     Htr = -(sum w C Y) A = -P A      Hrr = A' (sum w Y' C Y) A = A' S A      g_r = A' sum w (y x v) = A' n
+// The point loop sums P (9), S (6), n (3) - as many accumulators as before, 102 arithmetic instructions -
+// and the contraction with A happens once per iteration on the reduced sums, in float64
+// (map_sums_to_pose_frame).  Newton mode: - d2 w (J'v)(J'v)' with J'v = (v ; A'u), u = y x v, lands on the
+// same three sums, and the second-derivative term uses M' = sum w v y' = M R'.
+// acc: Htt(6) P(9) S(6) g_t(3) n(3) score n_hit [M'(9)].  y must be zero (not NaN) for a point outside the grid.
+template <int MODE>
+__device__ __forceinline__ void accumulate_point3_map(float yx, float yy, float yz, float px, float py, float pz, bool in,
+                                                      const float4& A4, const float4& B4, const float2& C2, float d1,
+                                                      float d2, float nhd2, float* acc) {
+  const bool hit = in & (A4.w > 0.f);
+  const float qx = px - A4.x, qy = py - A4.y, qz = pz - A4.z;
+  const float cxx = B4.x, cxy = B4.y, cxz = B4.z, cyy = B4.w, cyz = C2.x, czz = C2.y;
+  const float vx = fmaf(cxx, qx, fmaf(cxy, qy, cxz * qz));
+  const float vy = fmaf(cxy, qx, fmaf(cyy, qy, cyz * qz));
+  const float vz = fmaf(cxz, qx, fmaf(cyz, qy, czz * qz));
+  const float m = fmaf(qx, vx, fmaf(qy, vy, qz * vz));
+  const float s = hit ? d1 * __builtin_amdgcn_exp2f(nhd2 * m) : 0.f;
+  const float w = s * d2;
+  const float wxx = w * cxx, wxy = w * cxy, wxz = w * cxz, wyy = w * cyy, wyz = w * cyz, wzz = w * czz;   // w C
+  acc[0] += wxx; acc[1] += wxy; acc[2] += wxz; acc[3] += wyy; acc[4] += wyz; acc[5] += wzz;
+  const float wvx = w * vx, wvy = w * vy, wvz = w * vz;
+  acc[21] += wvx; acc[22] += wvy; acc[23] += wvz;
+  acc[24] = fmaf(yy, wvz, fmaf(-yz, wvy, acc[24]));            // n += y x (w v)
+  acc[25] = fmaf(yz, wvx, fmaf(-yx, wvz, acc[25]));
+  acc[26] = fmaf(yx, wvy, fmaf(-yy, wvx, acc[26]));
+  // Z = (w C) Y, Y = [[0, -yz, yy], [yz, 0, -yx], [-yy, yx, 0]]
+  const float wc[3][3] = {{wxx, wxy, wxz}, {wxy, wyy, wyz}, {wxz, wyz, wzz}};
+  float Z[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Z[r][0] = fmaf(wc[r][1], yz, -(wc[r][2] * yy));
+    Z[r][1] = fmaf(wc[r][2], yx, -(wc[r][0] * yz));
+    Z[r][2] = fmaf(wc[r][0], yy, -(wc[r][1] * yx));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += Z[r][c];
+  }
+  // S = Y' Z (symmetric): row 0 of Y' = (0, yz, -yy), row 1 = (-yz, 0, yx), row 2 = (yy, -yx, 0)
+  acc[15] = fmaf(yz, Z[1][0], fmaf(-yy, Z[2][0], acc[15]));
+  acc[16] = fmaf(yz, Z[1][1], fmaf(-yy, Z[2][1], acc[16]));
+  acc[17] = fmaf(yz, Z[1][2], fmaf(-yy, Z[2][2], acc[17]));
+  acc[18] = fmaf(yx, Z[2][1], fmaf(-yz, Z[0][1], acc[18]));
+  acc[19] = fmaf(yx, Z[2][2], fmaf(-yz, Z[0][2], acc[19]));
+  acc[20] = fmaf(yy, Z[0][2], fmaf(-yx, Z[1][2], acc[20]));
+  if (MODE == 1) {
+    const float wd = -d2 * w;
+    const float ux = fmaf(yy, vz, -(yz * vy)), uy = fmaf(yz, vx, -(yx * vz)), uz = fmaf(yx, vy, -(yy * vx));   // u = y x v
+    const float v3[3] = {vx, vy, vz}, u3[3] = {ux, uy, uz}, y3[3] = {yx, yy, yz}, wv3[3] = {wvx, wvy, wvz};
+    const float dv[3] = {wd * vx, wd * vy, wd * vz}, du[3] = {wd * ux, wd * uy, wd * uz};
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = i; j < 3; ++j) {
+        acc[q] = fmaf(dv[i], v3[j], acc[q]);                   // Htt - d2 w v v'
+        acc[15 + q] = fmaf(du[i], u3[j], acc[15 + q]);         // S   - d2 w u u'
+        ++q;
+      }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        acc[6 + 3 * r + c] = fmaf(-dv[r], u3[c], acc[6 + 3 * r + c]);      // Htr = -P A: P + d2 w v u'
+        acc[29 + 3 * r + c] = fmaf(wv3[r], y3[c], acc[29 + 3 * r + c]);    // M' = sum w v y'
+      }
+  }
+  acc[27] += s;
+  acc[28] += hit ? 1.f : 0.f;
+}
+
+// The reduced sums of accumulate_point3_map (sr: Htt P S g_t n score n_hit [M']) -> the 6x6 matrix and the
+// gradient in pose coordinates, at the pose the sums were taken at.  Float64, once per iteration.
+template <int MODE>
+__device__ __forceinline__ void map_sums_to_pose_frame(const double* pose, const double* sr, double* A, double* g) {
+  double sa, ca, sb, cb, sg, cg;
+  sincos_wrapped(pose[3], &sa, &ca);
+  sincos_wrapped(pose[4], &sb, &cb);
+  sincos_wrapped(pose[5], &sg, &cg);
+  const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
+                       sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
+                       -sb, cb * sa, cb * ca};
+  const double ax[3][3] = {{R[0], -sg, 0.0}, {R[3], cg, 0.0}, {R[6], 0.0, 1.0}};     // columns a_roll, a_pitch, a_yaw
+  A[0] = sr[0]; A[1] = sr[1]; A[2] = sr[2]; A[7] = sr[3]; A[8] = sr[4]; A[14] = sr[5];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double t = 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) t -= sr[6 + 3 * r + c] * ax[c][k];
+      A[6 * r + 3 + k] = t;
+    }
+  const double S[3][3] = {{sr[15], sr[16], sr[17]}, {sr[16], sr[18], sr[19]}, {sr[17], sr[19], sr[20]}};
+  double SA[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int l = 0; l < 3; ++l) SA[a][l] = S[a][0] * ax[0][l] + S[a][1] * ax[1][l] + S[a][2] * ax[2][l];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int l = k; l < 3; ++l) A[6 * (3 + k) + 3 + l] = ax[0][k] * SA[0][l] + ax[1][k] * SA[1][l] + ax[2][k] * SA[2][l];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < r; ++c) A[6 * r + c] = A[6 * c + r];
+  g[0] = sr[21]; g[1] = sr[22]; g[2] = sr[23];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g[3 + k] = ax[0][k] * sr[24] + ax[1][k] * sr[25] + ax[2][k] * sr[26];
+  if (MODE == 1) {
+    double M[9];                                               // M = M' R: the sums newton_rot_block3 expects
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) M[3 * a + b] = sr[29 + 3 * a] * R[b] + sr[30 + 3 * a] * R[3 + b] + sr[31 + 3 * a] * R[6 + b];
+    newton_rot_block3(pose, M, A);
+  }
 }
 
 // One pair, start to finish, on the calling workgroup (plain returns for the early outs: see process_pair).
@@ -346,9 +471,9 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     {
       Rot3F T;
       make_rot3(pose, T);
-      // the pose is the same in every lane: SGPRs, not 39 VGPRs held across the point loop
+      // the pose is the same in every lane: SGPRs, not VGPRs held across the point loop
 #pragma unroll
-      for (int j = 0; j < 9; ++j) { T.R[j] = uniformf(T.R[j]); T.Ra[j] = uniformf(T.Ra[j]); T.Rb[j] = uniformf(T.Rb[j]); T.Rg[j] = uniformf(T.Rg[j]); }
+      for (int j = 0; j < 9; ++j) T.R[j] = uniformf(T.R[j]);
       T.tx = uniformf(T.tx); T.ty = uniformf(T.ty); T.tz = uniformf(T.tz);
       // software-pipelined source stream, as in process_pair: two register sets, one in flight while
       // the other is consumed
@@ -360,19 +485,16 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
         z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, off, 0, 0));
       };
       auto consume = [&](int i, float x, float y, float z) {
-        float px = fmaf(T.R[0], x, fmaf(T.R[1], y, fmaf(T.R[2], z, T.tx)));
-        float py = fmaf(T.R[3], x, fmaf(T.R[4], y, fmaf(T.R[5], z, T.ty)));
-        float pz = fmaf(T.R[6], x, fmaf(T.R[7], y, fmaf(T.R[8], z, T.tz)));
+        float yx = fmaf(T.R[0], x, fmaf(T.R[1], y, T.R[2] * z));
+        float yy = fmaf(T.R[3], x, fmaf(T.R[4], y, T.R[5] * z));
+        float yz = fmaf(T.R[6], x, fmaf(T.R[7], y, T.R[8] * z));
+        const float px = yx + T.tx, py = yy + T.ty, pz = yz + T.tz;
         const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c, fz = (pz - oz) * inv_c;
         const bool in = (i < ns) & (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
         const int key = in ? (((int)fz * Hh + (int)fy) * W + (int)fx) : 0;
         int slot = idx[key];
-        if (!in) { px = py = pz = 0.f; x = y = z = 0.f; slot = 0; }
-        const float4 A4 = recA[slot];
-        const float4 B4 = recB[slot];
-        const float2 c2 = recC[slot];
-        const float4 C2 = make_float4(c2.x, c2.y, 0.f, 0.f);
-        accumulate_point3<MODE>(T, x, y, z, px, py, pz, in, A4, B4, C2, d1, d2, nhd2, acc);
+        if (!in) { yx = yy = yz = 0.f; slot = 0; }     // a NaN point must not reach the sums through 0 * NaN
+        accumulate_point3_map<MODE>(yx, yy, yz, px, py, pz, in, recA[slot], recB[slot], recC[slot], d1, d2, nhd2, acc);
       };
       if (ns > 0) {                                  // uniform
         load_set(tid, xa, ya, za);
@@ -402,30 +524,22 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
       __builtin_amdgcn_wave_barrier();               // same wave: LDS executes its operations in order
       const double* sr = bc + 6;
       double A[36], g[6];
-      A[0] = sr[0]; A[1] = sr[1]; A[2] = sr[2]; A[7] = sr[3]; A[8] = sr[4]; A[14] = sr[5];
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) A[6 * r + 3 + k] = sr[6 + 3 * r + k];
-      A[21] = sr[15]; A[22] = sr[16]; A[23] = sr[17]; A[28] = sr[18]; A[29] = sr[19]; A[35] = sr[20];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < r; ++c) A[6 * r + c] = A[6 * c + r];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) g[j] = sr[21 + j];
+      map_sums_to_pose_frame<MODE>(pose, sr, A, g);
       const double score = sr[27];
       const int n_hit = (int)(sr[28] + 0.5);
-      if (MODE == 1) newton_rot_block3(pose, sr + 29, A);
       int iter = misc[9], st = 0;
       const bool done = gn_update3(pose, A, g, n_hit, iter, st, a.prm, a.fixed_iterations, score, ls_lds, ls_lds, lane == 0);
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) bc[j] = pose[j];
-        if (MODE == 1) {                 // the reported rotation block is the full one
-          bc[6 + 15] = A[21]; bc[6 + 16] = A[22]; bc[6 + 17] = A[23]; bc[6 + 18] = A[28]; bc[6 + 19] = A[29]; bc[6 + 20] = A[35];
-        }
+        // the result reports H and g in pose coordinates: Htt stays, P / S / n make way for Htr / Hrr / g_r
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) bc[6 + 6 + 3 * r + k] = A[6 * r + 3 + k];
+        bc[6 + 15] = A[21]; bc[6 + 16] = A[22]; bc[6 + 17] = A[23]; bc[6 + 18] = A[28]; bc[6 + 19] = A[29]; bc[6 + 20] = A[35];
+        bc[6 + 24] = g[3]; bc[6 + 25] = g[4]; bc[6 + 26] = g[5];
         misc[11] = done ? 1 : 0;
         misc[9] = iter;
         misc[10] = st;

@@ -76,10 +76,14 @@ def test_batch3d_full_config5_pairs(gpu_lib):
     rs = _single(T, S, inits, fixed_iterations=10)
     for x, y in zip(rb, rs):
         assert x.iterations == 10 and x.status == 0
-        _same(x, y)
+        # mid-descent, 128 points per thread summed in float32 (the single-pair kernel: 2): the poses drift 2e-6 m
+        # apart, and with 9 mm thin voxel Gaussians that moves H by 2 q dp / sigma^2 = 5e-4
+        _same(x, y, pose_tol=1e-5, h_tol=3e-3)
     prm = o.Ndt3Params(fixed_iterations=10)
     ref = o.align3(o.build_grid3(*T[1], prm), *S[1], inits[1], prm)
     e = np.abs(np.array(rb[1].pose) - np.array(ref["pose"]))
+    es = np.abs(np.array(rs[1].pose) - np.array(ref["pose"]))
+    print("full-size pair after 10 iterations, |pose - oracle|: batch", e.max(), "single-pair", es.max())
     assert e.max() < 1e-4
     with NdtBatch3D() as b:
         rc = b.align(T, S, inits)
