@@ -494,6 +494,59 @@ def run_3d(a, dev, dev_index):
                          "frac": round(alg / (per_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
+def run_batch_3d(a, dev, dev_index, n_pairs=256, distinct=4):
+    """3D loop-closure batch (ndt3d_batch_align_dev): n_pairs config-5-sized pairs (131072 points each) per step,
+    fixed 30 iterations per pair.  The ray-cast generator is numpy (about 1 s per pair), so `distinct` pairs with
+    different sensor poses are generated and replicated into separate device buffers."""
+    from gtsam_ndt_amd import synth3d
+    from gtsam_ndt_amd.matcher import NdtBatch3D, NdtMatcher3D
+    rng = np.random.default_rng(5)
+    poses = [tuple(np.array(synth3d.T_STAR_3D) * rng.uniform(-1.0, 1.0, 6)) for _ in range(distinct)]
+    ds = [synth3d.make_pair3d(pose=p) for p in poses]
+    npts = int(ds[0]["tx"].size)
+    rep = [k % distinct for k in range(n_pairs)]
+    t = [torch.from_numpy(np.concatenate([ds[r][c] for r in rep])).to(dev) for c in ("tx", "ty", "tz")]
+    s = [torch.from_numpy(np.concatenate([ds[r][c] for r in rep])).to(dev) for c in ("sx", "sy", "sz")]
+    off = torch.arange(n_pairs + 1, dtype=torch.int64, device=dev) * npts
+    init = torch.zeros((n_pairs, 6), dtype=torch.float64, device=dev)
+    steps = max(3, min(a.steps, 10))
+    with NdtBatch3D(device=dev_index, fixed_iterations=K_GN) as b:
+        out = None
+        for _ in range(max(1, min(a.warmup, 2))):
+            out = b.align_dev(t, off, s, off, init, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev_ms = hip_events_ms(b.stream, lambda: [b.align_dev(t, off, s, off, init, out=out, stream=b.stream) for _ in range(steps)])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        res = b.decode(out)
+    assert all(r.status == 0 and r.iterations == K_GN for r in res)
+    # sampled cross-check against the single-pair path (k_iterate3) and the generating poses
+    cross = 0.0
+    with NdtMatcher3D(device=dev_index, fixed_iterations=K_GN) as m:
+        for k in range(distinct):
+            m.set_target(ds[k]["tx"], ds[k]["ty"], ds[k]["tz"])
+            r1 = m.align(ds[k]["sx"], ds[k]["sy"], ds[k]["sz"], (0.0,) * 6)
+            cross = max(cross, float(np.abs(np.array(r1.pose) - np.array(res[k].pose)).max()))
+    err = max(float(np.abs(np.array(res[k].pose) - np.array(ds[k % distinct]["pose"])).max()) for k in range(n_pairs))
+    launch_ms = ev_ms / steps
+    alg = n_pairs * npts * 12 * (1 + K_GN)                  # target once + source once per iteration, 12 B per point
+    return {"workload": f"{n_pairs} 3D scan pairs of config-5 size ({npts} + {npts} points, 1.0 m voxels; {distinct} distinct "
+                        "pairs replicated into separate buffers), fixed 30 GN iterations per pair, one GPU",
+            "value": round(n_pairs * K_GN * steps / el, 1), "unit": "pair-iterations/s",
+            "pairs_per_s": round(n_pairs * steps / el, 1), "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
+            "pose_diff_vs_single_pair_max": cross, "pose_err_vs_truth_max": err,
+            "roofline": {"bound": "hbm", "kernel": "k_batch3<GN>", "algorithmic_bytes_per_launch": alg,
+                         "bytes_rule": "12 B x (target points + 30 x source points) per pair: the 40-byte voxel records "
+                                       "are served from LDS (SURVEY 8d's 52 B per point counts them as HBM traffic)",
+                         "avg_launch_us": round(1e3 * launch_ms, 1),
+                         "timing": "HIP events on the context's stream over the timed region / launches",
+                         "achieved": round(alg / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "bound by VALU issue, not by memory: 127 vector instructions per point and iteration "
+                                 "(DESIGN.md section 5.5)"}}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -655,6 +708,8 @@ def main():
                 out["batch_4096"] = run_batch(a, dev, dev_index, 0, 1, None, barrier, ppr=4096, steps=max(3, min(a.steps, 10)))
         if not a.no_3d:
             out["3d"] = run_3d(a, dev, dev_index)
+            if not a.headline_only:
+                out["batch_3d"] = run_batch_3d(a, dev, dev_index)
         # the other single-pair configs of BASELINE.json beside the headline (parity-test cases; cheap to time)
         if not a.headline_only:
             out["configs_1_2"] = [single_pair_rate(dev, dev_index, c, a.steps, a.warmup) for c in (1, 2)]

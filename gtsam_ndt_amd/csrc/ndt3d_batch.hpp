@@ -47,6 +47,11 @@ struct Batch3Args {
 
 constexpr int kB3Threads = 1024;
 constexpr int kB3Waves = kB3Threads / 64;
+#ifndef NDT_B3_UNROLL
+#define NDT_B3_UNROLL 1
+#endif
+constexpr int kB3Unroll = NDT_B3_UNROLL;                // source points per thread and register set (2 measured equal:
+                                                        // the loop is bound by VALU issue, not by the LDS round trips)
 constexpr int kB3MaxSlots = 4096;                       // bound of the slab; the LDS carve allows fewer
 // LDS carve (bytes).  Fixed part first, then the voxel table (u16 per voxel), then the records.
 constexpr int kB3Red = 0;                               // float [Waves][kNumAcc3]
@@ -477,32 +482,47 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
       T.tx = uniformf(T.tx); T.ty = uniformf(T.ty); T.tz = uniformf(T.tz);
       // software-pipelined source stream, as in process_pair: two register sets, one in flight while
       // the other is consumed
-      float xa, ya, za, xb, yb, zb;
-      auto load_set = [&](int i, float& x, float& y, float& z) {
-        const int off = i * 4;
-        x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
-        y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
-        z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, off, 0, 0));
+      constexpr int U = kB3Unroll, kTrip = U * kB3Threads;
+      float xa[U], ya[U], za[U], xb[U], yb[U], zb[U];
+      auto load_set = [&](int base, float* x, float* y, float* z) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int off = (base + u * kB3Threads) * 4;
+          x[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+          y[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
+          z[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, off, 0, 0));
+        }
       };
-      auto consume = [&](int i, float x, float y, float z) {
-        float yx = fmaf(T.R[0], x, fmaf(T.R[1], y, T.R[2] * z));
-        float yy = fmaf(T.R[3], x, fmaf(T.R[4], y, T.R[5] * z));
-        float yz = fmaf(T.R[6], x, fmaf(T.R[7], y, T.R[8] * z));
-        const float px = yx + T.tx, py = yy + T.ty, pz = yz + T.tz;
-        const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c, fz = (pz - oz) * inv_c;
-        const bool in = (i < ns) & (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
-        const int key = in ? (((int)fz * Hh + (int)fy) * W + (int)fx) : 0;
-        int slot = idx[key];
-        if (!in) { yx = yy = yz = 0.f; slot = 0; }     // a NaN point must not reach the sums through 0 * NaN
-        accumulate_point3_map<MODE>(yx, yy, yz, px, py, pz, in, recA[slot], recB[slot], recC[slot], d1, d2, nhd2, acc);
+      // the U points of a set: all voxel lookups first (their LDS round trips overlap), then the sums
+      auto consume_set = [&](int base, const float* x, const float* y, const float* z) {
+        float yx[U], yy[U], yz[U], px[U], py[U], pz[U];
+        bool in[U];
+        float4 A4[U], B4[U];
+        float2 C2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          yx[u] = fmaf(T.R[0], x[u], fmaf(T.R[1], y[u], T.R[2] * z[u]));
+          yy[u] = fmaf(T.R[3], x[u], fmaf(T.R[4], y[u], T.R[5] * z[u]));
+          yz[u] = fmaf(T.R[6], x[u], fmaf(T.R[7], y[u], T.R[8] * z[u]));
+          px[u] = yx[u] + T.tx; py[u] = yy[u] + T.ty; pz[u] = yz[u] + T.tz;
+          const float fx = (px[u] - ox) * inv_c, fy = (py[u] - oy) * inv_c, fz = (pz[u] - oz) * inv_c;
+          in[u] = ((base + u * kB3Threads) < ns) & (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
+          const int key = in[u] ? (((int)fz * Hh + (int)fy) * W + (int)fx) : 0;
+          int slot = idx[key];
+          if (!in[u]) { yx[u] = yy[u] = yz[u] = 0.f; slot = 0; }   // a NaN point must not reach the sums through 0 * NaN
+          A4[u] = recA[slot]; B4[u] = recB[slot]; C2[u] = recC[slot];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          accumulate_point3_map<MODE>(yx[u], yy[u], yz[u], px[u], py[u], pz[u], in[u], A4[u], B4[u], C2[u], d1, d2, nhd2, acc);
       };
       if (ns > 0) {                                  // uniform
         load_set(tid, xa, ya, za);
-        for (int i = tid; i < ns; i += 2 * kB3Threads) {
-          load_set(i + kB3Threads, xb, yb, zb);
-          consume(i, xa, ya, za);
-          load_set(i + 2 * kB3Threads, xa, ya, za);
-          if (i + kB3Threads < ns) consume(i + kB3Threads, xb, yb, zb);     // wave-uniform except at the tail
+        for (int i = tid; i < ns; i += 2 * kTrip) {
+          load_set(i + kTrip, xb, yb, zb);
+          consume_set(i, xa, ya, za);
+          load_set(i + 2 * kTrip, xa, ya, za);
+          if (i + kTrip < ns) consume_set(i + kTrip, xb, yb, zb);     // wave-uniform except at the tail
         }
       }
     }

@@ -449,6 +449,10 @@ class NdtMatcherHip3 {
     const double init[6] = {guess.x, guess.y, guess.z, guess.roll, guess.pitch, guess.yaw};
     ndt3d_result r;
     check(ndt3d_align(h_, sx, sy, sz, n, init, &r), "ndt3d_align");
+    return toMatchResult(r);
+  }
+  ndt3d_handle* raw() { return h_; }
+  static MatchResult3 toMatchResult(const ndt3d_result& r) {
     MatchResult3 m;
     m.pose = {r.pose[0], r.pose[1], r.pose[2], r.pose[3], r.pose[4], r.pose[5]};
     for (int i = 0; i < 36; ++i) m.information[i] = r.H[i];
@@ -456,11 +460,70 @@ class NdtMatcherHip3 {
     m.score = r.score; m.iterations = r.iterations; m.n_hit = r.n_hit; m.status = r.status;
     return m;
   }
-  ndt3d_handle* raw() { return h_; }
 
  private:
   static void check(int32_t st, const char* where) { if (st < 0) throw NdtError(st, where); }
   ndt3d_handle* h_ = nullptr;
+};
+
+// 3D loop-closure candidates: many independent 3D pairs in one call (ndt3d_batch_*; the pair's voxel grid
+// lives in LDS for its whole alignment).  `levels` coarse to fine for a pyramid, one entry otherwise.
+class NdtBatchHip3 {
+ public:
+  struct Cloud { const float* x; const float* y; const float* z; size_t n; };
+
+  explicit NdtBatchHip3(const ndt3d_params& params = NdtMatcherHip3::defaultParams(), int device = 0) {
+    const int32_t st = ndt3d_batch_create(&params, device, &b_);
+    if (st != NDT_OK) throw NdtError(st, "ndt3d_batch_create");
+  }
+  NdtBatchHip3(const std::vector<ndt3d_params>& levels, int device) {
+    const int32_t st = ndt3d_batch_create_pyramid(levels.data(), static_cast<int32_t>(levels.size()), device, &b_);
+    if (st != NDT_OK) throw NdtError(st, "ndt3d_batch_create_pyramid");
+  }
+  ~NdtBatchHip3() { ndt3d_batch_destroy(b_); }
+  NdtBatchHip3(const NdtBatchHip3&) = delete;
+  NdtBatchHip3& operator=(const NdtBatchHip3&) = delete;
+
+  std::vector<MatchResult3> align(const std::vector<Cloud>& targets, const std::vector<Cloud>& sources,
+                                  const std::vector<Pose3>& guesses) {
+    const size_t n = targets.size();
+    if (sources.size() != n || guesses.size() != n || n == 0) throw NdtError(NDT_ERR_INVALID_ARG, "ndt3d_batch_align");
+    std::vector<uint64_t> toff(n + 1, 0), soff(n + 1, 0);
+    for (size_t k = 0; k < n; ++k) { toff[k + 1] = toff[k] + targets[k].n; soff[k + 1] = soff[k] + sources[k].n; }
+    std::vector<float> t[3], s[3];
+    for (int c = 0; c < 3; ++c) { t[c].resize(toff[n]); s[c].resize(soff[n]); }
+    std::vector<double> init(6 * n);
+    for (size_t k = 0; k < n; ++k) {
+      const float* tc[3] = {targets[k].x, targets[k].y, targets[k].z};
+      const float* sc[3] = {sources[k].x, sources[k].y, sources[k].z};
+      for (int c = 0; c < 3; ++c) {
+        std::copy(tc[c], tc[c] + targets[k].n, t[c].begin() + toff[k]);
+        std::copy(sc[c], sc[c] + sources[k].n, s[c].begin() + soff[k]);
+      }
+      const Pose3& g = guesses[k];
+      const double p[6] = {g.x, g.y, g.z, g.roll, g.pitch, g.yaw};
+      std::copy(p, p + 6, init.begin() + 6 * k);
+    }
+    std::vector<ndt3d_result> res(n);
+    const int32_t st = ndt3d_batch_align(b_, t[0].data(), t[1].data(), t[2].data(), toff.data(), s[0].data(), s[1].data(),
+                                         s[2].data(), soff.data(), init.data(), n, res.data());
+    if (st < 0) throw NdtError(st, "ndt3d_batch_align");
+    std::vector<MatchResult3> out;
+    out.reserve(n);
+    for (const auto& r : res) out.push_back(NdtMatcherHip3::toMatchResult(r));
+    return out;
+  }
+  // device arrays laid out as ndt3d_batch_align_dev takes them; asynchronous on `stream` (nullptr: the context's own)
+  void alignDev(const float* d_tx, const float* d_ty, const float* d_tz, const uint64_t* d_toff, const float* d_sx,
+                const float* d_sy, const float* d_sz, const uint64_t* d_soff, const double* d_init, size_t n_pairs,
+                ndt3d_result* d_results, void* stream = nullptr) {
+    const int32_t st = ndt3d_batch_align_dev(b_, d_tx, d_ty, d_tz, d_toff, d_sx, d_sy, d_sz, d_soff, d_init, n_pairs, d_results, stream);
+    if (st < 0) throw NdtError(st, "ndt3d_batch_align_dev");
+  }
+  void* stream() { return ndt3d_batch_stream(b_); }
+
+ private:
+  ndt3d_batch* b_ = nullptr;
 };
 
 }  // namespace ndt

@@ -132,6 +132,14 @@ int main(int argc, char** argv) {
       for (int k = 0; k < 6; ++k) ic += r3.information[k] * r3.covariance[6 * k];
       std::printf("three_d %.9g %.9g %.9g %.9g %.9g %.9g %d %d %.6f\n", r3.pose.x, r3.pose.y, r3.pose.z, r3.pose.roll,
                   r3.pose.pitch, r3.pose.yaw, r3.iterations, r3.status, ic);
+      // the same pair twice through the 3D batch (one of them from a displaced guess): both must land on the single-pair pose
+      ndt::NdtBatchHip3 b3;
+      const ndt::NdtBatchHip3::Cloud tc{x.data(), y.data(), z.data(), x.size()}, sc{qx.data(), qy.data(), qz.data(), qx.size()};
+      ndt::Pose3 off; off.x = 0.02; off.y = -0.02; off.yaw = 0.002;
+      const std::vector<ndt::MatchResult3> rb = b3.align({tc, tc}, {sc, sc}, {ndt::Pose3(), off});
+      for (size_t k = 0; k < rb.size(); ++k)
+        std::printf("three_d_batch%zu %.9g %.9g %.9g %.9g %.9g %.9g %d %d\n", k, rb[k].pose.x, rb[k].pose.y, rb[k].pose.z,
+                    rb[k].pose.roll, rb[k].pose.pitch, rb[k].pose.yaw, rb[k].iterations, rb[k].status);
     }
   } catch (const ndt::NdtError& e) {
     std::printf("error %d %s\n", e.code(), e.what());
