@@ -36,6 +36,9 @@ struct Batch3Args {
   Result3Dev* out;           // [n_pairs]
   unsigned int* queue;       // zeroed before the launch
   unsigned char* slab;       // [gridDim.x][kB3SlabBytes]
+  unsigned char* gslab;      // tables of the global-memory variant: [kG3Blocks][kG3SlabBytes]
+  int* fb_marks;             // [n_pairs], zeroed before the launches: k_batch3 sets 1 for a pair over the LDS carve,
+                             // k_batch3_fallback processes exactly those (null: such pairs get NDT_ERR_CAPACITY at once)
   int n_pairs;
   int min_points;
   int fixed_iterations;
@@ -68,6 +71,22 @@ constexpr int kB3SlabN = 0;
 constexpr int kB3SlabKey = kB3SlabN + kB3MaxSlots * 4;
 constexpr int kB3SlabSums = kB3SlabKey + kB3MaxSlots * 4;
 constexpr int kB3SlabBytes = kB3SlabSums + 9 * kB3MaxSlots * 8;
+
+// Second variant, for the pairs whose voxel grid does not fit the LDS carve (a scan against a wide or finely
+// gridded map): the same code with every table in a per-workgroup slab of global memory - u32 voxel -> slot
+// table (also the counts of the build), per-slot counts / keys / nine sums (global 64-bit atomics, one pass),
+// 40-byte records gathered through L2.  It runs on kG3Blocks workgroups and only on the pairs k_batch3 handed over.
+constexpr int kG3MaxCells = 1 << 21;                    // 2 097 152 voxels (e.g. 256 x 256 x 32)
+constexpr int kG3MaxSlots = 1 << 16;                    // occupied voxels (slot 0 is the dummy record)
+constexpr int kG3Blocks = 16;
+constexpr size_t kG3Idx = 0;                                                  // u32 [MaxCells]
+constexpr size_t kG3SlotN = kG3Idx + (size_t)kG3MaxCells * 4;                 // u32 [MaxSlots]
+constexpr size_t kG3SlotKey = kG3SlotN + (size_t)kG3MaxSlots * 4;             // u32 [MaxSlots]
+constexpr size_t kG3Sums = kG3SlotKey + (size_t)kG3MaxSlots * 4;              // u64 [9][MaxSlots]
+constexpr size_t kG3RecA = kG3Sums + (size_t)9 * kG3MaxSlots * 8;             // float4 [MaxSlots]
+constexpr size_t kG3RecB = kG3RecA + (size_t)kG3MaxSlots * 16;                // float4 [MaxSlots]
+constexpr size_t kG3RecC = kG3RecB + (size_t)kG3MaxSlots * 16;                // float2 [MaxSlots]
+constexpr size_t kG3SlabBytes = kG3RecC + (size_t)kG3MaxSlots * 8;            // 15.7 MB
 
 constexpr int kTgt3Unroll = 4;
 template <typename F>
@@ -241,19 +260,21 @@ __device__ __forceinline__ void map_sums_to_pose_frame(const double* pose, const
 }
 
 // One pair, start to finish, on the calling workgroup (plain returns for the early outs: see process_pair).
-template <int MODE>
+template <int MODE, bool GLOBAL>
 __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pair, unsigned char* smem) {
   constexpr int NA = Acc3<MODE>::kUsed;
+  using IdxT = typename std::conditional<GLOBAL, unsigned int, unsigned short>::type;
+  constexpr int kS = GLOBAL ? kG3MaxSlots : kB3MaxSlots;       // row stride of the sums in the slab
   float* red = reinterpret_cast<float*>(smem + kB3Red);
   double* bc = reinterpret_cast<double*>(smem + kB3Bc);
   int* misc = reinterpret_cast<int*>(smem + kB3Misc);
   int* s_scan = reinterpret_cast<int*>(smem + kB3Scan);
   LineSearch3* ls_lds = reinterpret_cast<LineSearch3*>(smem + kB3Ls);
-  unsigned short* idx = reinterpret_cast<unsigned short*>(smem + kB3Idx);
-  unsigned char* slab = a.slab + (size_t)blockIdx.x * kB3SlabBytes;
-  unsigned int* slot_n = reinterpret_cast<unsigned int*>(slab + kB3SlabN);
-  unsigned int* slot_key = reinterpret_cast<unsigned int*>(slab + kB3SlabKey);
-  unsigned long long* gsums = reinterpret_cast<unsigned long long*>(slab + kB3SlabSums);
+  unsigned char* slab = GLOBAL ? a.gslab + (size_t)blockIdx.x * kG3SlabBytes : a.slab + (size_t)blockIdx.x * kB3SlabBytes;
+  IdxT* idx = GLOBAL ? reinterpret_cast<IdxT*>(slab + kG3Idx) : reinterpret_cast<IdxT*>(smem + kB3Idx);
+  unsigned int* slot_n = reinterpret_cast<unsigned int*>(slab + (GLOBAL ? kG3SlotN : (size_t)kB3SlabN));
+  unsigned int* slot_key = reinterpret_cast<unsigned int*>(slab + (GLOBAL ? kG3SlotKey : (size_t)kB3SlabKey));
+  unsigned long long* gsums = reinterpret_cast<unsigned long long*>(slab + (GLOBAL ? kG3Sums : (size_t)kB3SlabSums));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int minpts = a.min_points < 2 ? 2 : a.min_points;
 
@@ -317,7 +338,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
         ncell_d *= (double)dims[c];
       }
       // the voxel table (2 B per voxel) and, during the build, the counts (4 B per voxel) behind it
-      if (st == 0 && (ncell_d > 65535.0 || kB3Idx + 16 + 6.0 * ncell_d > (double)kB3LdsBytes)) st = kStatusCapacity;
+      if (st == 0 && (GLOBAL ? ncell_d > (double)kG3MaxCells : kB3Idx + 16 + 6.0 * ncell_d > (double)kB3LdsBytes)) st = kStatusCapacity;
       misc[1] = dims[0]; misc[2] = dims[1]; misc[3] = dims[2]; misc[4] = st;
       reinterpret_cast<float*>(misc)[5] = o[0];
       reinterpret_cast<float*>(misc)[6] = o[1];
@@ -337,17 +358,21 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   static_assert(kFixShift == 22, "fix_scale literal");
   __syncthreads();                                 // misc is rewritten below
   if (st0 != 0) {                                  // uniform
-    if (tid == 0) write_result3(out, pose, nullptr, nullptr, 0.0, iter_base, 0, st0);
+    if (tid == 0) {
+      if (!GLOBAL && st0 == kStatusCapacity && a.fb_marks) a.fb_marks[pair] = 1;      // too many voxels for the LDS carve
+      else write_result3(out, pose, nullptr, nullptr, 0.0, iter_base, 0, st0);
+    }
     return;
   }
-  // per-pair carve behind the voxel table
+  // on chip: per-pair carve behind the voxel table; global variant: fixed regions of the slab, and the counts
+  // of the build live in the voxel table itself (converted to slot indices in place)
   const int rec_base = (kB3Idx + 2 * ncell + 15) & ~15;
-  const int slot_cap = (kB3LdsBytes - rec_base) / kB3RecBytes;      // records incl. the dummy record 0
-  unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + rec_base);                   // build: u32 [ncell]
-  unsigned long long* psum = reinterpret_cast<unsigned long long*>(smem + rec_base);      // build: u64 [3][nslot]
-  float4* recA = reinterpret_cast<float4*>(smem + rec_base);
-  float4* recB = reinterpret_cast<float4*>(smem + rec_base + 16 * slot_cap);
-  float2* recC = reinterpret_cast<float2*>(smem + rec_base + 32 * slot_cap);
+  const int slot_cap = GLOBAL ? kG3MaxSlots : (kB3LdsBytes - rec_base) / kB3RecBytes;      // records incl. the dummy record 0
+  unsigned int* cnt = GLOBAL ? reinterpret_cast<unsigned int*>(slab + kG3Idx) : reinterpret_cast<unsigned int*>(smem + rec_base);
+  unsigned long long* psum = reinterpret_cast<unsigned long long*>(smem + rec_base);      // on-chip build: u64 [3][nslot]
+  float4* recA = GLOBAL ? reinterpret_cast<float4*>(slab + kG3RecA) : reinterpret_cast<float4*>(smem + rec_base);
+  float4* recB = GLOBAL ? reinterpret_cast<float4*>(slab + kG3RecB) : reinterpret_cast<float4*>(smem + rec_base + 16 * slot_cap);
+  float2* recC = GLOBAL ? reinterpret_cast<float2*>(slab + kG3RecC) : reinterpret_cast<float2*>(smem + rec_base + 32 * slot_cap);
 
   auto voxel_of = [&](float px, float py, float pz, int& ix, int& iy, int& iz) -> bool {
     const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c, fz = (pz - oz) * inv_c;
@@ -364,6 +389,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     if (voxel_of(px, py, pz, ix, iy, iz)) atomicAdd(&cnt[(iz * Hh + iy) * W + ix], 1u);
   });
   __syncthreads();
+  if constexpr (GLOBAL) __threadfence();           // the counts were added at L2: drop what this CU's L1 holds of the slab
 
   // ---- compaction: voxels with n >= min_points get a slot, in voxel order (deterministic)
   const int chunk = (ncell + kB3Threads - 1) / kB3Threads;
@@ -374,14 +400,17 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   int nslot = 0;
   int s = block_excl_scan<Cfg1024>(local, s_scan, &nslot);
   nslot = __builtin_amdgcn_readfirstlane(nslot);
-  if (nslot + 1 > slot_cap || nslot > kB3MaxSlots || nslot < 1) {   // uniform (record 0 is the dummy)
-    if (tid == 0) write_result3(out, pose, nullptr, nullptr, 0.0, iter_base, 0, nslot < 1 ? 4 : kStatusCapacity);
+  if (nslot + 1 > slot_cap || nslot > kS || nslot < 1) {   // uniform (record 0 is the dummy)
+    if (tid == 0) {
+      if (!GLOBAL && nslot >= 1 && a.fb_marks) a.fb_marks[pair] = 1;                  // too many occupied voxels for the carve
+      else write_result3(out, pose, nullptr, nullptr, 0.0, iter_base, 0, nslot < 1 ? 4 : kStatusCapacity);
+    }
     return;
   }
   for (int k = c0; k < c1; ++k) {
-    const unsigned int n = cnt[k];
+    const unsigned int n = cnt[k];                 // (global variant: read before idx[k], the same word, is written)
     if (n >= (unsigned)minpts) {
-      idx[k] = (unsigned short)(s + 1);
+      idx[k] = (IdxT)(s + 1);
       slot_n[s] = n;
       slot_key[s] = (unsigned)k;
       ++s;
@@ -391,55 +420,85 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   }
   __syncthreads();                                 // cnt is dead; its bytes become the pass sums
 
-  // ---- a2 (2/2): exact fixed-point sums per slot, three of the nine per pass (LDS 64-bit integer atomics)
-#pragma unroll 1
-  for (int pass = 0; pass < 3; ++pass) {
-    for (int j = tid; j < 3 * nslot; j += kB3Threads) psum[j] = 0ull;
+  if constexpr (GLOBAL) {
+    // ---- a2 (2/2), global variant: the nine exact sums per slot by 64-bit atomics at L2, one pass
+    for (int j = tid; j < 9 * kS; j += kB3Threads)
+      if ((j % kS) < nslot) gsums[j] = 0ull;
+    __threadfence();
     __syncthreads();
     for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
       int ix, iy, iz;
       if (voxel_of(px, py, pz, ix, iy, iz)) {
-        const int slot = idx[(iz * Hh + iy) * W + ix];
+        const int slot = (int)idx[(iz * Hh + iy) * W + ix];
         if (slot) {
           const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
           const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
           const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
-          unsigned long long* q = psum + (slot - 1);
-          if (pass == 0) {          // s[0..2]
-            atomicAdd(q, (unsigned long long)(long long)ux);
-            atomicAdd(q + nslot, (unsigned long long)(long long)uy);
-            atomicAdd(q + 2 * nslot, (unsigned long long)(long long)uz);
-          } else if (pass == 1) {   // ss[0..2] = xx xy xz
-            atomicAdd(q, prod64(ux, ux));
-            atomicAdd(q + nslot, prod64(ux, uy));
-            atomicAdd(q + 2 * nslot, prod64(ux, uz));
-          } else {                  // ss[3..5] = yy yz zz
-            atomicAdd(q, prod64(uy, uy));
-            atomicAdd(q + nslot, prod64(uy, uz));
-            atomicAdd(q + 2 * nslot, prod64(uz, uz));
-          }
+          unsigned long long* q = gsums + (slot - 1);
+          atomicAdd(q, (unsigned long long)(long long)ux);
+          atomicAdd(q + kS, (unsigned long long)(long long)uy);
+          atomicAdd(q + 2 * kS, (unsigned long long)(long long)uz);
+          atomicAdd(q + 3 * kS, prod64(ux, ux));
+          atomicAdd(q + 4 * kS, prod64(ux, uy));
+          atomicAdd(q + 5 * kS, prod64(ux, uz));
+          atomicAdd(q + 6 * kS, prod64(uy, uy));
+          atomicAdd(q + 7 * kS, prod64(uy, uz));
+          atomicAdd(q + 8 * kS, prod64(uz, uz));
         }
       }
     });
     __syncthreads();
-    for (int j = tid; j < 3 * nslot; j += kB3Threads)
-      gsums[(size_t)(3 * pass + j / nslot) * kB3MaxSlots + (j % nslot)] = psum[j];
-    __syncthreads();
+  } else {
+    // ---- a2 (2/2): exact fixed-point sums per slot, three of the nine per pass (LDS 64-bit integer atomics)
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+      for (int j = tid; j < 3 * nslot; j += kB3Threads) psum[j] = 0ull;
+      __syncthreads();
+      for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+        int ix, iy, iz;
+        if (voxel_of(px, py, pz, ix, iy, iz)) {
+          const int slot = idx[(iz * Hh + iy) * W + ix];
+          if (slot) {
+            const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
+            const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
+            const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
+            unsigned long long* q = psum + (slot - 1);
+            if (pass == 0) {          // s[0..2]
+              atomicAdd(q, (unsigned long long)(long long)ux);
+              atomicAdd(q + nslot, (unsigned long long)(long long)uy);
+              atomicAdd(q + 2 * nslot, (unsigned long long)(long long)uz);
+            } else if (pass == 1) {   // ss[0..2] = xx xy xz
+              atomicAdd(q, prod64(ux, ux));
+              atomicAdd(q + nslot, prod64(ux, uy));
+              atomicAdd(q + 2 * nslot, prod64(ux, uz));
+            } else {                  // ss[3..5] = yy yz zz
+              atomicAdd(q, prod64(uy, uy));
+              atomicAdd(q + nslot, prod64(uy, uz));
+              atomicAdd(q + 2 * nslot, prod64(uz, uz));
+            }
+          }
+        }
+      });
+      __syncthreads();
+      for (int j = tid; j < 3 * nslot; j += kB3Threads)
+        gsums[(size_t)(3 * pass + j / nslot) * kS + (j % nslot)] = psum[j];
+      __syncthreads();
+    }
   }
   if (tid == 0) misc[8] = 0;
   __threadfence();                                 // the slab was written with plain stores by other waves of this workgroup
   __syncthreads();
 
-  // ---- a3: finalise, records into LDS
+  // ---- a3: finalise, records into LDS (global variant: into the slab)
   {
     int nvalid = 0;
     for (int sl = tid; sl < nslot; sl += kB3Threads) {
       CellAcc3 c;
       c.n = slot_n[sl]; c.pad = 0u;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) c.s[j] = (long long)gsums[(size_t)j * kB3MaxSlots + sl];
+      for (int j = 0; j < 3; ++j) c.s[j] = (long long)gsums[(size_t)j * kS + sl];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) c.ss[j] = (long long)gsums[(size_t)(3 + j) * kB3MaxSlots + sl];
+      for (int j = 0; j < 6; ++j) c.ss[j] = (long long)gsums[(size_t)(3 + j) * kS + sl];
       const unsigned int key = slot_key[sl], w32 = (unsigned)W, h32 = (unsigned)Hh;
       const int ix = (int)(key % w32), iy = (int)((key / w32) % h32), iz = (int)(key / (w32 * h32));
       float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
@@ -453,6 +512,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     }
     if (tid == 0) { recA[0] = make_float4(0.f, 0.f, 0.f, 0.f); recB[0] = recA[0]; recC[0] = make_float2(0.f, 0.f); }
     if (nvalid) atomicAdd(&misc[8], nvalid);
+    if constexpr (GLOBAL) __threadfence();         // records and table are read through L1 / L2 from here on
     __syncthreads();
   }
   if (__builtin_amdgcn_readfirstlane(misc[8]) < 1) {   // uniform
@@ -508,7 +568,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
           const float fx = (px[u] - ox) * inv_c, fy = (py[u] - oy) * inv_c, fz = (pz[u] - oz) * inv_c;
           in[u] = ((base + u * kB3Threads) < ns) & (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
           const int key = in[u] ? (((int)fz * Hh + (int)fy) * W + (int)fx) : 0;
-          int slot = idx[key];
+          int slot = (int)idx[key];
           if (!in[u]) { yx[u] = yy[u] = yz[u] = 0.f; slot = 0; }   // a NaN point must not reach the sums through 0 * NaN
           A4[u] = recA[slot]; B4[u] = recB[slot]; C2[u] = recC[slot];
         }
@@ -587,8 +647,22 @@ __global__ __launch_bounds__(kB3Threads) void k_batch3(Batch3Args a) {
     const int pair = __builtin_amdgcn_readfirstlane(misc[0]);
     __syncthreads();
     if (pair >= a.n_pairs) break;
-    process_pair3<MODE>(a, pair, smem);
+    process_pair3<MODE, false>(a, pair, smem);
     __syncthreads();                                 // LDS and the slab are rewritten by the next pair
+  }
+}
+
+// The pairs k_batch3 handed over (fb_marks), tables in global memory.  No queue: workgroup b looks at pairs
+// b, b + gridDim.x, ... (one scalar load each; with nothing handed over the launch costs a few microseconds).
+template <int MODE>
+__global__ __launch_bounds__(kB3Threads) void k_batch3_fallback(Batch3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  for (int pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
+    if (__builtin_amdgcn_readfirstlane(a.fb_marks[pair]) != 0) {              // uniform
+      process_pair3<MODE, true>(a, pair, smem);
+      __syncthreads();
+      __threadfence();                                // the next pair rewrites this workgroup's slab
+    }
   }
 }
 

@@ -11,6 +11,9 @@ struct ndt3d_batch {
   int n_cu = 0;
   unsigned int* d_queue = nullptr;
   unsigned char* d_slab = nullptr;    // [n_cu][kB3SlabBytes]
+  unsigned char* d_gslab = nullptr;   // [kG3Blocks][kG3SlabBytes]: tables of the global-memory variant
+  int* d_fb = nullptr;                // [n_pairs]: marks of the pairs k_batch3 left to the global-memory variant
+  size_t fb_cap = 0;
   // staging for the host-pointer entry point (one capacity per buffer)
   float *d_t[3] = {nullptr, nullptr, nullptr}, *d_s[3] = {nullptr, nullptr, nullptr};
   size_t cap_t[3] = {0, 0, 0}, cap_s[3] = {0, 0, 0};
@@ -39,8 +42,18 @@ int32_t batch3_launch(ndt3d_batch* b, const float* const d_t[3], const unsigned 
   a.out = reinterpret_cast<ndt::Result3Dev*>(d_out);
   a.queue = b->d_queue;
   a.slab = b->d_slab;
+  a.gslab = b->d_gslab;
   a.n_pairs = (int)n_pairs;
   const int blocks = (int)(n_pairs < (size_t)b->n_cu ? n_pairs : (size_t)b->n_cu);
+  const int blocks_fb = (int)(n_pairs < (size_t)ndt::kG3Blocks ? n_pairs : (size_t)ndt::kG3Blocks);
+  if (n_pairs > b->fb_cap) {
+    if (b->d_fb) (void)hipFree(b->d_fb);
+    b->d_fb = nullptr; b->fb_cap = 0;
+    const size_t want = n_pairs + n_pairs / 4 + 64;
+    HIP_TRY(hipMalloc((void**)&b->d_fb, want * sizeof(int)));
+    b->fb_cap = want;
+  }
+  a.fb_marks = b->d_fb;
   for (size_t lv = 0; lv < b->levels.size(); ++lv) {
     const ndt3d_params& p = b->levels[lv];
     a.chain = lv > 0 ? 1 : 0;
@@ -57,10 +70,18 @@ int32_t batch3_launch(ndt3d_batch* b, const float* const d_t[3], const unsigned 
     a.prm.step_max_trans = p.step_max_trans; a.prm.step_max_rot = p.step_max_rot;
     a.prm.step_scale = p.step_scale > 0.0 ? p.step_scale : 1.0;
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 16, st));
-    if (p.hessian_mode == NDT_HESSIAN_NEWTON)
+    HIP_TRY(hipMemsetAsync(b->d_fb, 0, n_pairs * sizeof(int), st));
+    const bool newton = p.hessian_mode == NDT_HESSIAN_NEWTON;
+    if (newton)
       hipLaunchKernelGGL((ndt::k_batch3<1>), dim3(blocks), dim3(ndt::kB3Threads), ndt::kB3LdsBytes, st, a);
     else
       hipLaunchKernelGGL((ndt::k_batch3<0>), dim3(blocks), dim3(ndt::kB3Threads), ndt::kB3LdsBytes, st, a);
+    HIP_TRY(hipGetLastError());
+    // pairs whose voxel grid does not fit the LDS carve (handed over through fb_marks): tables in global memory
+    if (newton)
+      hipLaunchKernelGGL((ndt::k_batch3_fallback<1>), dim3(blocks_fb), dim3(ndt::kB3Threads), ndt::kB3Idx, st, a);
+    else
+      hipLaunchKernelGGL((ndt::k_batch3_fallback<0>), dim3(blocks_fb), dim3(ndt::kB3Threads), ndt::kB3Idx, st, a);
     HIP_TRY(hipGetLastError());
   }
   return NDT_OK;
@@ -74,7 +95,7 @@ int32_t ndt3d_batch_destroy(ndt3d_batch* b) {
   if (!b) return NDT_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* dev[] = {b->d_slab, b->d_queue, b->d_t[0], b->d_t[1], b->d_t[2], b->d_s[0], b->d_s[1], b->d_s[2],
+  void* dev[] = {b->d_slab, b->d_gslab, b->d_fb, b->d_queue, b->d_t[0], b->d_t[1], b->d_t[2], b->d_s[0], b->d_s[1], b->d_s[2],
                  b->d_toff, b->d_soff, b->d_init, b->d_out};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (ndt3d_handle* f : b->fallback) ndt3d_destroy(f);
@@ -107,6 +128,7 @@ int32_t ndt3d_batch_create_pyramid(const ndt3d_params* levels, int32_t n_levels,
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipMalloc((void**)&b->d_queue, 16) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&b->d_slab, (size_t)b->n_cu * ndt::kB3SlabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&b->d_gslab, (size_t)ndt::kG3Blocks * ndt::kG3SlabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
   // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch3<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::kB3LdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
@@ -177,7 +199,7 @@ int32_t ndt3d_batch_align(ndt3d_batch* b, const float* tx, const float* ty, cons
   if (st != NDT_OK) return st;
   HIP_TRY(hipMemcpyAsync(results, b->d_out, n_pairs * sizeof(ndt3d_result), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  // pairs whose voxel grid does not fit the on-chip capacity go through the single-pair path
+  // pairs beyond the global-memory variant's limits as well go through the single-pair path
   for (size_t k = 0; k < n_pairs; ++k) {
     if (results[k].status != NDT_ERR_CAPACITY) continue;
     if (b->fallback.empty()) {

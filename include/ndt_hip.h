@@ -432,8 +432,10 @@ int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
  * ndt3d_align) up to float32 summation order: same records bit for bit, same per-point arithmetic.
  * On-chip capacity per pair: 2 B per voxel + 40 B per occupied voxel <= 157 KB and 6 B per voxel
  * <= 157 KB during the build (BASELINE config 5: 17 424 voxels, 2 706 occupied = 143 KB).  A pair
- * beyond it gets status NDT_ERR_CAPACITY from the _dev entry point; the host-pointer entry point
- * re-runs it through the single-pair path transparently.  Stream semantics as ndt2d_batch_align_dev. */
+ * beyond it is handed, on the device and within the same call, to a second variant of the kernel that
+ * keeps the pair's tables in global memory (up to 2^21 voxels - e.g. 256 x 256 x 32 - and 65 535 occupied).
+ * Beyond that a pair gets status NDT_ERR_CAPACITY from the _dev entry point, and the host-pointer entry
+ * point re-runs it through the single-pair path transparently.  Stream semantics as ndt2d_batch_align_dev. */
 typedef struct ndt3d_batch ndt3d_batch;
 int32_t ndt3d_batch_create(const ndt3d_params* p, int32_t device_id, ndt3d_batch** out);
 /* coarse-to-fine over the batch, as ndt2d_batch_create_pyramid (levels coarse to fine, at most 8) */
