@@ -28,7 +28,7 @@ NDT_ERR_RCCL = -7
 
 # ndt2d_set_tuning / ndt2d_batch_set_tuning knobs
 TUNING = {"launch_graphs": 1, "wide_threshold": 2, "short_scan_kernel": 3, "chunk_launches": 4, "binned_build": 5,
-          "batch_small_variant": 6, "team_kernel": 7, "split_from": 8}
+          "batch_small_variant": 6, "team_kernel": 7, "split_from": 8, "single_sync_build": 9}
 
 HESSIAN_GAUSS_NEWTON = 0
 HESSIAN_NEWTON = 1

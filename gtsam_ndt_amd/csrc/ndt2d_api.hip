@@ -53,6 +53,11 @@ struct ndt2d_handle {
   // binned grid build scratch (ndt2d_build.hpp)
   float* d_bx = nullptr; float* d_by = nullptr; size_t bcap = 0;
   unsigned int* d_tiles = nullptr; size_t tile_cap = 0;   // total[nt] | start[nt+1] | cursor[nt]
+  ndt::GeomDev* d_geom = nullptr;          // geometry decided on the device (one-round-trip ndt2d_set_target)
+  ndt::GeomDev* h_geom = nullptr;          // pinned: its read-back
+  int last_ntile = 0;                      // tiles of the cached grid: the next build's launch bound follows it
+  bool static_on_device = false;           // d_static holds this handle's parameters (some upload_static has run)
+  bool one_round_trip = true;              // NDT_TUNE_SINGLE_SYNC_BUILD
   bool use_binned_build = true;
   // hipGraph of the launch chain (launch-bound inner loop: one replay instead of K+1 launches)
   ChainGraphCache graphs;
@@ -196,14 +201,16 @@ int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* 
       BinGeom bg{g.gx[q], g.gy[q], g.inv_c, g.W, g.H, ntx, ntile};
       HIP_TRY(hipMemsetAsync(d_total, 0, ntile * sizeof(unsigned int), h->stream));
       hipLaunchKernelGGL(k_tile_count, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream,
-                         d_x, d_y, n, bg, d_total, q == 0 ? h->d_outside : (unsigned long long*)nullptr);
-      hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile);
+                         d_x, d_y, n, bg, d_total, q == 0 ? h->d_outside : (unsigned long long*)nullptr, (const GeomDev*)nullptr);
+      hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, (const GeomDev*)nullptr);
       hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int),
-                         h->stream, d_x, d_y, n, bg, d_cursor, h->d_bx, h->d_by);
+                         h->stream, d_x, d_y, n, bg, d_cursor, h->d_bx, h->d_by, (const GeomDev*)nullptr);
       hipLaunchKernelGGL(k_tile_accumulate, dim3(ntile), dim3(kBinThreads), 0, h->stream, h->d_bx, h->d_by, d_start, g, q,
-                         ntx, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+                         ntx, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, h->d_counters, (const GeomDev*)nullptr,
+                         (const GridDev*)nullptr);
       HIP_TRY(hipGetLastError());
     }
+    h->last_ntile = ntile;
     int* hc = (int*)h->h_small;
     unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 32);
     HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -267,19 +274,108 @@ int32_t setup_geometry(ndt2d_handle* h, float xmin, float xmax, float ymin, floa
   return NDT_OK;
 }
 
+// ndt2d_set_target with ONE host round trip: bounds -> geometry (k_geometry, on the device, into d_static) ->
+// binned build, enqueued back to back; the host learns the geometry together with the counters.  Possible
+// when the handle already holds storage and parameters on the device (any earlier target) and the new grid
+// fits them and the launch bound chosen here; otherwise *done = false (with the bounding box in hb_out when
+// the device got that far) and the caller builds the usual way.
+int32_t set_target_single_sync(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n, bool* done, unsigned int* hb_out,
+                               bool* have_bounds) {
+  *done = false; *have_bounds = false;
+  if (!h->one_round_trip || !h->use_binned_build || h->prm.overlap_grids == 4 || h->cell_capacity == 0 || !h->static_on_device ||
+      h->last_ntile <= 0 || n > 0xFFFFFFFFull || !h->grid.rec || !h->grid.acc)
+    return NDT_OK;
+  long long tb = 2ll * h->last_ntile + 16;
+  if (tb > kBinMaxTiles) tb = kBinMaxTiles;
+  const int tile_bound = (int)tb;
+  if (n > h->bcap) {
+    if (h->d_bx) (void)hipFree(h->d_bx);
+    if (h->d_by) (void)hipFree(h->d_by);
+    h->d_bx = h->d_by = nullptr; h->bcap = 0;
+    const size_t want = n + n / 4 + 1024;
+    HIP_TRY(hipMalloc((void**)&h->d_bx, want * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&h->d_by, want * sizeof(float)));
+    h->bcap = want;
+  }
+  const size_t tneed = 3 * (size_t)tile_bound + 4;
+  if (tneed > h->tile_cap) {
+    if (h->d_tiles) (void)hipFree(h->d_tiles);
+    h->d_tiles = nullptr; h->tile_cap = 0;
+    HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
+    h->tile_cap = tneed;
+  }
+  if (!h->d_geom) {
+    HIP_TRY(hipMalloc((void**)&h->d_geom, sizeof(GeomDev)));
+    HIP_TRY(hipHostMalloc((void**)&h->h_geom, sizeof(GeomDev), hipHostMallocDefault));
+  }
+  // tile tables laid out for the bound: total[tb] | start[tb+1] | cursor[tb]
+  unsigned int* d_total = h->d_tiles;
+  unsigned int* d_start = h->d_tiles + tile_bound;
+  unsigned int* d_cursor = h->d_tiles + 2 * tile_bound + 1;
+  GeomDev* dg = h->d_geom;
+  hipLaunchKernelGGL(k_build_init, dim3(1), dim3(1024), 0, h->stream, dg, d_total, tile_bound);
+  hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > kBoundsBlocks ? kBoundsBlocks : stream_blocks(n)), dim3(kBlock), 0, h->stream,
+                     d_x, d_y, n, &dg->bounds[0]);
+  hipLaunchKernelGGL(k_geometry, dim3(1), dim3(64), 0, h->stream, h->prm.cell_size, (unsigned long long)h->cell_capacity, tile_bound,
+                     &h->d_static->grid, dg);
+  const size_t chunk = (size_t)kBinThreads * kBinPerThread;
+  size_t nb = (n + chunk - 1) / chunk;
+  if (nb > 1024) nb = 1024;
+  const BinGeom none{};
+  hipLaunchKernelGGL(k_tile_count, dim3((unsigned)nb), dim3(kBinThreads), tile_bound * sizeof(unsigned int), h->stream, d_x, d_y, n,
+                     none, d_total, &dg->n_outside, (const GeomDev*)dg);
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, 0, (const GeomDev*)dg);
+  hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)nb), dim3(kBinThreads), 2 * tile_bound * sizeof(unsigned int), h->stream, d_x,
+                     d_y, n, none, d_cursor, h->d_bx, h->d_by, (const GeomDev*)dg);
+  hipLaunchKernelGGL(k_tile_accumulate, dim3(tile_bound), dim3(kBinThreads), 0, h->stream, h->d_bx, h->d_by, d_start, h->grid, 0, 0,
+                     0, h->prm.min_points, h->prm.eig_ratio, &dg->counters[0], (const GeomDev*)dg,
+                     (const GridDev*)&h->d_static->grid);
+  HIP_TRY(hipGetLastError());
+  GeomDev* hg = h->h_geom;
+  HIP_TRY(hipMemcpyAsync(hg, dg, sizeof(GeomDev), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int* hc = hg->counters;
+  for (int j = 0; j < 4; ++j) hb_out[j] = hg->bounds[j];
+  *have_bounds = true;
+  if (!hg->ok) return NDT_OK;                            // does not fit storage or bound (or no finite point): the usual way
+  // the host's view of the same geometry, from the same bounds; storage is large enough, nothing is reallocated
+  const int32_t gs = setup_geometry(h, ordered_to_float(hg->bounds[0]), ordered_to_float(hg->bounds[1]),
+                                    ordered_to_float(hg->bounds[2]), ordered_to_float(hg->bounds[3]));
+  if (gs != NDT_OK) return NDT_OK;
+  if (h->grid.W != hg->bin.W || h->grid.H != hg->bin.H || h->grid.ox != hg->bin.ox || h->grid.oy != hg->bin.oy) return NDT_OK;
+  h->h_static->grid = h->grid;                           // what d_static holds already
+  h->last_ntile = hg->bin.ntile;
+  h->n_valid = hc[0];
+  if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+  *done = true;
+  return NDT_OK;
+}
+
 int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n) {
   TraceRange range("ndt2d_set_target: grid build");
   h->has_target = false;
   if (n == 0) return NDT_ERR_INVALID_ARG;
+  unsigned int fast_bounds[4];
+  bool done = false, have_bounds = false;
+  { const int32_t fs = set_target_single_sync(h, d_x, d_y, n, &done, fast_bounds, &have_bounds); if (fs != NDT_OK) return fs; }
+  if (done) {
+    h->n_points = n;
+    h->has_target = true;
+    return NDT_OK;
+  }
   // a1: bounding box on the device, geometry on the host (oracle/ndt2d.py grid_geometry)
   unsigned int init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
   unsigned int* hb = (unsigned int*)h->h_small;
-  std::memcpy(hb, init, sizeof(init));
-  HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, sizeof(init), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > kBoundsBlocks ? kBoundsBlocks : stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, sizeof(init), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (have_bounds) {                                      // the single-sync attempt measured the box already
+    std::memcpy(hb, fast_bounds, sizeof(init));
+  } else {
+    std::memcpy(hb, init, sizeof(init));
+    HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > kBoundsBlocks ? kBoundsBlocks : stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, sizeof(init), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   if (hb[0] == 0xFFFFFFFFu || hb[1] == 0u) { set_error("target has no finite point"); return NDT_ERR_INVALID_ARG; }
   const int32_t gs = setup_geometry(h, ordered_to_float(hb[0]), ordered_to_float(hb[1]), ordered_to_float(hb[2]),
                                     ordered_to_float(hb[3]));
@@ -315,6 +411,7 @@ int32_t upload_static(ndt2d_handle* h) {
   p.step_scale = h->prm.step_scale > 0.0 ? h->prm.step_scale : 1.0;
   HIP_TRY(hipMemcpyAsync(h->d_static, c, sizeof(AlignStatic), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipEventRecord(h->upload_ev, h->stream));
+  h->static_on_device = true;
   return NDT_OK;
 }
 
@@ -738,10 +835,10 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   if (h->h_xcd_flag) (void)hipHostFree(h->h_xcd_flag);
   if (h->d_xcd) (void)hipFree(h->d_xcd);
   if (h->d_xcd_state) (void)hipFree(h->d_xcd_state);
-  void* dev[] = {h->d_dyn_multi, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
+  void* dev[] = {h->d_geom, h->d_dyn_multi, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
                  h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag};
+  void* host[] = {h->h_geom, h->h_static, h->h_state, h->h_small, h->h_flag};
   for (void* p : host) if (p) (void)hipHostFree(p);
   if (h->upload_ev) (void)hipEventDestroy(h->upload_ev);
   if (h->wait_ev) (void)hipEventDestroy(h->wait_ev);
@@ -764,6 +861,7 @@ int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value) {
     case NDT_TUNE_BINNED_BUILD: h->use_binned_build = value != 0; return NDT_OK;
     case NDT_TUNE_TEAM_KERNEL: h->use_xcd = value != 0; return NDT_OK;
     case NDT_TUNE_SPLIT_FROM: if (value < 1 || value > 1000) return NDT_ERR_INVALID_ARG; h->split_from = (int)value; return NDT_OK;
+    case NDT_TUNE_SINGLE_SYNC_BUILD: h->one_round_trip = value != 0; return NDT_OK;
     default: return NDT_ERR_INVALID_ARG;
   }
 }

@@ -23,6 +23,67 @@ struct BinGeom {
   int W, H, ntx, ntile;
 };
 
+// Geometry decided on the device (k_geometry below): the build kernels of one ndt2d_set_target call are then
+// enqueued without waiting for the bounding box to reach the host.  ok = 0: the geometry does not fit the
+// handle's storage or the launch bounds the host chose - every kernel that is given this struct returns at
+// once and the host, which reads it back with the results, repeats the build the slow way.
+struct GeomDev {
+  BinGeom bin;
+  int ok;
+  unsigned int bounds[4];     // the ordered-float bounding box (k_bounds accumulates here), for the host
+  int counters[2];            // valid cells, overflowed cells (k_tile_accumulate)
+  unsigned long long n_outside;
+};
+
+// start of a single-sync build: everything the kernels accumulate into, in one launch instead of four memsets
+__global__ __launch_bounds__(1024) void k_build_init(GeomDev* __restrict__ geom, unsigned int* __restrict__ tile_total, int tile_bound) {
+  for (int t = threadIdx.x; t < tile_bound; t += 1024) tile_total[t] = 0u;
+  if (threadIdx.x == 0) {
+    geom->ok = 0;
+    geom->bounds[0] = 0xFFFFFFFFu; geom->bounds[1] = 0u; geom->bounds[2] = 0xFFFFFFFFu; geom->bounds[3] = 0u;
+    geom->counters[0] = 0; geom->counters[1] = 0;
+    geom->n_outside = 0ull;
+  }
+}
+
+// a1 on the device: oracle/ndt2d.py grid_geometry, the arithmetic of setup_geometry() on the host (the host
+// recomputes it from the same bounds afterwards and compares).  One thread.
+__global__ void k_geometry(double c, unsigned long long cell_capacity, int tile_bound, GridDev* __restrict__ grid,
+                           GeomDev* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned int* bounds = out->bounds;
+  GeomDev o = *out;
+  if (!(bounds[0] == 0xFFFFFFFFu || bounds[1] == 0u)) {       // at least one finite point
+    const float xmin = ordered_to_float(bounds[0]), xmax = ordered_to_float(bounds[1]);
+    const float ymin = ordered_to_float(bounds[2]), ymax = ordered_to_float(bounds[3]);
+    const float inv_c = (float)(1.0 / c);
+    const double bx = floor((double)xmin / c), by = floor((double)ymin / c);
+    const float ox = (float)((bx - 1.0) * c), oy = (float)((by - 1.0) * c);
+    const float fx = (xmax - ox) * inv_c, fy = (ymax - oy) * inv_c;
+    const double kx = floor((double)fx), ky = floor((double)fy);
+    if (kx >= 0.0 && ky >= 0.0 && (kx + 2.0) * (ky + 2.0) <= (double)cell_capacity) {
+      const int W = (int)kx + 2, H = (int)ky + 2;
+      const int ntx = (W + kTile - 1) >> kTileShift, nty = (H + kTile - 1) >> kTileShift;
+      if ((long long)ntx * nty <= (long long)tile_bound) {
+        o.bin.ox = ox; o.bin.oy = oy; o.bin.inv_c = inv_c; o.bin.W = W; o.bin.H = H; o.bin.ntx = ntx; o.bin.ntile = ntx * nty;
+        o.ok = 1;
+        grid->ox = ox; grid->oy = oy; grid->inv_c = inv_c; grid->cell32 = (float)c;
+        grid->W = W; grid->H = H; grid->ngrid = 1; grid->pad = 0;
+        const double sh[4][2] = {{0.0, 0.0}, {0.5, 0.0}, {0.0, 0.5}, {0.5, 0.5}};
+#pragma unroll
+        for (int q = 0; q < kMaxGrids; ++q) {
+          grid->gx[q] = (float)((bx - 1.0 - sh[q][0]) * c);
+          grid->gy[q] = (float)((by - 1.0 - sh[q][1]) * c);
+        }
+        grid->cell = c;
+        grid->fix_scale = 4194304.0 / c;
+        static_assert(kFixShift == 22, "fix_scale literal");
+      }
+    }
+  }
+  *out = o;
+}
+
 __device__ __forceinline__ int tile_of(const BinGeom& g, float px, float py) {
   const float fx = (px - g.ox) * g.inv_c, fy = (py - g.oy) * g.inv_c;
   const bool in = in_interior(fx, fy, g.W, g.H);      // ring cells stay empty (ndt2d_kernels.hpp)
@@ -32,8 +93,10 @@ __device__ __forceinline__ int tile_of(const BinGeom& g, float px, float py) {
 // P1: per-tile totals.  LDS histogram per workgroup, one global atomic per touched tile.
 __global__ __launch_bounds__(kBinThreads) void k_tile_count(const float* __restrict__ x, const float* __restrict__ y,
                                                              size_t n, BinGeom g, unsigned int* __restrict__ tile_total,
-                                                             unsigned long long* __restrict__ n_outside) {
+                                                             unsigned long long* __restrict__ n_outside,
+                                                             const GeomDev* __restrict__ dg /* null: g is valid */) {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_hist[];
+  if (dg) { if (!dg->ok) return; g = dg->bin; }           // uniform
   for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) s_hist[t] = 0u;
   __syncthreads();
   unsigned int outside = 0;
@@ -65,8 +128,10 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_count(const float* __restr
 // exclusive scan of the tile totals (one workgroup; ntile <= kBinMaxTiles)
 __global__ __launch_bounds__(1024) void k_tile_scan(const unsigned int* __restrict__ tile_total,
                                                      unsigned int* __restrict__ tile_start,
-                                                     unsigned int* __restrict__ tile_cursor, int ntile) {
+                                                     unsigned int* __restrict__ tile_cursor, int ntile,
+                                                     const GeomDev* __restrict__ dg) {
   __shared__ unsigned int s_wave[16];
+  if (dg) { if (!dg->ok) return; ntile = dg->bin.ntile; }
   const int per = (ntile + 1023) / 1024;
   const int t0 = threadIdx.x * per;
   unsigned int local = 0;
@@ -97,8 +162,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const unsigned int* __restri
 // the workgroup's range in the tile from one global atomic per touched tile.
 __global__ __launch_bounds__(kBinThreads) void k_tile_scatter(const float* __restrict__ x, const float* __restrict__ y,
                                                                size_t n, BinGeom g, unsigned int* __restrict__ tile_cursor,
-                                                               float* __restrict__ bx, float* __restrict__ by) {
+                                                               float* __restrict__ bx, float* __restrict__ by,
+                                                               const GeomDev* __restrict__ dg) {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_mem[];
+  if (dg) { if (!dg->ok) return; g = dg->bin; }
   unsigned int* s_hist = s_mem;
   unsigned int* s_base = s_mem + g.ntile;
   const size_t chunk = (size_t)kBinThreads * kBinPerThread;
@@ -142,10 +209,20 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_scatter(const float* __res
 __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate(const float* __restrict__ bx, const float* __restrict__ by,
                                                                   const unsigned int* __restrict__ tile_start, GridDev g,
                                                                   int q, int ntx, int merge, int min_points,
-                                                                  double eig_ratio, int* __restrict__ counters) {
+                                                                  double eig_ratio, int* __restrict__ counters,
+                                                                  const GeomDev* __restrict__ dg,
+                                                                  const GridDev* __restrict__ dgrid) {
   __shared__ unsigned int s_n[kTileCells];
   __shared__ unsigned long long s_sum[5][kTileCells];
   const int tile = blockIdx.x;
+  if (dg) {       // geometry from the device (the launch covers the host's bound on the number of tiles); storage from g
+    if (!dg->ok || tile >= dg->bin.ntile) return;
+    ntx = dg->bin.ntx;
+    float4* rec = g.rec;
+    CellAcc* acc = g.acc;
+    g = *dgrid;
+    g.rec = rec; g.acc = acc;
+  }
   const int tx0 = (tile % ntx) << kTileShift, ty0 = (tile / ntx) << kTileShift;
   const size_t gbase = (size_t)q * g.W * g.H;
   const float ox = g.gx[q], oy = g.gy[q];

@@ -94,7 +94,7 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
     HIP_TRY(hipMemsetAsync(d_total, 0, ntile * sizeof(unsigned int), h->stream));
     hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
                        dz, n, bg, d_total, h->d_outside);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, (const GeomDev*)nullptr);
     hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
                        dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2]);
     hipLaunchKernelGGL(k_tile_accumulate3, dim3(ntile), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1], h->d_b[2],

@@ -222,6 +222,10 @@ int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const fl
  *   NDT_TUNE_SPLIT_FROM         multi-start / multi-scan calls of at least this many starts run two kernels per
  *                               iteration (one workgroup per start solves, then everybody evaluates) instead of
  *                               the fused kernel whose every workgroup repeats its starts' solves (default 12)
+ *   NDT_TUNE_SINGLE_SYNC_BUILD  1 (default): ndt2d_set_target on a handle that already holds a grid decides the new grid's
+ *                               geometry on the device and enqueues the whole build at once (one host round trip;
+ *                               it falls back by itself when the new grid does not fit the cached storage).
+ *                               0: bounding box to the host first, then the build (two round trips)
  *   NDT_TUNE_BATCH_SMALL_VARIANT (batch contexts) 1 (default): lidar-sized pairs run on the 256-thread
  *                               variant of the batch kernel first; 0: every pair on the 1024-thread one */
 enum {
@@ -232,7 +236,8 @@ enum {
   NDT_TUNE_BINNED_BUILD = 5,
   NDT_TUNE_BATCH_SMALL_VARIANT = 6,
   NDT_TUNE_TEAM_KERNEL = 7,
-  NDT_TUNE_SPLIT_FROM = 8
+  NDT_TUNE_SPLIT_FROM = 8,
+  NDT_TUNE_SINGLE_SYNC_BUILD = 9
 };
 int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value);
 /* Diagnostic: calls on this handle whose team kernel could not assemble its 32-workgroup teams (the GPU

@@ -1,0 +1,87 @@
+"""ndt2d_set_target with one host round trip (geometry decided on the device, NDT_TUNE_SINGLE_SYNC_BUILD) against
+the two-round-trip build: same grid bit for bit, same alignment, automatic fallback when the new grid does not
+fit the cached storage."""
+import time
+
+import numpy as np
+import pytest
+
+from gtsam_ndt_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid_state(m):
+    info = m.grid_info()
+    count, mean, icov = m.grid()
+    return (info.ox, info.oy, info.width, info.height, info.n_valid), count, mean, icov
+
+
+def _equal(a, b):
+    assert a[0] == b[0]
+    for u, v in zip(a[1:], b[1:]):
+        np.testing.assert_array_equal(u, v)
+
+
+def test_single_sync_build_equals_two_round_trips(gpu_lib):
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    a = synth.make_pair(2, n_tgt=60000, n_src=20000)
+    b = synth.make_pair(4, pair_index=3, n_tgt=50000, n_src=20000)        # another room, same extent class
+    shift = lambda d, dx, dy: (d["tx"] + np.float32(dx), d["ty"] + np.float32(dy))
+    targets = [(a["tx"], a["ty"]), (b["tx"], b["ty"]), shift(a, 3.3, -1.7), (a["tx"][:5000], a["ty"][:5000])]
+    with NdtMatcher2D() as fast, NdtMatcher2D(tuning={"single_sync_build": 0}) as slow:
+        for k, (x, y) in enumerate(targets * 2):          # the first build of `fast` has no cached storage: usual path
+            fast.set_target(x, y)
+            slow.set_target(x, y)
+            _equal(_grid_state(fast), _grid_state(slow))
+            src = a if k % 4 != 1 else b
+            rf = fast.align(src["sx"], src["sy"], src["init"])
+            rs = slow.align(src["sx"], src["sy"], src["init"])
+            assert rf.pose == rs.pose and rf.iterations == rs.iterations and np.array_equal(rf.H, rs.H)
+        # the incremental update after a single-sync build works on the host's copy of the geometry
+        fast.set_target(a["tx"][:30000], a["ty"][:30000]); slow.set_target(a["tx"][:30000], a["ty"][:30000])
+        assert fast.add_target_points(a["tx"][30000:], a["ty"][30000:]) == slow.add_target_points(a["tx"][30000:], a["ty"][30000:])
+        _equal(_grid_state(fast), _grid_state(slow))
+
+
+def test_single_sync_build_falls_back_when_the_grid_outgrows_the_storage(gpu_lib):
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    from oracle import ndt2d as o
+    small = synth.make_pair(1)                             # 8 m room: 20 x 20 cells
+    big = synth.make_pair(2, n_tgt=80000, n_src=20000)     # 50 m room: 104 x 104 cells
+    with NdtMatcher2D() as m:
+        m.set_target(small["tx"], small["ty"])
+        info = m.set_target(big["tx"], big["ty"])           # does not fit: the device says so, the host rebuilds
+        g = o.build_grid(big["tx"], big["ty"], o.NdtParams())
+        assert (info.width, info.height, info.n_valid) == (g.W, g.H, g.n_valid)
+        count, _, _ = m.grid()
+        np.testing.assert_array_equal(count.astype(np.int64), g.count)
+        r = m.align(big["sx"], big["sy"], big["init"])
+        assert r.status == 0
+        info = m.set_target(small["tx"], small["ty"])       # and back: fits, single sync
+        gs = o.build_grid(small["tx"], small["ty"], o.NdtParams())
+        assert (info.width, info.height, info.n_valid) == (gs.W, gs.H, gs.n_valid)
+        # a target without a finite point is still refused, and the cached state survives the refusal as before
+        with pytest.raises(RuntimeError):
+            m.set_target(np.full(10, np.nan, np.float32), np.full(10, np.nan, np.float32))
+        info = m.set_target(big["tx"], big["ty"])
+        assert (info.width, info.height, info.n_valid) == (g.W, g.H, g.n_valid)
+
+
+def test_single_sync_build_time_1m_points(gpu_lib):
+    """Informational: host call to grid ready, 1M-point config-3 submap (printed with -s)."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(3, n_src=1000)
+    tx, ty = (torch.from_numpy(d[k]).cuda() for k in ("tx", "ty"))
+    torch.cuda.synchronize()
+    out = {}
+    for name, tune in (("single_sync", 1), ("two_round_trips", 0)):
+        with NdtMatcher2D(tuning={"single_sync_build": tune}) as m:
+            ts = []
+            for _ in range(12):
+                t0 = time.perf_counter(); info = m.set_target(tx, ty); ts.append(time.perf_counter() - t0)
+            out[name] = (1e3 * float(np.median(ts[2:])), info.n_valid)
+    print("set_target, 1M points, ms:", out)
+    assert out["single_sync"][1] == out["two_round_trips"][1]
+    assert out["single_sync"][0] < 1.15 * out["two_round_trips"][0]
