@@ -145,7 +145,8 @@ __device__ __forceinline__ void write_result3(Result3Dev* o, const double* pose,
 // and the contraction with A happens once per iteration on the reduced sums, in float64
 // (map_sums_to_pose_frame).  Newton mode: - d2 w (J'v)(J'v)' with J'v = (v ; A'u), u = y x v, lands on the
 // same three sums, and the second-derivative term uses M' = sum w v y' = M R'.
-// acc: Htt(6) P(9) S(6) g_t(3) n(3) score n_hit [M'(9)].  y must be zero (not NaN) for a point outside the grid.
+// acc: Htt(6) P(9) S(6) g_t(3) n(3) score n_hit [M'(9)].  y and p' must be finite; a point outside the grid comes with
+// the all-zero record.
 template <int MODE>
 __device__ __forceinline__ void accumulate_point3_map(float yx, float yy, float yz, float px, float py, float pz, bool in,
                                                       const float4& A4, const float4& B4, const float2& C2, float d1,
@@ -561,15 +562,20 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
         float2 C2[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          yx[u] = fmaf(T.R[0], x[u], fmaf(T.R[1], y[u], T.R[2] * z[u]));
-          yy[u] = fmaf(T.R[3], x[u], fmaf(T.R[4], y[u], T.R[5] * z[u]));
-          yz[u] = fmaf(T.R[6], x[u], fmaf(T.R[7], y[u], T.R[8] * z[u]));
+          // NaN / inf (no-return points) never reach the sums: coordinates are clamped to +-1e15 first (v_med3_f32
+          // returns the finite bound for a NaN), the image then lies outside the grid and reads the all-zero record
+          // 0, against which every product below is a finite number times zero
+          const float cx = __builtin_amdgcn_fmed3f(x[u], -1e15f, 1e15f), cy = __builtin_amdgcn_fmed3f(y[u], -1e15f, 1e15f),
+                      cz = __builtin_amdgcn_fmed3f(z[u], -1e15f, 1e15f);
+          yx[u] = fmaf(T.R[0], cx, fmaf(T.R[1], cy, T.R[2] * cz));
+          yy[u] = fmaf(T.R[3], cx, fmaf(T.R[4], cy, T.R[5] * cz));
+          yz[u] = fmaf(T.R[6], cx, fmaf(T.R[7], cy, T.R[8] * cz));
           px[u] = yx[u] + T.tx; py[u] = yy[u] + T.ty; pz[u] = yz[u] + T.tz;
           const float fx = (px[u] - ox) * inv_c, fy = (py[u] - oy) * inv_c, fz = (pz[u] - oz) * inv_c;
           in[u] = ((base + u * kB3Threads) < ns) & (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
           const int key = in[u] ? (((int)fz * Hh + (int)fy) * W + (int)fx) : 0;
           int slot = (int)idx[key];
-          if (!in[u]) { yx[u] = yy[u] = yz[u] = 0.f; slot = 0; }   // a NaN point must not reach the sums through 0 * NaN
+          if (!in[u]) slot = 0;
           A4[u] = recA[slot]; B4[u] = recB[slot]; C2[u] = recC[slot];
         }
 #pragma unroll

@@ -91,10 +91,10 @@ def test_random_clouds_build_and_evaluate_like_the_oracle(gpu_lib):
 def test_random_clouds_3d(gpu_lib):
     """The 3D build (binned tiles, Jacobi finalise) and evaluation on random clustered clouds."""
     from gtsam_ndt_amd import _lib as L
-    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    from gtsam_ndt_amd.matcher import NdtBatch3D, NdtMatcher3D
     from oracle import ndt3d as o3
     rng = np.random.default_rng(77)
-    checked = 0
+    checked = n_batch = 0
     for i in range(24):
         centre = rng.uniform(-300, 300, 3) if i % 2 else rng.uniform(-3, 3, 3)
         spread = float(rng.uniform(1.0, 15.0))
@@ -134,8 +134,29 @@ def test_random_clouds_3d(gpu_lib):
                 hs = max(np.abs(Hm).max(), 1e-30)
                 assert np.abs(H - Hm).max() / hs < 2e-3, (i, kw)
                 assert abs(s - sm) <= 2e-3 * max(sm, 1e-6)
+            # the 3D batch kernel (voxel grid in LDS, or in global memory when the grid outgrows the carve) evaluates the same
+            # pair at the same pose - map-frame sums against the single-pair kernel's Jacobian form - with NaN-laced copies
+            # of the clouds: no-return points must change nothing
+            def laced(c, every):
+                out = []
+                for a in c:
+                    b = np.concatenate([a, np.full(max(1, a.size // every), np.nan, np.float32)])
+                    out.append(b)
+                out[1][-1] = np.inf
+                return tuple(out)
+            with NdtBatch3D(fixed_iterations=1, **kw) as b:
+                rb, rl = b.align([(tx, ty, tz), laced((tx, ty, tz), 9)], [(sx, sy, sz), laced((sx, sy, sz), 7)], [pose, pose])
+            assert rb.status == rl.status and rb.n_hit == rl.n_hit and rb.pose == rl.pose and np.array_equal(rb.H, rl.H), i
+            if rb.status in (L.NDT_OK, L.NDT_NOT_CONVERGED):
+                assert rb.n_hit == nh, (i, rb.n_hit, nh)
+                hs = max(np.abs(H).max(), 1e-30)
+                assert np.abs(rb.H - H).max() / hs < 2e-4, (i, kw)
+                assert abs(rb.score - s) <= 1e-4 * max(s, 1e-6)
+                n_batch += 1
+            else:
+                assert rb.status in (L.NDT_TOO_FEW_HITS, L.NDT_DEGENERATE_HESSIAN), (i, rb.status)
             checked += 1
-    assert checked >= 12
+    assert checked >= 12 and n_batch >= 8
 
 
 def test_random_clouds_three_iterations_batch_vs_single_pair(gpu_lib):
