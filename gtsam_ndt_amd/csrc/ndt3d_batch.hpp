@@ -5,8 +5,8 @@
 //     table takes 2 bytes per voxel, the records get the rest (config 5: 44 x 44 x 9 = 17 424
 //     voxels, 2 706 occupied: 35 KB + 108 KB of the 160 KB);
 //   - the nine exact fixed-point sums of a voxel (72 bytes per slot) do not fit next to the table,
-//     so the build adds them up in LDS three at a time (three passes over the target, which is
-//     L2-resident after the first) and parks each pass in a per-workgroup slab of global memory;
+//     so the build adds them up in LDS five and four at a time (the records' 40 bytes per slot hold
+//     five; two passes over the target) and parks each pass in a per-workgroup slab of global memory;
 //     the finalise reads them back once and writes the records into LDS;
 //   - source points stream from HBM/L2 once per iteration; the 29 (Newton: 38) sums are reduced
 //     per wave (DPP) -> LDS -> wave 0, which also does the 6x6 solve: two workgroup barriers per
@@ -370,7 +370,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   const int rec_base = (kB3Idx + 2 * ncell + 15) & ~15;
   const int slot_cap = GLOBAL ? kG3MaxSlots : (kB3LdsBytes - rec_base) / kB3RecBytes;      // records incl. the dummy record 0
   unsigned int* cnt = GLOBAL ? reinterpret_cast<unsigned int*>(slab + kG3Idx) : reinterpret_cast<unsigned int*>(smem + rec_base);
-  unsigned long long* psum = reinterpret_cast<unsigned long long*>(smem + rec_base);      // on-chip build: u64 [3][nslot]
+  unsigned long long* psum = reinterpret_cast<unsigned long long*>(smem + rec_base);      // on-chip build: u64 [5][nslot]
   float4* recA = GLOBAL ? reinterpret_cast<float4*>(slab + kG3RecA) : reinterpret_cast<float4*>(smem + rec_base);
   float4* recB = GLOBAL ? reinterpret_cast<float4*>(slab + kG3RecB) : reinterpret_cast<float4*>(smem + rec_base + 16 * slot_cap);
   float2* recC = GLOBAL ? reinterpret_cast<float2*>(slab + kG3RecC) : reinterpret_cast<float2*>(smem + rec_base + 32 * slot_cap);
@@ -450,10 +450,12 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     });
     __syncthreads();
   } else {
-    // ---- a2 (2/2): exact fixed-point sums per slot, three of the nine per pass (LDS 64-bit integer atomics)
+    // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics).  The records' region holds 40 B per
+    // slot = five 64-bit sums: s[0..2], ss[0..1] in the first pass over the target, ss[2..5] in the second
 #pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
-      for (int j = tid; j < 3 * nslot; j += kB3Threads) psum[j] = 0ull;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int nsum = pass == 0 ? 5 : 4;
+      for (int j = tid; j < nsum * nslot; j += kB3Threads) psum[j] = 0ull;
       __syncthreads();
       for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
         int ix, iy, iz;
@@ -464,25 +466,24 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
             const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
             const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
             unsigned long long* q = psum + (slot - 1);
-            if (pass == 0) {          // s[0..2]
+            if (pass == 0) {          // s[0..2], ss[0..1] = xx xy
               atomicAdd(q, (unsigned long long)(long long)ux);
               atomicAdd(q + nslot, (unsigned long long)(long long)uy);
               atomicAdd(q + 2 * nslot, (unsigned long long)(long long)uz);
-            } else if (pass == 1) {   // ss[0..2] = xx xy xz
-              atomicAdd(q, prod64(ux, ux));
-              atomicAdd(q + nslot, prod64(ux, uy));
-              atomicAdd(q + 2 * nslot, prod64(ux, uz));
-            } else {                  // ss[3..5] = yy yz zz
-              atomicAdd(q, prod64(uy, uy));
-              atomicAdd(q + nslot, prod64(uy, uz));
-              atomicAdd(q + 2 * nslot, prod64(uz, uz));
+              atomicAdd(q + 3 * nslot, prod64(ux, ux));
+              atomicAdd(q + 4 * nslot, prod64(ux, uy));
+            } else {                  // ss[2..5] = xz yy yz zz
+              atomicAdd(q, prod64(ux, uz));
+              atomicAdd(q + nslot, prod64(uy, uy));
+              atomicAdd(q + 2 * nslot, prod64(uy, uz));
+              atomicAdd(q + 3 * nslot, prod64(uz, uz));
             }
           }
         }
       });
       __syncthreads();
-      for (int j = tid; j < 3 * nslot; j += kB3Threads)
-        gsums[(size_t)(3 * pass + j / nslot) * kS + (j % nslot)] = psum[j];
+      for (int j = tid; j < nsum * nslot; j += kB3Threads)
+        gsums[(size_t)(5 * pass + j / nslot) * kS + (j % nslot)] = psum[j];
       __syncthreads();
     }
   }

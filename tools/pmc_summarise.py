@@ -71,6 +71,7 @@ def traffic(kernel_prefix):
 it = traffic("k_iterate<")
 ba = traffic("BatchCfg<1024")          # the 1024-thread variant does the config-4 pairs; the 256-thread pre-pass only marks them
 i3 = traffic("k_iterate3")
+b3 = traffic("k_batch3<")              # the 3D loop-closure batch (256 config-5-sized pairs per launch in bench.py)
 summary = {
     "source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes "
               "(--kernel-trace only) of `bench.py --no-cpu-baseline --headline-only --steps 10 --warmup 2` on one MI355X",
@@ -89,6 +90,9 @@ if i3:
 if ba:
     summary["k_batch"] = dict(ba, pairs=512)
     summary["batch_bytes_per_launch"] = ba["read_bytes"] + ba["write_bytes"]
+if b3:
+    summary["k_batch3"] = dict(b3, pairs=256, algorithmic_bytes=256 * 131072 * 12 * 31)
+    summary["batch3_bytes_per_launch"] = b3["read_bytes"] + b3["write_bytes"]
 with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
     json.dump(summary, f, indent=1)
 
