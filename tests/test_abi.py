@@ -78,6 +78,12 @@ def test_matcher_raises_without_device(ndt_lib):
     with pytest.raises(_lib.NdtError) as e:
         NdtMatcher2D()
     assert e.value.code == _lib.NDT_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+    # every context type: the batch, multi-device, 3D and 3D-batch entry points fail the same way
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtBatch3D, NdtMatcher3D, NdtMulti2D
+    for make in (NdtBatch2D, NdtBatch3D, NdtMatcher3D, lambda: NdtMulti2D(devices=[0])):
+        with pytest.raises(_lib.NdtError) as e:
+            make()
+        assert e.value.code == _lib.NDT_ERR_NO_DEVICE, make
 
 
 def test_product_never_imports_the_oracle():
