@@ -119,19 +119,9 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
   return NDT_OK;
 }
 
-int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
+// Voxel-grid geometry for a bounding box (oracle/ndt3d.py grid_geometry3) and storage for its voxels.
+int32_t setup_geometry3(ndt3d_handle* h, const float lo[3], const float hi[3]) {
   using namespace ndt;
-  TraceRange range("ndt3d_set_target: voxel grid build");
-  h->has_target = false;
-  unsigned int* hb = (unsigned int*)h->h_small;
-  for (int a = 0; a < 3; ++a) { hb[2 * a] = 0xFFFFFFFFu; hb[2 * a + 1] = 0u; }
-  HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, 24, hipMemcpyHostToDevice, h->stream));
-  const int sb = stream_blocks(n) > 512 ? 512 : stream_blocks(n);
-  hipLaunchKernelGGL(k_bounds3, dim3(sb), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_bounds);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, 24, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  if (hb[0] == 0xFFFFFFFFu || hb[1] == 0u) { set_error("target has no finite point"); return NDT_ERR_INVALID_ARG; }
   const double c = h->prm.cell_size;
   Grid3Dev& g = h->grid;
   g.cell = c;
@@ -140,7 +130,7 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
   int dims[3];
   double ncell_d = 1.0;
   for (int a = 0; a < 3; ++a) {
-    const float mn = ordered_to_float(hb[2 * a]), mx = ordered_to_float(hb[2 * a + 1]);
+    const float mn = lo[a], mx = hi[a];
     o[a] = (float)((std::floor((double)mn / c) - 1.0) * c);
     const volatile float f = (mx - o[a]) * g.inv_c;
     const double k = std::floor((double)f);
@@ -162,6 +152,25 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
     HIP_TRY(hipMalloc((void**)&g.acc, want * sizeof(CellAcc3)));
     h->cell_capacity = want;
   }
+  return NDT_OK;
+}
+
+int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
+  using namespace ndt;
+  TraceRange range("ndt3d_set_target: voxel grid build");
+  h->has_target = false;
+  unsigned int* hb = (unsigned int*)h->h_small;
+  for (int a = 0; a < 3; ++a) { hb[2 * a] = 0xFFFFFFFFu; hb[2 * a + 1] = 0u; }
+  HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, 24, hipMemcpyHostToDevice, h->stream));
+  const int sb = stream_blocks(n) > 512 ? 512 : stream_blocks(n);
+  hipLaunchKernelGGL(k_bounds3, dim3(sb), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_bounds);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, 24, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (hb[0] == 0xFFFFFFFFu || hb[1] == 0u) { set_error("target has no finite point"); return NDT_ERR_INVALID_ARG; }
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) { lo[a] = ordered_to_float(hb[2 * a]); hi[a] = ordered_to_float(hb[2 * a + 1]); }
+  { const int32_t gs = setup_geometry3(h, lo, hi); if (gs != NDT_OK) return gs; }
   const int32_t as = accumulate3(h, dx, dy, dz, n, /*merge=*/false, nullptr);
   if (as != NDT_OK) return as;
   h->has_target = true;
@@ -331,6 +340,56 @@ int32_t ndt3d_add_target_points(ndt3d_handle* h, const float* x, const float* y,
   if (n_outside) *n_outside = (size_t)outside;
   if (fs != NDT_OK) { h->has_target = false; return fs; }
   return NDT_OK;          // geometry, storage and parameters are unchanged: the device context stays as it is
+}
+
+int32_t ndt3d_reserve_target(ndt3d_handle* h, const double lo[3], const double hi[3]) {
+  if (!h || !lo || !hi) return NDT_ERR_INVALID_ARG;
+  float l[3], u[3];
+  for (int a = 0; a < 3; ++a) {
+    if (!(lo[a] <= hi[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a])) return NDT_ERR_INVALID_ARG;
+    l[a] = (float)lo[a]; u[a] = (float)hi[a];
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
+  h->has_target = false;
+  { const int32_t gs = setup_geometry3(h, l, u); if (gs != NDT_OK) return gs; }
+  const size_t ncell = (size_t)h->grid.W * h->grid.H * h->grid.D;
+  HIP_TRY(hipMemsetAsync(h->grid.acc, 0, ncell * sizeof(ndt::CellAcc3), h->stream));
+  HIP_TRY(hipMemsetAsync(h->grid.rec, 0, 4 * ncell * sizeof(float4), h->stream));
+  h->n_valid = 0;
+  h->has_target = true;
+  return upload_static3(h);
+}
+
+int32_t ndt3d_add_target_points_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n,
+                                    const double pose[6], size_t* n_outside, void* stream) {
+  if (!h || !d_x || !d_y || !d_z || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
+  if (stream) HIP_TRY(ndt::order_after(h->stream, (hipStream_t)stream));
+  const float* p[3] = {d_x, d_y, d_z};
+  if (pose) {
+    const int32_t st = ensure3(h->d_t, &h->tcap, n);
+    if (st != NDT_OK) return st;
+    const double ca = std::cos(pose[3]), sa = std::sin(pose[3]), cb = std::cos(pose[4]), sb = std::sin(pose[4]),
+                 cg = std::cos(pose[5]), sg = std::sin(pose[5]);
+    const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
+                         sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
+                         -sb, cb * sa, cb * ca};
+    ndt::Rigid3F T;
+    for (int j = 0; j < 9; ++j) T.r[j] = (float)R[j];
+    for (int j = 0; j < 3; ++j) T.t[j] = (float)pose[j];
+    hipLaunchKernelGGL(ndt::k_transform_points3, dim3((unsigned)((n + ndt::kBlock - 1) / ndt::kBlock)), dim3(ndt::kBlock), 0, h->stream,
+                       d_x, d_y, d_z, n, T, h->d_t[0], h->d_t[1], h->d_t[2]);
+    HIP_TRY(hipGetLastError());
+    for (int a = 0; a < 3; ++a) p[a] = h->d_t[a];
+  }
+  unsigned long long outside = 0;
+  const int32_t fs = accumulate3(h, p[0], p[1], p[2], n, /*merge=*/true, &outside);
+  if (n_outside) *n_outside = (size_t)outside;
+  if (fs != NDT_OK) { h->has_target = false; return fs; }
+  return NDT_OK;
 }
 
 int32_t ndt3d_set_target_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n, void* stream) {

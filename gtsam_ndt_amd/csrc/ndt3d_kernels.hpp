@@ -70,6 +70,27 @@ struct AlignDyn3 {
   LineSearch3 ls[2];
 };
 
+// A 3D scan moved into the map frame with the pose an alignment returned, before it is merged into the voxel
+// grid (ndt3d_add_target_points_dev): R = Rz Ry Rx formed in float64 and rounded to float32 by the host,
+// p' = ((r0 x + r1 y) + r2 z) + t per row with every float32 operation rounded separately (no contraction),
+// so that a host restatement reproduces the points bit for bit.
+struct Rigid3F { float r[9]; float t[3]; };
+__global__ __launch_bounds__(kBlock) void k_transform_points3(const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ z, size_t n, Rigid3F T,
+                                                               float* __restrict__ ox, float* __restrict__ oy,
+                                                               float* __restrict__ oz) {
+#pragma clang fp contract(off)
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[i], py = y[i], pz = z[i];
+  float* out[3] = {ox, oy, oz};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float a = T.r[3 * r] * px, b = T.r[3 * r + 1] * py, c = T.r[3 * r + 2] * pz;
+    out[r][i] = ((a + b) + c) + T.t[r];
+  }
+}
+
 // ---------------------------------------------------------------------------- bounds
 __global__ __launch_bounds__(kBlock) void k_bounds3(const float* __restrict__ x, const float* __restrict__ y,
                                                      const float* __restrict__ z, size_t n,

@@ -571,10 +571,28 @@ class NdtMatcher3D:
                 "ndt3d_set_target")
         return self.grid_info()
 
-    def add_target_points(self, x, y, z) -> int:
-        """Merge more points into the cached voxel grid; returns how many fell outside its extent."""
-        x, y, z = _host_f32(x), _host_f32(y), _host_f32(z)
+    def reserve_target(self, lo, hi):
+        """Empty voxel grid over the box lo .. hi (x, y, z); fill it with add_target_points()."""
+        a = (C.c_double * 3)(*[float(v) for v in lo])
+        b = (C.c_double * 3)(*[float(v) for v in hi])
+        L.check(self._lib.ndt3d_reserve_target(self._h, a, b), "ndt3d_reserve_target")
+        return self.grid_info()
+
+    def add_target_points(self, x, y, z, pose=None) -> int:
+        """Merge more points into the cached voxel grid; returns how many fell outside its extent.
+        Device tensors may carry a pose (tx, ty, tz, roll, pitch, yaw) that moves them into the map frame first."""
         out = C.c_size_t(0)
+        if _is_dev(x):
+            import torch
+            n = x.numel()
+            p = (C.c_double * 6)(*[float(v) for v in pose]) if pose is not None else None
+            L.check(self._lib.ndt3d_add_target_points_dev(self._h, _dev_ptr(x, n), _dev_ptr(y, n), _dev_ptr(z, n), n, p,
+                                                          C.byref(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "ndt3d_add_target_points_dev")
+            return int(out.value)
+        if pose is not None:
+            raise ValueError("pose is applied on the device: pass device tensors")
+        x, y, z = _host_f32(x), _host_f32(y), _host_f32(z)
         L.check(self._lib.ndt3d_add_target_points(self._h, x.ctypes.data, y.ctypes.data, z.ctypes.data, x.size,
                                                   C.byref(out)), "ndt3d_add_target_points")
         return int(out.value)

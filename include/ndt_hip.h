@@ -404,6 +404,16 @@ int32_t ndt3d_set_target(ndt3d_handle* h, const float* x, const float* y, const 
  * grid's exact sums and re-finalises; points outside the cached extent are counted and ignored. */
 int32_t ndt3d_add_target_points(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n,
                                 size_t* n_outside);
+/* Empty voxel grid over a chosen extent (lo / hi = min / max corner, x y z), to be filled with
+ * ndt3d_add_target_points(_dev): a submap that grows scan by scan, as ndt2d_reserve_target. */
+int32_t ndt3d_reserve_target(ndt3d_handle* h, const double lo[3], const double hi[3]);
+/* ndt3d_add_target_points with the points already on the device, optionally moved into the map frame first:
+ * pose != NULL applies p' = R p + t in float32 (R = Rz(yaw) Ry(pitch) Rx(roll) formed in float64 and rounded to
+ * float32; each row ((r0 x + r1 y) + r2 z) + t with every operation rounded separately) - the pose an alignment
+ * of that scan returned - so a 3D scan goes align -> submap without leaving the GPU.  `stream` is the stream that
+ * produced the arrays (NULL: already complete); the call returns when the grid is updated. */
+int32_t ndt3d_add_target_points_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n,
+                                    const double pose[6], size_t* n_outside, void* stream);
 /* device arrays; `stream` = the stream that produced them (NULL: already complete) */
 int32_t ndt3d_set_target_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n,
                              void* stream);
