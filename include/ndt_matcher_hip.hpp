@@ -443,6 +443,26 @@ class NdtMatcherHip3 {
     check(ndt3d_add_target_points(h_, x, y, z, n, &outside), "ndt3d_add_target_points");
     return outside;
   }
+  // empty voxel grid over a chosen box (a submap that grows scan by scan)
+  void reserveTarget(const std::array<double, 3>& lo, const std::array<double, 3>& hi) {
+    check(ndt3d_reserve_target(h_, lo.data(), hi.data()), "ndt3d_reserve_target");
+  }
+  // device points, optionally moved into the map frame by `pose` first (the pose an alignment returned);
+  // producer_stream = the stream that wrote them (nullptr: complete)
+  size_t addTargetPointsDev(const float* d_x, const float* d_y, const float* d_z, size_t n, const Pose3* pose = nullptr,
+                            void* producer_stream = nullptr) {
+    size_t outside = 0;
+    double p[6] = {0, 0, 0, 0, 0, 0};
+    if (pose) { p[0] = pose->x; p[1] = pose->y; p[2] = pose->z; p[3] = pose->roll; p[4] = pose->pitch; p[5] = pose->yaw; }
+    check(ndt3d_add_target_points_dev(h_, d_x, d_y, d_z, n, pose ? p : nullptr, &outside, producer_stream), "ndt3d_add_target_points_dev");
+    return outside;
+  }
+  MatchResult3 alignDev(const float* d_sx, const float* d_sy, const float* d_sz, size_t n, const Pose3& guess = Pose3()) {
+    const double init[6] = {guess.x, guess.y, guess.z, guess.roll, guess.pitch, guess.yaw};
+    ndt3d_result r;
+    check(ndt3d_align_dev(h_, d_sx, d_sy, d_sz, n, init, &r), "ndt3d_align_dev");
+    return toMatchResult(r);
+  }
   ndt3d_grid_info gridInfo() const { ndt3d_grid_info g; check(ndt3d_get_grid_info(h_, &g), "ndt3d_get_grid_info"); return g; }
 
   MatchResult3 align(const float* sx, const float* sy, const float* sz, size_t n, const Pose3& guess = Pose3()) {
