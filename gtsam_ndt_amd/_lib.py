@@ -162,6 +162,8 @@ SIGNATURES = {
     "ndt3d_add_target_points": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ndt3d_set_target_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ndt3d_reserve_target": (C.c_int32, [_vp, _dp, _dp]),
+    "ndt3d_range_image_to_points_dev": (C.c_int32, [_vp, C.c_int32, C.c_int32, _dp, C.c_double, C.c_double, C.c_double,
+                                                    C.c_double, _vp, _vp, _vp, _vp]),
     "ndt3d_add_target_points_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(C.c_size_t), _vp]),
     "ndt3d_get_grid_info": (C.c_int32, [_vp, C.POINTER(GridInfo3D)]),
     "ndt3d_get_grid": (C.c_int32, [_vp, _vp, _vp, _vp]),

@@ -1,5 +1,7 @@
 // C-ABI of the 3D SE(3) variant (included at the end of ndt2d_api.hip: one translation unit).
 #pragma once
+#include <vector>
+
 #include "ndt3d_kernels.hpp"
 #include "ndt3d_build.hpp"
 
@@ -340,6 +342,24 @@ int32_t ndt3d_add_target_points(ndt3d_handle* h, const float* x, const float* y,
   if (n_outside) *n_outside = (size_t)outside;
   if (fs != NDT_OK) { h->has_target = false; return fs; }
   return NDT_OK;          // geometry, storage and parameters are unchanged: the device context stays as it is
+}
+
+int32_t ndt3d_range_image_to_points_dev(const float* d_ranges, int32_t n_elev, int32_t n_azim, const double* elevations,
+                                        double azimuth0, double azimuth_inc, double range_min, double range_max, float* d_x,
+                                        float* d_y, float* d_z, void* stream) {
+  if (!d_ranges || !elevations || !d_x || !d_y || !d_z || n_elev < 1 || n_elev > ndt::kMaxRings || n_azim < 1 ||
+      !std::isfinite(azimuth0) || !std::isfinite(azimuth_inc))
+    return NDT_ERR_INVALID_ARG;
+  ndt::RingTable rings{};
+  for (int e = 0; e < n_elev; ++e) {
+    if (!std::isfinite(elevations[e])) return NDT_ERR_INVALID_ARG;
+    rings.cs[2 * e] = std::cos(elevations[e]); rings.cs[2 * e + 1] = std::sin(elevations[e]);
+  }
+  const size_t n = (size_t)n_elev * (size_t)n_azim;
+  hipLaunchKernelGGL(ndt::k_range_image_to_points, dim3(stream_blocks(n)), dim3(ndt::kBlock), 0, (hipStream_t)stream, d_ranges,
+                     n_elev, n_azim, rings, azimuth0, azimuth_inc, (float)range_min, (float)range_max, d_x, d_y, d_z);
+  HIP_TRY(hipGetLastError());
+  return NDT_OK;
 }
 
 int32_t ndt3d_reserve_target(ndt3d_handle* h, const double lo[3], const double hi[3]) {

@@ -91,6 +91,30 @@ __global__ __launch_bounds__(kBlock) void k_transform_points3(const float* __res
   }
 }
 
+// Range image of a spinning multi-beam lidar -> Cartesian SoA (the driver side of the 3D boundary): ring e (its
+// elevation cos / sin from a table passed by value), azimuth column j at az0 + j * az_inc, one sincos per point from
+// the column index; ranges outside [range_min, range_max] or non-finite become NaN points, which every kernel ignores.
+constexpr int kMaxRings = 128;
+struct RingTable { double cs[2 * kMaxRings]; };      // cos, sin of each ring's elevation: 2 KB of kernel arguments
+__global__ __launch_bounds__(kBlock) void k_range_image_to_points(const float* __restrict__ r, int n_elev, int n_azim,
+                                                                   RingTable rings, double az0, double az_inc,
+                                                                   float range_min, float range_max,
+                                                                   float* __restrict__ x, float* __restrict__ y,
+                                                                   float* __restrict__ z) {
+  const size_t n = (size_t)n_elev * n_azim;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const int e = (int)(i / (size_t)n_azim), j = (int)(i - (size_t)e * n_azim);
+    const float ri = r[i];
+    double s, c;
+    sincos(fma((double)j, az_inc, az0), &s, &c);
+    const double ce = rings.cs[2 * e], se = rings.cs[2 * e + 1];
+    const bool ok = isfinite(ri) & (ri >= range_min) & (ri <= range_max);
+    x[i] = ok ? (float)((double)ri * (ce * c)) : NAN;
+    y[i] = ok ? (float)((double)ri * (ce * s)) : NAN;
+    z[i] = ok ? (float)((double)ri * se) : NAN;
+  }
+}
+
 // ---------------------------------------------------------------------------- bounds
 __global__ __launch_bounds__(kBlock) void k_bounds3(const float* __restrict__ x, const float* __restrict__ y,
                                                      const float* __restrict__ z, size_t n,

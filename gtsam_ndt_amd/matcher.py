@@ -787,6 +787,22 @@ def polar_to_points(ranges, angle_min: float, angle_inc: float, range_min: float
 PYRAMID_LEVELS = ((4.0, 0.1), (2.0, 0.03))
 
 
+def range_image_to_points(ranges, elevations, azimuth0: float, azimuth_inc: float, range_min: float = 0.0,
+                          range_max: float = 1e30):
+    """Range image [n_elev, n_azim] (torch CUDA float32 tensor) of a multi-beam lidar -> (x, y, z) CUDA tensors of
+    n_elev * n_azim points, on the device (ndt3d_range_image_to_points_dev)."""
+    import torch
+    n_elev, n_azim = ranges.shape
+    n = n_elev * n_azim
+    out = [torch.empty(n, dtype=torch.float32, device=ranges.device) for _ in range(3)]
+    el = (C.c_double * n_elev)(*[float(v) for v in elevations])
+    L.check(L.load().ndt3d_range_image_to_points_dev(_dev_ptr(ranges, n), n_elev, n_azim, el, float(azimuth0), float(azimuth_inc),
+                                                     float(range_min), float(range_max), _dev_ptr(out[0], n), _dev_ptr(out[1], n),
+                                                     _dev_ptr(out[2], n), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            "ndt3d_range_image_to_points_dev")
+    return tuple(out)
+
+
 class NdtPyramid2D:
     """Multi-resolution alignment: one NdtMatcher2D per level, each level started from the
     previous level's pose; the last level runs with the caller's parameters."""

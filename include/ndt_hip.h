@@ -404,6 +404,15 @@ int32_t ndt3d_set_target(ndt3d_handle* h, const float* x, const float* y, const 
  * grid's exact sums and re-finalises; points outside the cached extent are counted and ignored. */
 int32_t ndt3d_add_target_points(ndt3d_handle* h, const float* x, const float* y, const float* z, size_t n,
                                 size_t* n_outside);
+/* Range image of a spinning multi-beam lidar -> SoA Cartesian points on the device (the driver side of the 3D
+ * boundary, as ndt2d_polar_to_points_dev): d_ranges is [n_elev][n_azim] row-major, n_elev <= 128; ring e looks up
+ * at elevations[e] (host array, radians), column j at azimuth0 + j * azimuth_inc;
+ * p = r (cos e cos a, cos e sin a, sin e).  Ranges outside [range_min, range_max] or non-finite become NaN points,
+ * which every entry point of this library ignores.  d_* are device pointers; asynchronous on `stream`
+ * (NULL = default stream). */
+int32_t ndt3d_range_image_to_points_dev(const float* d_ranges, int32_t n_elev, int32_t n_azim, const double* elevations,
+                                        double azimuth0, double azimuth_inc, double range_min, double range_max, float* d_x,
+                                        float* d_y, float* d_z, void* stream);
 /* Empty voxel grid over a chosen extent (lo / hi = min / max corner, x y z), to be filled with
  * ndt3d_add_target_points(_dev): a submap that grows scan by scan, as ndt2d_reserve_target. */
 int32_t ndt3d_reserve_target(ndt3d_handle* h, const double lo[3], const double hi[3]);

@@ -95,3 +95,31 @@ def test_reserved_voxel_grid_filled_in_chunks_equals_one_shot_build(gpu_lib):
             np.testing.assert_array_equal(u, v)
         ra, rb = a.align(d["sx"], d["sy"], d["sz"], d["init"]), b.align(d["sx"], d["sy"], d["sz"], d["init"])
         assert ra.pose == rb.pose and np.array_equal(ra.H, rb.H)
+
+
+def test_range_image_to_points_kernel(gpu_lib):
+    """ndt3d_range_image_to_points_dev against the float64 direction formula of synth3d.lidar_scan, with no-return
+    cells; the converted scan aligns like the host-converted one."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtMatcher3D, range_image_to_points
+    n_elev, n_azim = 32, 1024
+    el = np.deg2rad(np.linspace(-24.0, 20.0, n_elev))
+    az0, inc = 0.5 * (2.0 * np.pi / n_azim), 2.0 * np.pi / n_azim
+    p = synth3d.lidar_scan(300, POSES[1], n_elev=n_elev, n_azim=n_azim, sigma=0.02)         # ring-major, azimuth inner
+    rng = np.linalg.norm(p, axis=1).astype(np.float32).reshape(n_elev, n_azim)
+    rng[3, 10:20] = np.nan; rng[7, 5] = 0.01; rng[9, 100] = 500.0                            # no return, too near, too far
+    x, y, z = (t.cpu().numpy() for t in range_image_to_points(torch.from_numpy(rng).cuda(), el, az0, inc, 0.05, 100.0))
+    E, A = np.meshgrid(el, az0 + inc * np.arange(n_azim), indexing="ij")
+    r64 = rng.astype(np.float64)
+    ref = np.stack([r64 * np.cos(E) * np.cos(A), r64 * np.cos(E) * np.sin(A), r64 * np.sin(E)], axis=-1).reshape(-1, 3)
+    bad = ~(np.isfinite(rng) & (rng >= 0.05) & (rng <= 100.0)).reshape(-1)
+    assert bad.sum() == 12 and np.array_equal(np.isnan(x), bad) and np.array_equal(np.isnan(z), bad)
+    got = np.stack([x, y, z], axis=1)
+    np.testing.assert_allclose(got[~bad], ref[~bad], rtol=0, atol=4e-6)
+    d = synth3d.make_pair3d(n_elev=n_elev, n_azim=n_azim, pose=POSES[1])
+    with NdtMatcher3D() as m:
+        m.set_target(d["tx"], d["ty"], d["tz"])
+        guess = tuple(np.array(POSES[1]) + np.array([0.05, -0.04, 0.01, 0.002, -0.002, 0.01]))
+        a = m.align(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(z).cuda(), guess)
+    e = np.abs(np.array(a.pose) - np.array(POSES[1]))
+    assert a.status == 0 and e[:3].max() < 0.02 and e[3:].max() < 3e-3, a.pose
