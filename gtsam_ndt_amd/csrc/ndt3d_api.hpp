@@ -512,6 +512,51 @@ int32_t ndt3d_align_finish(ndt3d_handle* h, ndt3d_result* out) {
   return NDT_OK;
 }
 
+// Per-iteration trace, as ndt2d_align_trace: one plain k_iterate3 launch and one state fetch per iteration.
+int32_t ndt3d_align_trace(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n,
+                          const double init_pose[6], ndt3d_result* rows, int32_t capacity, int32_t* n_rows, ndt3d_result* out) {
+  using namespace ndt;
+  if (!h || !sx || !sy || !sz || !init_pose || !rows || capacity < 1 || !n_rows || n == 0 || n > kMaxSourcePoints)
+    return NDT_ERR_INVALID_ARG;
+  *n_rows = 0;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  TraceRange range("ndt3d_align_trace");
+  HIP_TRY(hipSetDevice(h->device));
+  auto to_row = [](const IterState3& s, ndt3d_result* r) {
+    std::memset(r, 0, sizeof(*r));
+    for (int j = 0; j < 6; ++j) { r->pose[j] = s.pose[j]; r->g[j] = s.g[j]; }
+    unpack_h21(s.H, r->H);
+    r->score = s.score; r->iterations = s.iter; r->n_hit = s.n_hit; r->status = s.status;
+  };
+  if (h->n_valid < 1) {
+    std::memset(&rows[0], 0, sizeof(ndt3d_result));
+    for (int j = 0; j < 6; ++j) rows[0].pose[j] = init_pose[j];
+    rows[0].status = NDT_TOO_FEW_CELLS;
+    if (out) *out = rows[0];
+    return NDT_OK;
+  }
+  { const int32_t us = upload_source3(h, sx, sy, sz, n); if (us != NDT_OK) return us; }
+  const int fixed = h->prm.fixed_iterations;
+  const int K = fixed > 0 ? fixed : h->prm.max_iterations;
+  const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON;
+  h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
+  hipLaunchKernelGGL(k_begin3, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, h->d_s[0], h->d_s[1], h->d_s[2], (int)n,
+                     init_pose[0], init_pose[1], init_pose[2], init_pose[3], init_pose[4], init_pose[5], fixed,
+                     (IterState3*)nullptr, (int*)nullptr, h->call_seq);
+  for (int k = 0; k <= K; ++k) {
+    if (newton) hipLaunchKernelGGL((k_iterate3<1>), dim3(kMaxBlocks), dim3(kBlock), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
+    else hipLaunchKernelGGL((k_iterate3<0>), dim3(kMaxBlocks), dim3(kBlock), 0, h->stream, h->d_static, h->d_call, h->d_dyn, k & 1);
+    HIP_TRY(hipGetLastError());
+    if (k == 0) continue;                                  // launch 0 only evaluates
+    HIP_TRY(hipMemcpyAsync(h->h_state, &h->d_dyn->state[k & 1], sizeof(IterState3), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (*n_rows < capacity) to_row(*h->h_state, &rows[(*n_rows)++]);
+    if (h->h_state->done) break;
+  }
+  if (out) to_row(*h->h_state, out);
+  return NDT_OK;
+}
+
 void* ndt3d_stream(ndt3d_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,

@@ -642,6 +642,17 @@ class NdtMatcher3D:
                              np.array(r.g, dtype=np.float64), float(r.score), int(r.iterations), int(r.n_hit),
                              int(r.status))
 
+    def align_trace(self, sx, sy, sz, init_pose=(0.0,) * 6, capacity: int = 256):
+        """Per-iteration trace (ndt3d_align_trace; host arrays): a list of AlignResult3D, entry j = the state
+        after j + 1 updates (H, g, score, n_hit of the evaluation behind that update)."""
+        sx, sy, sz = _host_f32(sx), _host_f32(sy), _host_f32(sz)
+        p = (C.c_double * 6)(*[float(v) for v in init_pose])
+        rows = (L.Result3D * capacity)()
+        n_rows = C.c_int32(0)
+        L.check(self._lib.ndt3d_align_trace(self._h, sx.ctypes.data, sy.ctypes.data, sz.ctypes.data, sx.size, p,
+                                            C.cast(rows, C.c_void_p), capacity, C.byref(n_rows), None), "ndt3d_align_trace")
+        return [self._result(rows[j]) for j in range(n_rows.value)]
+
     def align_async(self, sx, sy, sz, init_pose=(0.0,) * 6, producer_complete: bool = False):
         """Enqueue the loop on the handle's stream (device tensors only); finish() waits and fetches."""
         import torch

@@ -443,6 +443,11 @@ int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, c
 int32_t ndt3d_align_dev_async(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
                               const double init_pose[6]);
 int32_t ndt3d_align_finish(ndt3d_handle* h, ndt3d_result* out);
+/* Per-iteration trace, as ndt2d_align_trace (debugging and stage-by-stage parity checks; never on a timed path):
+ * rows[j], j < *n_rows <= capacity, is the state after j + 1 updates - the pose after them, H / g / score / n_hit
+ * of the evaluation that produced the (j+1)-th update.  out (may be NULL): the final result.  Host arrays. */
+int32_t ndt3d_align_trace(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n,
+                          const double init_pose[6], ndt3d_result* rows, int32_t capacity, int32_t* n_rows, ndt3d_result* out);
 void* ndt3d_stream(ndt3d_handle* h);
 /* as ndt2d_wait_stream: order the handle's stream behind the producer of the device arrays */
 int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);

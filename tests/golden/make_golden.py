@@ -58,7 +58,8 @@ def main3d():
     d = synth3d.make_pair3d(n_elev=16, n_azim=256)
     prm = o3.Ndt3Params()
     g = o3.build_grid3(d["tx"], d["ty"], d["tz"], prm)
-    r = o3.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm)
+    trace = []
+    r = o3.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm, trace=trace)
     k5 = o3.align3(g, d["sx"], d["sy"], d["sz"], d["init"], o3.Ndt3Params(fixed_iterations=5))
     ev = o3.evaluate3(g, d["sx"], d["sy"], d["sz"], d["pose"], prm)
     out = {k: d[k] for k in ("tx", "ty", "tz", "sx", "sy", "sz")}
@@ -68,7 +69,11 @@ def main3d():
                 "grid_valid": g.valid, "final_pose": np.array(r["pose"]),
                 "final_iterations": np.int32(r["iterations"]), "final_status": np.int32(r["status"]),
                 "fixed5_pose": np.array(k5["pose"]), "eval_H": ev[0], "eval_g": ev[1],
-                "eval_score": np.float64(ev[2]), "eval_n_hit": np.int32(ev[3])})
+                "eval_score": np.float64(ev[2]), "eval_n_hit": np.int32(ev[3]),
+                # per-iteration trace: entry j = the evaluation at the pose before update j + 1
+                "trace_pose": np.array([t["pose"] for t in trace]), "trace_H": np.array([t["H"] for t in trace]),
+                "trace_g": np.array([t["g"] for t in trace]), "trace_score": np.array([t["score"] for t in trace]),
+                "trace_n_hit": np.array([t["n_hit"] for t in trace], dtype=np.int32)})
     path = os.path.join(ROOT, "tests", "golden", "ndt3d_small.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes;", r["iterations"], "iterations; pose", r["pose"])

@@ -190,3 +190,41 @@ def test_hip_per_iteration_trace_follows_the_golden_trace(gold, gpu_lib):
         gs = np.sqrt(np.abs(np.diag(tH[j])) * max(ts[j], 1.0))
         assert np.max(np.abs(r.g - tg[j]) / gs) < 5e-3, j
         assert np.abs(np.array(r.pose) - tp[j + 1]).max() < 1e-4, j    # pose after update j+1 = pose of evaluation j+1
+
+
+def test_oracle3d_reproduces_golden_trace():
+    from oracle import ndt3d as o3
+    g3 = np.load(GOLD3)
+    prm = o3.Ndt3Params()
+    trace = []
+    o3.align3(o3.build_grid3(g3["tx"], g3["ty"], g3["tz"], prm), g3["sx"], g3["sy"], g3["sz"], tuple(g3["init"]), prm, trace=trace)
+    assert len(trace) == len(g3["trace_pose"])
+    np.testing.assert_allclose(np.array([t["pose"] for t in trace]), g3["trace_pose"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(np.array([t["H"] for t in trace]), g3["trace_H"], rtol=1e-9, atol=1e-9 * np.abs(g3["trace_H"]).max())
+    np.testing.assert_array_equal(np.array([t["n_hit"] for t in trace]), g3["trace_n_hit"])
+
+
+@pytest.mark.gpu
+def test_hip_3d_per_iteration_trace_follows_the_golden_trace(gpu_lib):
+    """ndt3d_align_trace against the committed oracle trace of the 4096-point pair, iteration by iteration: hits,
+    score, the 6 x 6 H and g of every evaluation, and the pose after every update."""
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    g3 = np.load(GOLD3)
+    with NdtMatcher3D() as m:
+        m.set_target(g3["tx"], g3["ty"], g3["tz"])
+        rows = m.align_trace(g3["sx"], g3["sy"], g3["sz"], tuple(g3["init"]))
+        final = m.align(g3["sx"], g3["sy"], g3["sz"], tuple(g3["init"]))
+    tp, tH, tg, ts, tn = g3["trace_pose"], g3["trace_H"], g3["trace_g"], g3["trace_score"], g3["trace_n_hit"]
+    assert abs(len(rows) - len(tp)) <= 3 and rows[-1].status == int(g3["final_status"])
+    assert rows[-1].pose == final.pose and rows[-1].iterations == final.iterations      # the same kernels, launched one by one
+    k = min(len(rows), len(tp)) - 1
+    for j in range(k):
+        r = rows[j]
+        assert r.iterations == j + 1
+        assert abs(r.n_hit - int(tn[j])) <= 3, j                       # a boundary point may change voxel in float32
+        assert abs(r.score - ts[j]) / ts[j] < 5e-3, j
+        sc = np.sqrt(np.outer(np.abs(np.diag(tH[j])), np.abs(np.diag(tH[j]))))
+        assert np.max(np.abs(r.H - tH[j]) / sc) < 5e-3, j
+        gs = np.sqrt(np.abs(np.diag(tH[j])) * max(ts[j], 1.0))
+        assert np.max(np.abs(r.g - tg[j]) / gs) < 5e-3, j
+        assert np.abs(np.array(r.pose) - tp[j + 1]).max() < 1e-4, j    # pose after update j+1 = pose of evaluation j+1
