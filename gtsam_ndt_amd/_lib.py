@@ -172,6 +172,8 @@ SIGNATURES = {
     "ndt3d_align_dev_async": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp]),
     "ndt3d_align_finish": (C.c_int32, [_vp, C.POINTER(Result3D)]),
     "ndt3d_stream": (_vp, [_vp]),
+    "ndt3d_align_multi_scan_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _dp, C.c_int32, _vp]),
+    "ndt3d_align_multi_start_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.c_int32, _vp]),
     "ndt3d_align_trace": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, _vp, C.c_int32, C.POINTER(C.c_int32), _vp]),
     "ndt3d_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result3D)]),
     "ndt3d_batch_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),

@@ -4,6 +4,7 @@
 
 #include "ndt3d_kernels.hpp"
 #include "ndt3d_build.hpp"
+#include "ndt3d_multi.hpp"
 
 struct ndt3d_handle {
   int device = 0;
@@ -35,6 +36,8 @@ struct ndt3d_handle {
   // the state copy enqueued behind it, 2 converged-mode chunk loop
   int in_flight = 0;
   ndt::ChunkRun chunk_run;
+  ndt::AlignDynMulti3* d_dyn_multi = nullptr;   // multi-scan / multi-start chains (ndt3d_multi.hpp), on first use
+  ndt::IterState3* h_state_multi = nullptr;     // pinned [kMaxStarts3]
 };
 
 namespace {
@@ -253,6 +256,77 @@ int32_t run_align3(ndt3d_handle* h, const float* dx, const float* dy, const floa
   return st != NDT_OK ? st : finish_align3(h);
 }
 
+void unpack_h21(const double* s, double* H);
+
+void state3_to_result(const ndt::IterState3& s, ndt3d_result* out) {
+  std::memset(out, 0, sizeof(*out));
+  for (int j = 0; j < 6; ++j) { out->pose[j] = s.pose[j]; out->g[j] = s.g[j]; }
+  unpack_h21(s.H, out->H);
+  out->score = s.score; out->iterations = s.iter; out->n_hit = s.n_hit; out->status = s.status;
+}
+
+// m alignments against the cached voxel grid in one launch chain (ndt3d_multi.hpp)
+int32_t multi_align3(ndt3d_handle* h, const float* const* sxs, const float* const* sys, const float* const* szs, const size_t* ns,
+                     bool shared, const double* init_poses, int32_t m, ndt3d_result* results) {
+  using namespace ndt;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  TraceRange range(shared ? "ndt3d_align_multi_start" : "ndt3d_align_multi_scan");
+  HIP_TRY(hipSetDevice(h->device));
+  { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
+  if (h->n_valid < 1) {
+    for (int32_t k = 0; k < m; ++k) {
+      std::memset(&results[k], 0, sizeof(ndt3d_result));
+      for (int j = 0; j < 6; ++j) results[k].pose[j] = init_poses[6 * k + j];
+      results[k].status = NDT_TOO_FEW_CELLS;
+    }
+    return NDT_OK;
+  }
+  if (!h->h_state_multi) HIP_TRY(hipHostMalloc((void**)&h->h_state_multi, kMaxStarts3 * sizeof(IterState3), hipHostMallocDefault));
+  if (!h->d_dyn_multi) {
+    HIP_TRY(hipMalloc((void**)&h->d_dyn_multi, sizeof(AlignDynMulti3)));
+    HIP_TRY(hipMemsetAsync(h->d_dyn_multi, 0, sizeof(AlignDynMulti3), h->stream));
+  }
+  const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON;
+  const int fixed = h->prm.fixed_iterations;
+  const int K = fixed > 0 ? fixed : h->prm.max_iterations;
+  const bool converged_mode = fixed == 0;
+  __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);
+  h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
+  StartPoses3 sp{};
+  StartScans3 sc{};
+  for (int k = 0; k < m; ++k) {
+    for (int j = 0; j < 6; ++j) sp.p[k][j] = init_poses[6 * k + j];
+    const int q = shared ? 0 : k;
+    sc.sx[k] = sxs[q]; sc.sy[k] = sys[q]; sc.sz[k] = szs[q]; sc.n[k] = (int)ns[q];
+  }
+  hipLaunchKernelGGL(k_begin_multi3_scans, dim3(1), dim3(64), 0, h->stream, h->d_dyn_multi, sc, (int)m);
+  hipLaunchKernelGGL(k_begin_multi3, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn_multi, sp, (int)m, fixed,
+                     converged_mode ? h->h_state_multi : (IterState3*)nullptr, converged_mode ? h->h_flag : (int*)nullptr,
+                     h->call_seq);
+  HIP_TRY(hipGetLastError());
+  const int chunk = 8;
+  const int steps = converged_mode ? chunk : K + 1;
+  hipGraphExec_t exec = nullptr;
+  const void* fs = newton ? (const void*)&k_multi_solve3<1> : (const void*)&k_multi_solve3<0>;
+  const void* fb = newton ? (const void*)&k_multi_body3<1> : (const void*)&k_multi_body3<0>;
+  HIP_TRY(h->graphs.get2(fs, dim3(m), dim3(kBlock), fb, dim3(kMaxBlocks, m), dim3(kBlock), (void*)h->d_static, (void*)h->d_call,
+                         (void*)h->d_dyn_multi, steps, 0x100000 | (m << 8) | h->prm.hessian_mode, h->stream, &exec));
+  if (converged_mode) {
+    bool seen = false;
+    HIP_TRY(run_chunks_until_flag(exec, h->stream, h->h_flag, steps, K + 1, h->call_seq, &seen));
+    HIP_TRY(hipGetLastError());
+    if (!seen) { set_error("the 3D multi-scan loop did not report its end"); return NDT_ERR_HIP; }
+  } else {
+    HIP_TRY(hipGraphLaunch(exec, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_state_multi, h->d_dyn_multi->state[K & 1], kMaxStarts3 * sizeof(IterState3), hipMemcpyDeviceToHost,
+                           h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  for (int k = 0; k < m; ++k) state3_to_result(h->h_state_multi[k], &results[k]);
+  return NDT_OK;
+}
+
 void unpack_h21(const double* s, double* H) {
   H[0] = s[0]; H[1] = s[1]; H[2] = s[2]; H[7] = s[3]; H[8] = s[4]; H[14] = s[5];
   for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) H[6 * r + 3 + k] = s[6 + 3 * r + k];
@@ -312,9 +386,9 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->graphs.clear();
   void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
-                 h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->grid.rec, h->grid.acc};
+                 h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->grid.rec, h->grid.acc, h->d_dyn_multi};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag};
+  void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag, h->h_state_multi};
   for (void* p : host) if (p) (void)hipHostFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -555,6 +629,21 @@ int32_t ndt3d_align_trace(ndt3d_handle* h, const float* sx, const float* sy, con
   }
   if (out) to_row(*h->h_state, out);
   return NDT_OK;
+}
+
+int32_t ndt3d_align_multi_scan_dev(ndt3d_handle* h, const float* const* d_sx, const float* const* d_sy, const float* const* d_sz,
+                                   const size_t* n, const double* init_poses, int32_t m, ndt3d_result* results) {
+  if (!h || !d_sx || !d_sy || !d_sz || !n || !init_poses || !results || m < 1 || m > ndt::kMaxStarts3) return NDT_ERR_INVALID_ARG;
+  for (int32_t k = 0; k < m; ++k)
+    if (!d_sx[k] || !d_sy[k] || !d_sz[k] || n[k] == 0 || n[k] > kMaxSourcePoints) return NDT_ERR_INVALID_ARG;
+  return multi_align3(h, d_sx, d_sy, d_sz, n, /*shared=*/false, init_poses, m, results);
+}
+
+int32_t ndt3d_align_multi_start_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                                    const double* init_poses, int32_t m, ndt3d_result* results) {
+  if (!h || !d_sx || !d_sy || !d_sz || !init_poses || !results || m < 1 || m > ndt::kMaxStarts3) return NDT_ERR_INVALID_ARG;
+  if (n == 0 || n > kMaxSourcePoints) return NDT_ERR_INVALID_ARG;
+  return multi_align3(h, &d_sx, &d_sy, &d_sz, &n, /*shared=*/true, init_poses, m, results);
 }
 
 void* ndt3d_stream(ndt3d_handle* h) { return h ? (void*)h->stream : nullptr; }

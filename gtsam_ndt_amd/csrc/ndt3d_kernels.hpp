@@ -508,6 +508,74 @@ __device__ __forceinline__ void accumulate_point3(const Rot3F& T, float x, float
   acc[28] += hit ? 1.f : 0.f;
 }
 
+// a4-a7 of one launch for one alignment, shared by k_iterate3 and the multi-scan chain (k_multi_body3): this
+// workgroup's points (thread -> point assignment i, i + stride, ...; the first point already loaded) under `pose`,
+// per-thread sums, the wave's sums through LDS, one partial row entry per sum at partial_col[row * kMaxBlocks].
+template <int MODE>
+__device__ __forceinline__ void evaluate_block3(const Grid3Dev& G, const SolveParams& prm, const double* pose,
+                                                const float* __restrict__ sx, const float* __restrict__ sy,
+                                                const float* __restrict__ sz, int n, int i, float x, float y, float z,
+                                                float (*s_wave)[kNumAcc3], float* s_t_wave, float* __restrict__ partial_col) {
+  constexpr int NA = Acc3<MODE>::kUsed;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int stride = kMaxBlocks * kBlock;
+  Rot3F T;
+  make_rot3(pose, T);
+  const float fW = (float)G.W, fH = (float)G.H, fD = (float)G.D;
+  const float d1 = prm.d1, d2 = prm.d2;
+  const float nhd2 = -0.5f * d2 * 1.44269504088896340736f;
+
+  float acc[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) acc[j] = 0.f;
+
+  while (i < n) {
+    const int inext = i + stride;
+    float xn = 0.f, yn = 0.f, zn = 0.f;
+    if (inext < n) { xn = sx[inext]; yn = sy[inext]; zn = sz[inext]; }
+    float px = fmaf(T.R[0], x, fmaf(T.R[1], y, fmaf(T.R[2], z, T.tx)));
+    float py = fmaf(T.R[3], x, fmaf(T.R[4], y, fmaf(T.R[5], z, T.ty)));
+    float pz = fmaf(T.R[6], x, fmaf(T.R[7], y, fmaf(T.R[8], z, T.tz)));
+    const float fx = (px - G.ox) * G.inv_c, fy = (py - G.oy) * G.inv_c, fz = (pz - G.oz) * G.inv_c;
+    const bool in = (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
+    const int key = in ? (((int)fz * G.H + (int)fy) * G.W + (int)fx) : 0;
+    if (!in) { px = py = pz = 0.f; x = y = z = 0.f; }
+    const float4 A4 = G.rec[4 * key];
+    const float4 B4 = G.rec[4 * key + 1];
+    const float4 C2 = G.rec[4 * key + 2];
+    accumulate_point3<MODE>(T, x, y, z, px, py, pz, in, A4, B4, C2, d1, d2, nhd2, acc);
+    x = xn; y = yn; z = zn; i = inext;
+  }
+
+  // the wave's sums through LDS instead of one DPP tree each (wave_reduce11_lds of the 2D path):
+  // park [j][lane] (row stride 66 floats), lane 2j+q adds the 32 values of accumulator j whose
+  // lane index is q mod 2 in two chains, one quad DPP step folds the pair; 32 accumulators per round
+  {
+    float* t = s_t_wave;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) t[j * kSum3RowStride + lane] = acc[j];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int base = 0; base < NA; base += 32) {
+      const int j = base + (lane >> 1);
+      float a = 0.f, b = 0.f;
+      if (j < NA) {
+        const float* row = t + j * kSum3RowStride + (lane & 1);
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) { a += row[2 * k]; b += row[2 * k + 2]; }
+      }
+      float v = a + b;
+      v += dpp_mov<0xB1, 0xf>(v);
+      if ((lane & 1) == 0 && j < NA) s_wave[wave][j] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < Acc3<MODE>::kRows) {
+    const float r = tid < NA ? ((s_wave[0][tid] + s_wave[1][tid]) + s_wave[2][tid]) + s_wave[3][tid] : 0.f;
+    partial_col[(size_t)tid * kMaxBlocks] = r;
+  }
+}
+
 // Per-call part of the context (k_begin of the 2D path).
 __global__ void k_begin3(AlignCall3* __restrict__ call, AlignDyn3* __restrict__ dyn, const float* sx,
                          const float* sy, const float* sz, int n, double p0, double p1, double p2, double p3,
@@ -579,7 +647,6 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
                "s"(prm.d1), "s"(prm.d2), "s"(prm.min_hits), "s"(prm.max_iterations),
                "s"(prm.eps_trans), "s"(prm.eps_rot), "s"(prm.step_max_trans), "s"(prm.step_max_rot), "s"(ps_iter),
                "s"(ps_done), "s"(ps_have), "s"(fixed_iterations));
-  const int stride = kMaxBlocks * kBlock;
   int i = blockIdx.x * kBlock + tid;
   float x = 0.f, y = 0.f, z = 0.f;
   if (i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
@@ -671,61 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate3(const AlignStatic3* __restr
     copy_state3(cur, prev, 1);
   }
 
-  Rot3F T;
-  make_rot3(pose, T);
-  const float fW = (float)G.W, fH = (float)G.H, fD = (float)G.D;
-  const float d1 = prm.d1, d2 = prm.d2;
-  const float nhd2 = -0.5f * d2 * 1.44269504088896340736f;
-
-  float acc[NA];
-#pragma unroll
-  for (int j = 0; j < NA; ++j) acc[j] = 0.f;
-
-  while (i < n) {
-    const int inext = i + stride;
-    float xn = 0.f, yn = 0.f, zn = 0.f;
-    if (inext < n) { xn = sx[inext]; yn = sy[inext]; zn = sz[inext]; }
-    float px = fmaf(T.R[0], x, fmaf(T.R[1], y, fmaf(T.R[2], z, T.tx)));
-    float py = fmaf(T.R[3], x, fmaf(T.R[4], y, fmaf(T.R[5], z, T.ty)));
-    float pz = fmaf(T.R[6], x, fmaf(T.R[7], y, fmaf(T.R[8], z, T.tz)));
-    const float fx = (px - G.ox) * G.inv_c, fy = (py - G.oy) * G.inv_c, fz = (pz - G.oz) * G.inv_c;
-    const bool in = (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
-    const int key = in ? (((int)fz * G.H + (int)fy) * G.W + (int)fx) : 0;
-    if (!in) { px = py = pz = 0.f; x = y = z = 0.f; }
-    const float4 A4 = G.rec[4 * key];
-    const float4 B4 = G.rec[4 * key + 1];
-    const float4 C2 = G.rec[4 * key + 2];
-    accumulate_point3<MODE>(T, x, y, z, px, py, pz, in, A4, B4, C2, d1, d2, nhd2, acc);
-    x = xn; y = yn; z = zn; i = inext;
-  }
-
-  // the wave's sums through LDS instead of one DPP tree each (wave_reduce11_lds of the 2D path):
-  // park [j][lane] (row stride 66 floats), lane 2j+q adds the 32 values of accumulator j whose
-  // lane index is q mod 2 in two chains, one quad DPP step folds the pair; 32 accumulators per round
-  {
-    float* t = s_t[wave];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) t[j * kSum3RowStride + lane] = acc[j];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int base = 0; base < NA; base += 32) {
-      const int j = base + (lane >> 1);
-      float a = 0.f, b = 0.f;
-      if (j < NA) {
-        const float* row = t + j * kSum3RowStride + (lane & 1);
-#pragma unroll
-        for (int k = 0; k < 32; k += 2) { a += row[2 * k]; b += row[2 * k + 2]; }
-      }
-      float v = a + b;
-      v += dpp_mov<0xB1, 0xf>(v);
-      if ((lane & 1) == 0 && j < NA) s_wave[wave][j] = v;
-    }
-  }
-  __syncthreads();
-  if (tid < Acc3<MODE>::kRows) {
-    const float r = tid < NA ? ((s_wave[0][tid] + s_wave[1][tid]) + s_wave[2][tid]) + s_wave[3][tid] : 0.f;
-    dyn->partials[parity][tid][blockIdx.x] = r;
-  }
+  evaluate_block3<MODE>(G, prm, pose, sx, sy, sz, n, i, x, y, z, s_wave, s_t[wave], &dyn->partials[parity][0][blockIdx.x]);
 }
 
 }  // namespace ndt

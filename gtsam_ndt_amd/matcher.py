@@ -642,6 +642,34 @@ class NdtMatcher3D:
                              np.array(r.g, dtype=np.float64), float(r.score), int(r.iterations), int(r.n_hit),
                              int(r.status))
 
+    def align_multi_scan(self, scans, init_poses):
+        """Up to 64 different device scans [(x, y, z), ...] against the cached voxel grid, each from its own initial
+        pose, in one launch chain (ndt3d_align_multi_scan_dev); scan k's result equals align(scan k, pose k) bit for bit."""
+        import torch
+        m = len(scans)
+        poses = np.ascontiguousarray(init_poses, dtype=np.float64).reshape(m, 6)
+        ns = (C.c_size_t * m)(*[int(s[0].numel()) for s in scans])
+        ptr = [(C.c_void_p * m)(*[_dev_ptr(s[a], s[0].numel()).value for s in scans]) for a in range(3)]
+        out = (L.Result3D * m)()
+        L.check(self._lib.ndt3d_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ndt3d_wait_stream")
+        L.check(self._lib.ndt3d_align_multi_scan_dev(self._h, C.cast(ptr[0], C.c_void_p), C.cast(ptr[1], C.c_void_p),
+                                                     C.cast(ptr[2], C.c_void_p), C.cast(ns, C.c_void_p),
+                                                     poses.ctypes.data_as(L._dp), m, C.cast(out, C.c_void_p)),
+                "ndt3d_align_multi_scan_dev")
+        return [self._result(out[k]) for k in range(m)]
+
+    def align_multi_start(self, sx, sy, sz, init_poses):
+        """Up to 64 alignments of one device scan from different initial poses in one launch chain."""
+        import torch
+        poses = np.ascontiguousarray(init_poses, dtype=np.float64).reshape(-1, 6)
+        m, n = poses.shape[0], sx.numel()
+        out = (L.Result3D * m)()
+        L.check(self._lib.ndt3d_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ndt3d_wait_stream")
+        L.check(self._lib.ndt3d_align_multi_start_dev(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), _dev_ptr(sz, n), n,
+                                                      poses.ctypes.data_as(L._dp), m, C.cast(out, C.c_void_p)),
+                "ndt3d_align_multi_start_dev")
+        return [self._result(out[k]) for k in range(m)]
+
     def align_trace(self, sx, sy, sz, init_pose=(0.0,) * 6, capacity: int = 256):
         """Per-iteration trace (ndt3d_align_trace; host arrays): a list of AlignResult3D, entry j = the state
         after j + 1 updates (H, g, score, n_hit of the evaluation behind that update)."""

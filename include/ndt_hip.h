@@ -443,6 +443,17 @@ int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, c
 int32_t ndt3d_align_dev_async(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
                               const double init_pose[6]);
 int32_t ndt3d_align_finish(ndt3d_handle* h, ndt3d_result* out);
+/* Many alignments against the cached voxel grid in ONE launch chain, as ndt2d_align_multi_scan_dev /
+ * ndt2d_align_multi_start_dev: m (1..64) different scans, each from its own initial pose (d_sx / d_sy / d_sz / n:
+ * host arrays of m device pointers / sizes; init_poses [m][6]) - or one scan from m initial poses.  Per
+ * iteration the chain runs two kernels (one workgroup per start reduces and solves, then 256 x m workgroups
+ * evaluate), so the launch boundary and the 6 x 6 solve are paid once per iteration for all starts.
+ * results[k] is bit for bit what ndt3d_align_dev returns for scan k and init_poses[k]; a start that has
+ * finished is frozen while the others go on.  Synchronous in the results (host memory). */
+int32_t ndt3d_align_multi_scan_dev(ndt3d_handle* h, const float* const* d_sx, const float* const* d_sy, const float* const* d_sz,
+                                   const size_t* n, const double* init_poses, int32_t m, ndt3d_result* results);
+int32_t ndt3d_align_multi_start_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                                    const double* init_poses, int32_t m, ndt3d_result* results);
 /* Per-iteration trace, as ndt2d_align_trace (debugging and stage-by-stage parity checks; never on a timed path):
  * rows[j], j < *n_rows <= capacity, is the state after j + 1 updates - the pose after them, H / g / score / n_hit
  * of the evaluation that produced the (j+1)-th update.  out (may be NULL): the final result.  Host arrays. */
