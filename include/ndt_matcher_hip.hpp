@@ -463,6 +463,35 @@ class NdtMatcherHip3 {
     check(ndt3d_align_dev(h_, d_sx, d_sy, d_sz, n, init, &r), "ndt3d_align_dev");
     return toMatchResult(r);
   }
+  // up to 64 different device scans against the cached voxel grid in one launch chain; result k is bit for bit
+  // what alignDev returns for scan k and guesses[k]
+  struct DeviceScan3 { const float* x; const float* y; const float* z; size_t n; };
+  std::vector<MatchResult3> alignMultiScanDev(const std::vector<DeviceScan3>& scans, const std::vector<Pose3>& guesses) {
+    const size_t m = scans.size();
+    if (m == 0 || guesses.size() != m) throw NdtError(NDT_ERR_INVALID_ARG, "ndt3d_align_multi_scan_dev");
+    std::vector<const float*> px(m), py(m), pz(m);
+    std::vector<size_t> ns(m);
+    std::vector<double> init(6 * m);
+    for (size_t k = 0; k < m; ++k) {
+      px[k] = scans[k].x; py[k] = scans[k].y; pz[k] = scans[k].z; ns[k] = scans[k].n;
+      const Pose3& g = guesses[k];
+      const double p[6] = {g.x, g.y, g.z, g.roll, g.pitch, g.yaw};
+      std::copy(p, p + 6, init.begin() + 6 * k);
+    }
+    std::vector<ndt3d_result> res(m);
+    check(ndt3d_align_multi_scan_dev(h_, px.data(), py.data(), pz.data(), ns.data(), init.data(), static_cast<int32_t>(m), res.data()),
+          "ndt3d_align_multi_scan_dev");
+    std::vector<MatchResult3> out;
+    out.reserve(m);
+    for (const auto& r : res) out.push_back(toMatchResult(r));
+    return out;
+  }
+  // one device scan from several initial poses (a lattice of hypotheses around a poor guess)
+  std::vector<MatchResult3> alignMultiStartDev(const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                                               const std::vector<Pose3>& guesses) {
+    std::vector<DeviceScan3> scans(guesses.size(), DeviceScan3{d_sx, d_sy, d_sz, n});
+    return alignMultiScanDev(scans, guesses);
+  }
   ndt3d_grid_info gridInfo() const { ndt3d_grid_info g; check(ndt3d_get_grid_info(h_, &g), "ndt3d_get_grid_info"); return g; }
 
   MatchResult3 align(const float* sx, const float* sy, const float* sz, size_t n, const Pose3& guess = Pose3()) {
