@@ -572,9 +572,13 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
           yy[u] = fmaf(T.R[3], cx, fmaf(T.R[4], cy, T.R[5] * cz));
           yz[u] = fmaf(T.R[6], cx, fmaf(T.R[7], cy, T.R[8] * cz));
           px[u] = yx[u] + T.tx; py[u] = yy[u] + T.ty; pz[u] = yz[u] + T.tz;
-          const float fx = (px[u] - ox) * inv_c, fy = (py[u] - oy) * inv_c, fz = (pz[u] - oz) * inv_c;
-          in[u] = ((base + u * kB3Threads) < ns) & (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
-          const int key = in[u] ? (((int)fz * Hh + (int)fy) * W + (int)fx) : 0;
+          // voxel indices by floor (one saturating v_cvt_flr_i32_f32 each; the coordinates are finite), in range iff
+          // 0 <= index < extent as ONE unsigned compare per axis - the same voxel as (int)f under f >= 0 && f < extent
+          const int ix = floor_to_int((px[u] - ox) * inv_c), iy = floor_to_int((py[u] - oy) * inv_c),
+                    iz = floor_to_int((pz[u] - oz) * inv_c);
+          in[u] = ((base + u * kB3Threads) < ns) & ((unsigned)ix < (unsigned)W) & ((unsigned)iy < (unsigned)Hh) &
+                  ((unsigned)iz < (unsigned)D);
+          const int key = in[u] ? ((iz * Hh + iy) * W + ix) : 0;
           int slot = (int)idx[key];
           if (!in[u]) slot = 0;
           A4[u] = recA[slot]; B4[u] = recB[slot]; C2[u] = recC[slot];
