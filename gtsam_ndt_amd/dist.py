@@ -22,7 +22,8 @@ def shard_sizes(n_pairs_total: int, world: int) -> list[int]:
 
 
 def gather_results(local, n_pairs_total: int, group=None):
-    """all_gather the [n_local, 18] float64 result rows of every rank into global pair order.
+    """all_gather the float64 result rows of every rank ([n_local, 18] for ndt2d_result, [n_local, 51] for
+    ndt3d_result: the width is the tensor's) into global pair order.
 
     Shards may differ in length by one, so each rank pads to the longest shard, the padded
     blocks are gathered with one all_gather_into_tensor (the only collective of the path;
@@ -63,4 +64,17 @@ def pack_pairs(pairs):
     cat = lambda k: np.concatenate([p[k] for p in pairs])
     init = np.array([p["init"] for p in pairs], dtype=np.float64).reshape(n, 3)
     return {"tx": cat("tx"), "ty": cat("ty"), "toff": toff, "sx": cat("sx"), "sy": cat("sy"), "soff": soff,
+            "init": init}
+
+
+def pack_pairs3d(pairs):
+    """The same for 3D pairs (synth3d.make_pair3d() dicts): the layout NdtBatch3D.align_dev takes."""
+    n = len(pairs)
+    toff = np.zeros(n + 1, dtype=np.int64)
+    soff = np.zeros(n + 1, dtype=np.int64)
+    toff[1:] = np.cumsum([len(p["tx"]) for p in pairs])
+    soff[1:] = np.cumsum([len(p["sx"]) for p in pairs])
+    cat = lambda k: np.concatenate([p[k] for p in pairs])
+    init = np.array([p["init"] for p in pairs], dtype=np.float64).reshape(n, 6)
+    return {"t": [cat("tx"), cat("ty"), cat("tz")], "toff": toff, "s": [cat("sx"), cat("sy"), cat("sz")], "soff": soff,
             "init": init}

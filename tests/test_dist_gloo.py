@@ -21,10 +21,10 @@ def test_shards_partition_the_batch():
         nd.shard_range(10, 2, 2)
 
 
-def _fake_rows(idx):
-    """Deterministic stand-in for ndt2d_result rows keyed by global pair index."""
+def _fake_rows(idx, width=18):
+    """Deterministic stand-in for ndt2d_result (18 doubles) / ndt3d_result (51) rows keyed by global pair index."""
     i = np.asarray(list(idx), dtype=np.float64)[:, None]
-    return torch.from_numpy(i * 1000.0 + np.arange(18, dtype=np.float64)[None, :])
+    return torch.from_numpy(i * 1000.0 + np.arange(width, dtype=np.float64)[None, :])
 
 
 def _worker(rank, world, port, total, q):
@@ -34,6 +34,8 @@ def _worker(rank, world, port, total, q):
         mine = nd.shard_range(total, rank, world)
         allr = nd.gather_results(_fake_rows(mine), total)
         ok = bool(torch.equal(allr, _fake_rows(range(total))))
+        all3 = nd.gather_results(_fake_rows(mine, 51), total)              # the 3D batch's rows through the same gather
+        ok = ok and bool(torch.equal(all3, _fake_rows(range(total), 51)))
         t = nd.max_over_ranks(1.0 + rank)
         q.put((rank, ok, t))
     finally:
@@ -65,3 +67,8 @@ def test_pack_pairs_layout():
     assert list(b["toff"]) == [0, 100, 201, 303] and list(b["soff"]) == [0, 50, 102, 156]
     assert np.array_equal(b["tx"][100:201], ps[1]["tx"]) and np.array_equal(b["sy"][102:156], ps[2]["sy"])
     assert b["init"].shape == (3, 3)
+    from gtsam_ndt_amd import synth3d
+    p3 = [synth3d.make_pair3d(n_elev=4, n_azim=16 + 8 * k) for k in range(2)]
+    b3 = nd.pack_pairs3d(p3)
+    assert list(b3["toff"]) == [0, 64, 160] and b3["init"].shape == (2, 6) and len(b3["t"]) == 3
+    assert np.array_equal(b3["s"][2][64:160], p3[1]["sz"])
