@@ -1,12 +1,12 @@
 // 3D loop-closure candidate batch: the 3D twin of ndt2d_batch.hpp.  Persistent 1024-thread workgroups
 // (one per CU) pull scan pairs from a queue and run the whole alignment of a pair on chip:
 //   - the pair's voxel grid lives in LDS for the Gauss-Newton loop: a dense u16 voxel -> slot table
-//     and 40-byte records (mean, n | Sigma^-1) per occupied voxel.  The carve is per pair: the
+//     and 36-byte records (mean | Sigma^-1) per occupied voxel.  The carve is per pair: the
 //     table takes 2 bytes per voxel, the records get the rest (config 5: 44 x 44 x 9 = 17 424
-//     voxels, 2 706 occupied: 35 KB + 108 KB of the 160 KB);
+//     voxels, 2 706 occupied: 35 KB + 97 KB of the 160 KB; up to 3 494 occupied voxels fit that grid);
 //   - the nine exact fixed-point sums of a voxel (72 bytes per slot) do not fit next to the table,
-//     so the build adds them up in LDS five and four at a time (the records' 40 bytes per slot hold
-//     five; two passes over the target) and parks each pass in a per-workgroup slab of global memory;
+//     so the build adds them up in LDS four at a time (the records' 36 bytes per slot hold
+//     four; two passes over the target) and parks each pass in a per-workgroup slab of global memory;
 //     the finalise reads them back once and writes the records into LDS;
 //   - source points stream from HBM/L2 once per iteration; the 29 (Newton: 38) sums are reduced
 //     per wave (DPP) -> LDS -> wave 0, which also does the 6x6 solve: two workgroup barriers per
@@ -64,7 +64,8 @@ constexpr int kB3Scan = kB3Misc + 64;                   // int [16]
 constexpr int kB3Ls = kB3Scan + 64;                     // LineSearch3
 constexpr int kB3Idx = kB3Ls + 128;                     // u16 [ncell]
 constexpr int kB3LdsBytes = 160 * 1024;
-constexpr int kB3RecBytes = 40;                         // per slot: float4 (mean, n) + float4 (xx xy xz yy) + float2 (yz zz)
+constexpr int kB3RecBytes = 36;                         // per slot: float4 (mean, xx) + float4 (xy xz yy yz) + float (zz); a valid
+                                                        // record has xx > 0 (Sigma^-1 is positive definite), the dummy record 0 is all zero
 static_assert(sizeof(LineSearch3) <= 128 && (kB3Idx % 16) == 0 && (kB3Bc % 16) == 0, "carve");
 // slab of one workgroup: u32 slot_n[S], u32 slot_key[S], u64 sums[9][S]
 constexpr int kB3SlabN = 0;
@@ -85,7 +86,7 @@ constexpr size_t kG3SlotKey = kG3SlotN + (size_t)kG3MaxSlots * 4;             //
 constexpr size_t kG3Sums = kG3SlotKey + (size_t)kG3MaxSlots * 4;              // u64 [9][MaxSlots]
 constexpr size_t kG3RecA = kG3Sums + (size_t)9 * kG3MaxSlots * 8;             // float4 [MaxSlots]
 constexpr size_t kG3RecB = kG3RecA + (size_t)kG3MaxSlots * 16;                // float4 [MaxSlots]
-constexpr size_t kG3RecC = kG3RecB + (size_t)kG3MaxSlots * 16;                // float2 [MaxSlots]
+constexpr size_t kG3RecC = kG3RecB + (size_t)kG3MaxSlots * 16;                // float [MaxSlots] (region sized for 8 B each)
 constexpr size_t kG3SlabBytes = kG3RecC + (size_t)kG3MaxSlots * 8;            // 15.7 MB
 
 constexpr int kTgt3Unroll = 4;
@@ -149,11 +150,11 @@ __device__ __forceinline__ void write_result3(Result3Dev* o, const double* pose,
 // the all-zero record.
 template <int MODE>
 __device__ __forceinline__ void accumulate_point3_map(float yx, float yy, float yz, float px, float py, float pz, bool in,
-                                                      const float4& A4, const float4& B4, const float2& C2, float d1,
+                                                      const float4& A4, const float4& B4, const float C1, float d1,
                                                       float d2, float nhd2, float* acc) {
-  const bool hit = in & (A4.w > 0.f);
+  const float cxx = A4.w, cxy = B4.x, cxz = B4.y, cyy = B4.z, cyz = B4.w, czz = C1;
+  const bool hit = in & (cxx > 0.f);
   const float qx = px - A4.x, qy = py - A4.y, qz = pz - A4.z;
-  const float cxx = B4.x, cxy = B4.y, cxz = B4.z, cyy = B4.w, cyz = C2.x, czz = C2.y;
   const float vx = fmaf(cxx, qx, fmaf(cxy, qy, cxz * qz));
   const float vy = fmaf(cxy, qx, fmaf(cyy, qy, cyz * qz));
   const float vz = fmaf(cxz, qx, fmaf(cyz, qy, czz * qz));
@@ -370,10 +371,10 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   const int rec_base = (kB3Idx + 2 * ncell + 15) & ~15;
   const int slot_cap = GLOBAL ? kG3MaxSlots : (kB3LdsBytes - rec_base) / kB3RecBytes;      // records incl. the dummy record 0
   unsigned int* cnt = GLOBAL ? reinterpret_cast<unsigned int*>(slab + kG3Idx) : reinterpret_cast<unsigned int*>(smem + rec_base);
-  unsigned long long* psum = reinterpret_cast<unsigned long long*>(smem + rec_base);      // on-chip build: u64 [5][nslot]
+  unsigned long long* psum = reinterpret_cast<unsigned long long*>(smem + rec_base);      // on-chip build: u64 [per][nslot]
   float4* recA = GLOBAL ? reinterpret_cast<float4*>(slab + kG3RecA) : reinterpret_cast<float4*>(smem + rec_base);
   float4* recB = GLOBAL ? reinterpret_cast<float4*>(slab + kG3RecB) : reinterpret_cast<float4*>(smem + rec_base + 16 * slot_cap);
-  float2* recC = GLOBAL ? reinterpret_cast<float2*>(slab + kG3RecC) : reinterpret_cast<float2*>(smem + rec_base + 32 * slot_cap);
+  float* recC = GLOBAL ? reinterpret_cast<float*>(slab + kG3RecC) : reinterpret_cast<float*>(smem + rec_base + 32 * slot_cap);
 
   auto voxel_of = [&](float px, float py, float pz, int& ix, int& iy, int& iz) -> bool {
     const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c, fz = (pz - oz) * inv_c;
@@ -450,12 +451,15 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     });
     __syncthreads();
   } else {
-    // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics).  The records' region holds 40 B per
-    // slot = five 64-bit sums: s[0..2], ss[0..1] in the first pass over the target, ss[2..5] in the second
+    // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics).  The records' region (36 B per slot
+    // of capacity) holds `per` of the nine 64-bit sums of every occupied slot at a time: config 5 (2 706 slots) five, so
+    // two passes over the target; a grid that fills the carve four, so three passes
+    int per = (kB3LdsBytes - rec_base) / (8 * nslot);
+    per = per > 9 ? 9 : per;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      const int nsum = pass == 0 ? 5 : 4;
-      for (int j = tid; j < nsum * nslot; j += kB3Threads) psum[j] = 0ull;
+    for (int j0 = 0; j0 < 9; j0 += per) {
+      const int j1 = j0 + per < 9 ? j0 + per : 9;
+      for (int j = tid; j < (j1 - j0) * nslot; j += kB3Threads) psum[j] = 0ull;
       __syncthreads();
       for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
         int ix, iy, iz;
@@ -465,25 +469,20 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
             const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
             const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
             const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
+            // s[0..2], ss[0..5] = xx xy xz yy yz zz
+            const unsigned long long v[9] = {(unsigned long long)(long long)ux, (unsigned long long)(long long)uy,
+                                             (unsigned long long)(long long)uz, prod64(ux, ux), prod64(ux, uy), prod64(ux, uz),
+                                             prod64(uy, uy), prod64(uy, uz), prod64(uz, uz)};
             unsigned long long* q = psum + (slot - 1);
-            if (pass == 0) {          // s[0..2], ss[0..1] = xx xy
-              atomicAdd(q, (unsigned long long)(long long)ux);
-              atomicAdd(q + nslot, (unsigned long long)(long long)uy);
-              atomicAdd(q + 2 * nslot, (unsigned long long)(long long)uz);
-              atomicAdd(q + 3 * nslot, prod64(ux, ux));
-              atomicAdd(q + 4 * nslot, prod64(ux, uy));
-            } else {                  // ss[2..5] = xz yy yz zz
-              atomicAdd(q, prod64(ux, uz));
-              atomicAdd(q + nslot, prod64(uy, uy));
-              atomicAdd(q + 2 * nslot, prod64(uy, uz));
-              atomicAdd(q + 3 * nslot, prod64(uz, uz));
-            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+              if (c >= j0 && c < j1) atomicAdd(q + (c - j0) * nslot, v[c]);      // uniform condition
           }
         }
       });
       __syncthreads();
-      for (int j = tid; j < nsum * nslot; j += kB3Threads)
-        gsums[(size_t)(5 * pass + j / nslot) * kS + (j % nslot)] = psum[j];
+      for (int j = tid; j < (j1 - j0) * nslot; j += kB3Threads)
+        gsums[(size_t)(j0 + j / nslot) * kS + (j % nslot)] = psum[j];
       __syncthreads();
     }
   }
@@ -509,10 +508,11 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
         ok = finalise_sums3(c, cell_centre(ox, ix, a.cell), cell_centre(oy, iy, a.cell), cell_centre(oz, iz, a.cell), fix_scale,
                             a.min_points, a.eig_ratio, ra, rb, rc);
       if (!ok) { ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = ra; rc = ra; }
-      recA[sl + 1] = ra; recB[sl + 1] = rb; recC[sl + 1] = make_float2(rc.x, rc.y);
+      // finalise_sums3's record (mean | n, xx xy xz yy, yz zz) repacked into 9 floats
+      recA[sl + 1] = make_float4(ra.x, ra.y, ra.z, rb.x); recB[sl + 1] = make_float4(rb.y, rb.z, rb.w, rc.x); recC[sl + 1] = rc.y;
       nvalid += ok ? 1 : 0;
     }
-    if (tid == 0) { recA[0] = make_float4(0.f, 0.f, 0.f, 0.f); recB[0] = recA[0]; recC[0] = make_float2(0.f, 0.f); }
+    if (tid == 0) { recA[0] = make_float4(0.f, 0.f, 0.f, 0.f); recB[0] = recA[0]; recC[0] = 0.f; }
     if (nvalid) atomicAdd(&misc[8], nvalid);
     if constexpr (GLOBAL) __threadfence();         // records and table are read through L1 / L2 from here on
     __syncthreads();
@@ -560,7 +560,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
         float yx[U], yy[U], yz[U], px[U], py[U], pz[U];
         bool in[U];
         float4 A4[U], B4[U];
-        float2 C2[U];
+        float C1[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           // NaN / inf (no-return points) never reach the sums: coordinates are clamped to +-1e15 first (v_med3_f32
@@ -581,11 +581,11 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
           const int key = in[u] ? ((iz * Hh + iy) * W + ix) : 0;
           int slot = (int)idx[key];
           if (!in[u]) slot = 0;
-          A4[u] = recA[slot]; B4[u] = recB[slot]; C2[u] = recC[slot];
+          A4[u] = recA[slot]; B4[u] = recB[slot]; C1[u] = recC[slot];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          accumulate_point3_map<MODE>(yx[u], yy[u], yz[u], px[u], py[u], pz[u], in[u], A4[u], B4[u], C2[u], d1, d2, nhd2, acc);
+          accumulate_point3_map<MODE>(yx[u], yy[u], yz[u], px[u], py[u], pz[u], in[u], A4[u], B4[u], C1[u], d1, d2, nhd2, acc);
       };
       if (ns > 0) {                                  // uniform
         load_set(tid, xa, ya, za);

@@ -201,6 +201,56 @@ struct Staging {
 
 }  // namespace
 
+// ---- 3D: synth3d.lidar_scan on the device (ray cast of the box room; workload generator for config 5) ----------
+constexpr int kMaxBoxes = NDT_SYNTH_MAX_BOXES;
+struct Lidar3dArgs {
+  double lo[kMaxBoxes][3], hi[kMaxBoxes][3];     // clutter boxes
+  double rlo[3], rhi[3];                         // the room
+  double o[3];                                   // ray origin (sensor position in the map frame)
+  double R[9];                                   // sensor orientation
+  double el0, el_step, az_step, amp;             // beam pattern; amp = sqrt(3) * sigma
+  unsigned long long seed;
+  int n_box, n_elev, n_azim;
+};
+__global__ __launch_bounds__(256) void k_lidar3d(Lidar3dArgs a, float* __restrict__ x, float* __restrict__ y,
+                                                 float* __restrict__ z) {
+  const int n = a.n_elev * a.n_azim;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int e = i / a.n_azim, j = i - e * a.n_azim;
+    // np.deg2rad(np.linspace(-24, 20, n_elev)): start + e * step (the last beam is the stop value itself)
+    const double el_deg = e == a.n_elev - 1 && a.n_elev > 1 ? 20.0 : a.el0 + (double)e * a.el_step;
+    const double el = el_deg * (3.141592653589793 / 180.0);
+    const double az = ((double)j + 0.5) * a.az_step;
+    double se, ce, sa, ca;
+    sincos(el, &se, &ce);
+    sincos(az, &sa, &ca);
+    const double ds[3] = {ce * ca, ce * sa, se};
+    double t_hit = INFINITY, inv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double d = a.R[3 * c] * ds[0] + a.R[3 * c + 1] * ds[1] + a.R[3 * c + 2] * ds[2];
+      if (fabs(d) < 1e-12) d = 1e-12;
+      inv[c] = 1.0 / d;
+      t_hit = fmin(t_hit, fmax((a.rlo[c] - a.o[c]) * inv[c], (a.rhi[c] - a.o[c]) * inv[c]));   // inside the room: exit distance
+    }
+    for (int b = 0; b < a.n_box; ++b) {
+      double tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double t1 = (a.lo[b][c] - a.o[c]) * inv[c], t2 = (a.hi[b][c] - a.o[c]) * inv[c];
+        tn = fmax(tn, fmin(t1, t2));
+        tf = fmin(tf, fmax(t1, t2));
+      }
+      if (tn <= tf && tn > 0.0 && tn < t_hit) t_hit = tn;
+    }
+    const unsigned long long k = 4ull * (unsigned long long)i;
+    const double noise = (uniform01(a.seed, k) + uniform01(a.seed, k + 1) + uniform01(a.seed, k + 2) + uniform01(a.seed, k + 3) - 2.0) * a.amp;
+    const double r = t_hit + noise;
+    x[i] = (float)(ds[0] * r); y[i] = (float)(ds[1] * r); z[i] = (float)(ds[2] * r);
+  }
+}
+
+
 extern "C" {
 
 const char* ndt_synth_last_error(void) { return synth_error().c_str(); }
@@ -280,6 +330,38 @@ int32_t ndt_synth_config4_dev(uint64_t first_pair, size_t n_pairs, size_t n_tgt,
                      (const PairDev*)((char*)s.dev + bytes_scene), n_tgt, n_src, kSqrt3 * sigma, d_tx, d_ty, d_sx, d_sy);
   SYNTH_TRY(hipGetLastError());
   SYNTH_TRY(hipStreamSynchronize(st));      // staging is released on return
+  return 0;
+}
+
+int32_t ndt_synth_lidar3d_dev(const double* boxes_lo, const double* boxes_hi, int32_t n_box, double L, double height,
+                              double sensor_z, uint64_t seed, const double pose[6], int32_t n_elev, int32_t n_azim,
+                              double sigma, float* d_x, float* d_y, float* d_z, void* stream) {
+  if (!boxes_lo || !boxes_hi || n_box < 0 || n_box > kMaxBoxes || !pose || n_elev < 1 || n_azim < 1 || !d_x || !d_y || !d_z ||
+      !(L > 0.0) || !(height > 0.0))
+    return -1;
+  Lidar3dArgs a{};
+  for (int b = 0; b < n_box; ++b)
+    for (int c = 0; c < 3; ++c) { a.lo[b][c] = boxes_lo[3 * b + c]; a.hi[b][c] = boxes_hi[3 * b + c]; }
+  a.rlo[0] = -0.5 * L; a.rlo[1] = -0.5 * L; a.rlo[2] = 0.0;
+  a.rhi[0] = 0.5 * L; a.rhi[1] = 0.5 * L; a.rhi[2] = height;
+  a.o[0] = pose[0]; a.o[1] = pose[1]; a.o[2] = pose[2] + sensor_z;
+  const double ca = std::cos(pose[3]), sa = std::sin(pose[3]), cb = std::cos(pose[4]), sb = std::sin(pose[4]),
+               cg = std::cos(pose[5]), sg = std::sin(pose[5]);
+  const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
+                       sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
+                       -sb, cb * sa, cb * ca};
+  for (int j = 0; j < 9; ++j) a.R[j] = R[j];
+  a.el0 = -24.0;
+  a.el_step = n_elev > 1 ? 44.0 / (double)(n_elev - 1) : 0.0;
+  a.az_step = 2.0 * 3.141592653589793 / (double)n_azim;
+  a.amp = kSqrt3 * sigma;
+  a.seed = seed;
+  a.n_box = n_box; a.n_elev = n_elev; a.n_azim = n_azim;
+  const size_t n = (size_t)n_elev * (size_t)n_azim;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_lidar3d, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, d_x, d_y, d_z);
+  SYNTH_TRY(hipGetLastError());
   return 0;
 }
 

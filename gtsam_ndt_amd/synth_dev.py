@@ -24,6 +24,8 @@ SIGNATURES = {
                                          _vp, _vp]),
     "ndt_synth_config4_dev": (C.c_int32, [C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
+    "ndt_synth_lidar3d_dev": (C.c_int32, [_vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, _vp, C.c_int32,
+                                          C.c_int32, C.c_double, _vp, _vp, _vp, _vp]),
     "ndt_synth_last_error": (C.c_char_p, []),
 }
 
@@ -103,3 +105,27 @@ def config4_batch(first_pair: int, n_pairs: int, n_tgt: int = 100_000, n_src: in
                                             t["soff"].data_ptr(), t["init"].data_ptr(), t["pose"].data_ptr(),
                                             torch.cuda.current_stream().cuda_stream), "ndt_synth_config4_dev")
     return t
+
+
+def lidar_scan3d(seed: int, pose, n_elev: int = 64, n_azim: int = 2048, sigma: float = 0.02, L: float = 40.0,
+                 height: float = 6.0, scene_seed: int = 5, device="cuda:0", out=None):
+    """synth3d.lidar_scan on the device (ndt_synth_lidar3d_dev): (x, y, z) float32 CUDA tensors of n_elev * n_azim
+    sensor-frame points.  Same scene, beams and noise as the numpy generator; equal to it up to float32 rounding
+    (not bit for bit: the beam directions' cos / sin come from the device's libm)."""
+    import torch
+    from . import synth3d
+    lo, hi = synth3d.scene_boxes(scene_seed, L, height)
+    lo = np.ascontiguousarray(lo, dtype=np.float64)
+    hi = np.ascontiguousarray(hi, dtype=np.float64)
+    n = n_elev * n_azim
+    if out is None:
+        out = tuple(torch.empty(n, dtype=torch.float32, device=device) for _ in range(3))
+    if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n for t in out):
+        raise ValueError("out must be three contiguous float32 CUDA tensors of n_elev * n_azim elements")
+    p = (C.c_double * 6)(*[float(v) for v in pose])
+    with torch.cuda.device(out[0].device):
+        _check(load().ndt_synth_lidar3d_dev(lo.ctypes.data, hi.ctypes.data, lo.shape[0], float(L), float(height),
+                                            float(synth3d.SENSOR_Z), int(seed), C.cast(p, _vp), int(n_elev), int(n_azim),
+                                            float(sigma), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "ndt_synth_lidar3d_dev")
+    return out

@@ -465,13 +465,14 @@ int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
 
 /* ---- 3D loop-closure candidate batch ------------------------------------------------------------ */
 /* The 3D twin of ndt2d_batch: independent 3D scan pairs aligned concurrently, one persistent
- * 1024-thread workgroup per CU, the pair's voxel grid (u16 voxel -> slot table + 40-byte records) in
+ * 1024-thread workgroup per CU, the pair's voxel grid (u16 voxel -> slot table + 36-byte records) in
  * LDS for the whole Gauss-Newton / Newton loop.  Clouds are concatenated SoA arrays; pair k owns
  * target points [toff[k], toff[k+1]) and source points [soff[k], soff[k+1]); init is [n_pairs][6];
  * results is [n_pairs].  Every pair's result equals the single-pair path's (ndt3d_set_target +
  * ndt3d_align) up to float32 summation order: same records bit for bit, same per-point arithmetic.
- * On-chip capacity per pair: 2 B per voxel + 40 B per occupied voxel <= 157 KB and 6 B per voxel
- * <= 157 KB during the build (BASELINE config 5: 17 424 voxels, 2 706 occupied = 143 KB).  A pair
+ * On-chip capacity per pair: 2 B per voxel + 36 B per occupied voxel <= 157 KB and 6 B per voxel
+ * <= 157 KB during the build (BASELINE config 5: 17 424 voxels, 2 706 occupied = 132 KB; that grid holds up to
+ * 3 494 occupied voxels).  A pair
  * beyond it is handed, on the device and within the same call, to a second variant of the kernel that
  * keeps the pair's tables in global memory (up to 2^21 voxels - e.g. 256 x 256 x 32 - and 65 535 occupied).
  * Beyond that a pair gets status NDT_ERR_CAPACITY from the _dev entry point, and the host-pointer entry

@@ -44,6 +44,17 @@ int32_t ndt_synth_config4_dev(uint64_t first_pair, size_t n_pairs, size_t n_tgt,
                               float* d_ty, float* d_sx, float* d_sy, uint64_t* d_toff, uint64_t* d_soff, double* d_init,
                               double* d_pose, void* stream);
 
+/* synth3d.lidar_scan(seed, pose, n_elev, n_azim, sigma) on the device: the 64-beam lidar of BASELINE config 5 ray
+ * cast against the box room [-L/2, L/2]^2 x [0, height] with the clutter boxes boxes_lo / boxes_hi (HOST arrays
+ * [n_box][3], n_box <= 32: synth3d.scene_boxes), sensor at pose (tx, ty, tz + sensor_z; roll, pitch, yaw), points in
+ * the SENSOR frame, ring-major.  Same beams, same noise counters, float64 ray casting; NOT bit-identical to numpy
+ * (the beams' cos / sin come from the device's libm): points agree to float32 rounding except for a ray that grazes
+ * a box edge.  d_x / d_y / d_z: device arrays of n_elev * n_azim floats.  Asynchronous on `stream`. */
+#define NDT_SYNTH_MAX_BOXES 32
+int32_t ndt_synth_lidar3d_dev(const double* boxes_lo, const double* boxes_hi, int32_t n_box, double L, double height,
+                              double sensor_z, uint64_t seed, const double pose[6], int32_t n_elev, int32_t n_azim,
+                              double sigma, float* d_x, float* d_y, float* d_z, void* stream);
+
 /* text of the last error on this thread ("" if none) */
 const char* ndt_synth_last_error(void);
 

@@ -70,3 +70,19 @@ def test_sample_scene_on_the_config3_submap_is_bit_identical(synth_dev, gpu_lib)
     # a later window of the same stream: `first`
     x2, _ = synth_dev.sample_scene(scene, 1000, seed=S * 7919 + 11, sigma=synth.SIGMA, first=299_000)
     assert np.array_equal(x2.cpu().numpy(), d["tx"][299_000:])
+
+
+@pytest.mark.gpu
+def test_device_lidar3d_matches_numpy_generator(gpu_lib):
+    """ndt_synth_lidar3d_dev vs synth3d.lidar_scan: same scene, beams and noise counters; float64 ray casting on both
+    sides, the beam directions' cos / sin from two different libms - equal to float32 rounding, except that a ray
+    grazing a box edge may hit on one side and miss on the other (a handful of beams at most)."""
+    from gtsam_ndt_amd import synth3d, synth_dev
+    for seed, pose, shape, scene in ((101, (0.0,) * 6, (64, 2048), 5), (7, (0.30, -0.20, 0.05, 0.01, -0.01, 0.03), (32, 512), 5),
+                                     (9, (-1.5, 2.0, 0.1, -0.02, 0.015, 1.1), (16, 300), 12)):
+        ref = synth3d.lidar_scan(seed, pose, shape[0], shape[1], 0.02, scene_seed=scene).astype(np.float32)
+        x, y, z = (t.cpu().numpy() for t in synth_dev.lidar_scan3d(seed, pose, shape[0], shape[1], 0.02, scene_seed=scene))
+        got = np.stack([x, y, z], axis=1)
+        err = np.abs(got - ref).max(axis=1)
+        assert (err > 1e-5).sum() <= 4, ((err > 1e-5).sum(), err.max())
+        assert np.median(err) < 2e-6
