@@ -67,19 +67,25 @@ constexpr int kB3LdsBytes = 160 * 1024;
 constexpr int kB3RecBytes = 36;                         // per slot: float4 (mean, xx) + float4 (xy xz yy yz) + float (zz); a valid
                                                         // record has xx > 0 (Sigma^-1 is positive definite), the dummy record 0 is all zero
 static_assert(sizeof(LineSearch3) <= 128 && (kB3Idx % 16) == 0 && (kB3Bc % 16) == 0, "carve");
-// slab of one workgroup: u32 slot_n[S], u32 slot_key[S], u64 sums[9][S]
+// slab of one workgroup: u32 slot_n[S], u32 slot_key[S], u64 sums[9][S], overflow records
 constexpr int kB3SlabN = 0;
 constexpr int kB3SlabKey = kB3SlabN + kB3MaxSlots * 4;
 constexpr int kB3SlabSums = kB3SlabKey + kB3MaxSlots * 4;
-constexpr int kB3SlabBytes = kB3SlabSums + 9 * kB3MaxSlots * 8;
+// records beyond the LDS carve (a pair with a few more occupied voxels than fit keeps the first ones on chip, the
+// rest here, gathered through L2): float4 [S], float4 [S], float [S]
+constexpr int kB3SlabRecA = kB3SlabSums + 9 * kB3MaxSlots * 8;
+constexpr int kB3SlabRecB = kB3SlabRecA + kB3MaxSlots * 16;
+constexpr int kB3SlabRecC = kB3SlabRecB + kB3MaxSlots * 16;
+constexpr int kB3SlabBytes = kB3SlabRecC + kB3MaxSlots * 4;
 
 // Second variant, for the pairs whose voxel grid does not fit the LDS carve (a scan against a wide or finely
 // gridded map): the same code with every table in a per-workgroup slab of global memory - u32 voxel -> slot
 // table (also the counts of the build), per-slot counts / keys / nine sums (global 64-bit atomics, one pass),
 // 40-byte records gathered through L2.  It runs on kG3Blocks workgroups and only on the pairs k_batch3 handed over.
-constexpr int kG3MaxCells = 1 << 21;                    // 2 097 152 voxels (e.g. 256 x 256 x 32)
-constexpr int kG3MaxSlots = 1 << 16;                    // occupied voxels (slot 0 is the dummy record)
-constexpr int kG3Blocks = 16;
+constexpr int kG3MaxCells = 1 << 20;                    // 1 048 576 voxels (e.g. 256 x 256 x 16)
+constexpr int kG3MaxSlots = 1 << 15;                    // occupied voxels (slot 0 is the dummy record)
+constexpr int kG3Blocks = 64;                           // a pair costs a workgroup here about twice what it costs on chip: the
+                                                        // variant is slow per batch only for lack of workgroups (slab memory)
 constexpr size_t kG3Idx = 0;                                                  // u32 [MaxCells]
 constexpr size_t kG3SlotN = kG3Idx + (size_t)kG3MaxCells * 4;                 // u32 [MaxSlots]
 constexpr size_t kG3SlotKey = kG3SlotN + (size_t)kG3MaxSlots * 4;             // u32 [MaxSlots]
@@ -87,7 +93,7 @@ constexpr size_t kG3Sums = kG3SlotKey + (size_t)kG3MaxSlots * 4;              //
 constexpr size_t kG3RecA = kG3Sums + (size_t)9 * kG3MaxSlots * 8;             // float4 [MaxSlots]
 constexpr size_t kG3RecB = kG3RecA + (size_t)kG3MaxSlots * 16;                // float4 [MaxSlots]
 constexpr size_t kG3RecC = kG3RecB + (size_t)kG3MaxSlots * 16;                // float [MaxSlots] (region sized for 8 B each)
-constexpr size_t kG3SlabBytes = kG3RecC + (size_t)kG3MaxSlots * 8;            // 15.7 MB
+constexpr size_t kG3SlabBytes = kG3RecC + (size_t)kG3MaxSlots * 8;            // 7.9 MB
 
 constexpr int kTgt3Unroll = 4;
 template <typename F>
@@ -402,13 +408,20 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   int nslot = 0;
   int s = block_excl_scan<Cfg1024>(local, s_scan, &nslot);
   nslot = __builtin_amdgcn_readfirstlane(nslot);
-  if (nslot + 1 > slot_cap || nslot > kS || nslot < 1) {   // uniform (record 0 is the dummy)
+  // On chip, a pair with more occupied voxels than records fit keeps the first slot_cap records in LDS and the rest in
+  // the slab ("overflow": gathered through L2, a few percent of the lookups) as long as the slab bound holds.
+  const bool overflow = !GLOBAL && nslot + 1 > slot_cap;                               // uniform
+  if (nslot > kS || nslot < 1 || (GLOBAL && nslot + 1 > slot_cap) ||
+      (!GLOBAL && 8 * nslot > kB3LdsBytes - rec_base)) {   // (record 0 is the dummy; one sum per slot must fit a build pass)
     if (tid == 0) {
       if (!GLOBAL && nslot >= 1 && a.fb_marks) a.fb_marks[pair] = 1;                  // too many occupied voxels for the carve
       else write_result3(out, pose, nullptr, nullptr, 0.0, iter_base, 0, nslot < 1 ? 4 : kStatusCapacity);
     }
     return;
   }
+  float4* ovA = reinterpret_cast<float4*>(slab + kB3SlabRecA);       // record of slot s >= slot_cap at [s - slot_cap]
+  float4* ovB = reinterpret_cast<float4*>(slab + kB3SlabRecB);
+  float* ovC = reinterpret_cast<float*>(slab + kB3SlabRecC);
   for (int k = c0; k < c1; ++k) {
     const unsigned int n = cnt[k];                 // (global variant: read before idx[k], the same word, is written)
     if (n >= (unsigned)minpts) {
@@ -509,12 +522,14 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
                             a.min_points, a.eig_ratio, ra, rb, rc);
       if (!ok) { ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = ra; rc = ra; }
       // finalise_sums3's record (mean | n, xx xy xz yy, yz zz) repacked into 9 floats
-      recA[sl + 1] = make_float4(ra.x, ra.y, ra.z, rb.x); recB[sl + 1] = make_float4(rb.y, rb.z, rb.w, rc.x); recC[sl + 1] = rc.y;
+      const float4 qa = make_float4(ra.x, ra.y, ra.z, rb.x), qb = make_float4(rb.y, rb.z, rb.w, rc.x);
+      if (sl + 1 < slot_cap) { recA[sl + 1] = qa; recB[sl + 1] = qb; recC[sl + 1] = rc.y; }
+      else { ovA[sl + 1 - slot_cap] = qa; ovB[sl + 1 - slot_cap] = qb; ovC[sl + 1 - slot_cap] = rc.y; }
       nvalid += ok ? 1 : 0;
     }
     if (tid == 0) { recA[0] = make_float4(0.f, 0.f, 0.f, 0.f); recB[0] = recA[0]; recC[0] = 0.f; }
     if (nvalid) atomicAdd(&misc[8], nvalid);
-    if constexpr (GLOBAL) __threadfence();         // records and table are read through L1 / L2 from here on
+    if (GLOBAL || overflow) __threadfence();       // records (and table) are read through L1 / L2 from here on
     __syncthreads();
   }
   if (__builtin_amdgcn_readfirstlane(misc[8]) < 1) {   // uniform
@@ -555,8 +570,10 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
           z[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, off, 0, 0));
         }
       };
-      // the U points of a set: all voxel lookups first (their LDS round trips overlap), then the sums
-      auto consume_set = [&](int base, const float* x, const float* y, const float* z) {
+      // the U points of a set: all voxel lookups first (their LDS round trips overlap), then the sums.  OV: some
+      // records live in the slab (uniform per pair, so the common loop carries nothing of it)
+      auto consume_set = [&](auto ov_tag, int base, const float* x, const float* y, const float* z) {
+        constexpr bool OV = decltype(ov_tag)::value;
         float yx[U], yy[U], yz[U], px[U], py[U], pz[U];
         bool in[U];
         float4 A4[U], B4[U];
@@ -581,20 +598,25 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
           const int key = in[u] ? ((iz * Hh + iy) * W + ix) : 0;
           int slot = (int)idx[key];
           if (!in[u]) slot = 0;
-          A4[u] = recA[slot]; B4[u] = recB[slot]; C1[u] = recC[slot];
+          if (OV && slot >= slot_cap) { A4[u] = ovA[slot - slot_cap]; B4[u] = ovB[slot - slot_cap]; C1[u] = ovC[slot - slot_cap]; }
+          else { A4[u] = recA[slot]; B4[u] = recB[slot]; C1[u] = recC[slot]; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
           accumulate_point3_map<MODE>(yx[u], yy[u], yz[u], px[u], py[u], pz[u], in[u], A4[u], B4[u], C1[u], d1, d2, nhd2, acc);
       };
-      if (ns > 0) {                                  // uniform
+      auto point_loop = [&](auto ov_tag) {
         load_set(tid, xa, ya, za);
         for (int i = tid; i < ns; i += 2 * kTrip) {
           load_set(i + kTrip, xb, yb, zb);
-          consume_set(i, xa, ya, za);
+          consume_set(ov_tag, i, xa, ya, za);
           load_set(i + 2 * kTrip, xa, ya, za);
-          if (i + kTrip < ns) consume_set(i + kTrip, xb, yb, zb);     // wave-uniform except at the tail
+          if (i + kTrip < ns) consume_set(ov_tag, i + kTrip, xb, yb, zb);     // wave-uniform except at the tail
         }
+      };
+      if (ns > 0) {                                  // uniform
+        if (overflow) point_loop(std::true_type{});
+        else point_loop(std::false_type{});
       }
     }
 #pragma unroll

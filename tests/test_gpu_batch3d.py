@@ -150,7 +150,7 @@ def test_batch3d_capacity_handover_on_the_device(gpu_lib, mode):
 
 
 def test_batch3d_beyond_the_global_tables(gpu_lib):
-    """0.1 m voxels over the 40 m room: 425 x 425 x 75 voxels exceed the global-memory variant too (2^21 voxels).
+    """0.1 m voxels over the 40 m room: 425 x 425 x 75 voxels exceed the global-memory variant too (2^20 voxels).
     The device entry point says so per pair; the host entry point re-runs the pair through the single-pair path."""
     from gtsam_ndt_amd.matcher import NdtBatch3D
     ds, T, S = _pairs(POSES[:2], [(32, 512), (16, 256)])
@@ -188,3 +188,26 @@ def test_batch3d_pyramid_and_device_entry(gpu_lib):
         assert r.status == 0 and e[:3].max() < 0.03 and e[3:].max() < 5e-3, (r.pose, t)
         assert r.pose == h.pose and r.iterations == h.iterations
         assert np.abs(np.array(f.pose) - t)[:3].max() > e[:3].max()       # the 1 m grid alone ends elsewhere
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_batch3d_records_beyond_the_carve_overflow_to_the_slab(gpu_lib, mode):
+    """0.9 m voxels on full-size scans: 48 x 48 x 10 voxels, 3 309 occupied - 127 more than the 3 182 records the LDS carve
+    holds beside that table.  The pair stays on the on-chip kernel: the last records live in the slab and are gathered
+    through L2.  Same results as the single-pair path; a second pair that fits rides along in the same launch."""
+    from gtsam_ndt_amd.matcher import NdtBatch3D
+    ds, T, S = _pairs(POSES[:2], [(64, 2048), (32, 512)])
+    inits = [d["init"] for d in ds]
+    kw = dict(cell_size=0.9, step_max_trans=0.9, hessian_mode=mode)
+    if mode == 1:
+        gn = _single(T, S, inits, cell_size=0.9, step_max_trans=0.9)
+        inits = [tuple(np.array(r.pose) + 1e-3 * np.array([1, -1, 0.5, 0.1, -0.1, 0.2])) for r in gn]
+        kw["fixed_iterations"] = 1
+    with NdtBatch3D(**kw) as b:
+        rb = b.align(T, S, inits)
+        rb2 = b.align(T, S, inits)
+    rs = _single(T, S, inits, **kw)
+    for x, x2, y in zip(rb, rb2, rs):
+        assert x.status == y.status and x.status in (0, 1)
+        _same(x, y, pose_tol=1e-5, h_tol=3e-3)
+        assert x.pose == x2.pose and np.array_equal(x.H, x2.H)
