@@ -410,8 +410,11 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   nslot = __builtin_amdgcn_readfirstlane(nslot);
   // On chip, a pair with more occupied voxels than records fit keeps the first slot_cap records in LDS and the rest in
   // the slab ("overflow": gathered through L2, a few percent of the lookups) as long as the slab bound holds.
-  const bool overflow = !GLOBAL && nslot + 1 > slot_cap;                               // uniform
-  if (nslot > kS || nslot < 1 || (GLOBAL && nslot + 1 > slot_cap) ||
+#ifndef NDT_B3_OVERFLOW
+#define NDT_B3_OVERFLOW 1          // 0 (tools only): over-capacity pairs always go to the global-table variant
+#endif
+  const bool overflow = NDT_B3_OVERFLOW && !GLOBAL && nslot + 1 > slot_cap;           // uniform
+  if (nslot > kS || nslot < 1 || ((GLOBAL || !NDT_B3_OVERFLOW) && nslot + 1 > slot_cap) ||
       (!GLOBAL && 8 * nslot > kB3LdsBytes - rec_base)) {   // (record 0 is the dummy; one sum per slot must fit a build pass)
     if (tid == 0) {
       if (!GLOBAL && nslot >= 1 && a.fb_marks) a.fb_marks[pair] = 1;                  // too many occupied voxels for the carve
