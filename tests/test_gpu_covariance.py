@@ -80,3 +80,46 @@ def test_calibration_function_is_s_hinv_s(ndt_lib):
     assert ndt_lib.ndt2d_calibrated_covariance(bad.ctypes.data_as(C.POINTER(C.c_double)), 0,
                                                out.ctypes.data_as(C.POINTER(C.c_double))) == L.NDT_DEGENERATE_HESSIAN
     assert not out.any()
+
+
+@gpu
+def test_3d_inverse_hessian_against_the_empirical_scatter(gpu_lib):
+    """The same Monte-Carlo in 3D (config-5 scans; the pair is placed at a random pose in the room every time, so the
+    beams sample other surface points, fresh range noise; all alignments in one ndt3d_batch call).  Unlike 2D, the
+    plain H^-1 of the Gauss-Newton form is a fair covariance at this density (48 points per occupied voxel): every
+    direction within a factor 0.2 .. 5 of the empirical one, so MatchResult3::covariance needs no inflation there
+    (docs/ALGORITHM.md section 2.9 has the sparse and noisy cases, where it does)."""
+    import math
+    import torch
+    from gtsam_ndt_amd import synth3d, synth_dev
+    from gtsam_ndt_amd.matcher import NdtBatch3D
+    R3, n_elev, n_azim = 160, 64, 2048
+    n = n_elev * n_azim
+    rel = tuple(0.5 * np.array(synth3d.T_STAR_3D))
+    R_rel, t_rel = synth3d.rotation(*rel[3:]), np.array(rel[:3])
+    euler = lambda M: (math.atan2(M[2, 1], M[2, 2]), -math.asin(M[2, 0]), math.atan2(M[1, 0], M[0, 0]))
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    t = [torch.empty(R3 * n, dtype=torch.float32, device=dev) for _ in range(3)]
+    s = [torch.empty(R3 * n, dtype=torch.float32, device=dev) for _ in range(3)]
+    for r in range(R3):
+        A = (rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-0.05, 0.05), rng.uniform(-0.01, 0.01),
+             rng.uniform(-0.01, 0.01), rng.uniform(-0.3, 0.3))
+        RA = synth3d.rotation(*A[3:])
+        B = tuple(np.array(A[:3]) + RA @ t_rel) + euler(RA @ R_rel)          # B = A o rel: the relative pose is `rel` every time
+        sl = slice(r * n, (r + 1) * n)
+        synth_dev.lidar_scan3d(5000 + 2 * r, A, n_elev, n_azim, 0.02, out=tuple(c[sl] for c in t))
+        synth_dev.lidar_scan3d(5001 + 2 * r, B, n_elev, n_azim, 0.02, out=tuple(c[sl] for c in s))
+    off = torch.arange(R3 + 1, dtype=torch.int64, device=dev) * n
+    init = torch.zeros((R3, 6), dtype=torch.float64, device=dev)
+    with NdtBatch3D() as b:
+        rows = b.decode(b.align_dev(t, off, s, off, init))
+    assert all(r.status == 0 for r in rows)
+    est = np.array([r.pose for r in rows])
+    assert np.abs(est.mean(0) - np.array(rel)).max() < 2e-3
+    C = np.cov(est.T)
+    lo, hi = np.inf, 0.0
+    for r in rows[:40]:
+        ev = np.linalg.eigvals(np.linalg.solve(np.linalg.inv(r.H), C)).real
+        lo, hi = min(lo, ev.min()), max(hi, ev.max())
+    assert 0.2 < lo and hi < 5.0, (lo, hi)
