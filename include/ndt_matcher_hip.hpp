@@ -424,6 +424,43 @@ inline bool invert6(const double* H, double* C) {
   return true;
 }
 
+// R = Rz(yaw) Ry(pitch) Rx(roll), row-major
+inline std::array<double, 9> rotationOf(const Pose3& p) {
+  const double ca = std::cos(p.roll), sa = std::sin(p.roll), cb = std::cos(p.pitch), sb = std::sin(p.pitch),
+               cg = std::cos(p.yaw), sg = std::sin(p.yaw);
+  return {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
+          sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
+          -sb, cb * sa, cb * ca};
+}
+
+// MatchResult3::covariance is for additive errors on (tx, ty, tz, roll, pitch, yaw).  A factor on SE(3) (e.g.
+// gtsam::BetweenFactor<gtsam::Pose3>, whose tangent vector is (rotation; translation) in the measured pose's own
+// frame) wants C_local = J C J' with, to first order, omega_body = E (d roll, d pitch, d yaw)',
+// E = [[1, 0, -sin pitch], [0, cos roll, sin roll cos pitch], [0, -sin roll, cos roll cos pitch]], and rho = R' dt.
+// Returned row-major 6x6 in the order (omega_x, omega_y, omega_z, rho_x, rho_y, rho_z).
+inline std::array<double, 36> covarianceInLocalFrame3(const Pose3& pose, const std::array<double, 36>& cov) {
+  const std::array<double, 9> R = rotationOf(pose);
+  const double ca = std::cos(pose.roll), sa = std::sin(pose.roll), cb = std::cos(pose.pitch), sb = std::sin(pose.pitch);
+  double J[36] = {0};
+  const double E[9] = {1.0, 0.0, -sb, 0.0, ca, sa * cb, 0.0, -sa, ca * cb};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      J[6 * i + 3 + j] = E[3 * i + j];            // omega <- euler increments
+      J[6 * (3 + i) + j] = R[3 * j + i];          // rho <- R' dt
+    }
+  double T[36];
+  std::array<double, 36> out{};
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      T[6 * i + j] = 0.0;
+      for (int k = 0; k < 6; ++k) T[6 * i + j] += J[6 * i + k] * cov[6 * k + j];
+    }
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j)
+      for (int k = 0; k < 6; ++k) out[6 * i + j] += T[6 * i + k] * J[6 * j + k];
+  return out;
+}
+
 class NdtMatcherHip3 {
  public:
   static ndt3d_params defaultParams() { ndt3d_params p; ndt3d_default_params(&p); return p; }

@@ -1,6 +1,7 @@
 // C++ adapter smoke test: reads two scans (raw float32 files written by the pytest driver),
 // aligns them through ndt::NdtMatcherHip / ndt::NdtBatchHip and prints the result as JSON-ish
 // text that the driver compares with the oracle.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -132,6 +133,25 @@ int main(int argc, char** argv) {
       for (int k = 0; k < 6; ++k) ic += r3.information[k] * r3.covariance[6 * k];
       std::printf("three_d %.9g %.9g %.9g %.9g %.9g %.9g %d %d %.6f\n", r3.pose.x, r3.pose.y, r3.pose.z, r3.pose.roll,
                   r3.pose.pitch, r3.pose.yaw, r3.iterations, r3.status, ic);
+      {
+        // covarianceInLocalFrame3: its Jacobian against a finite perturbation of the pose - the body-frame rotation
+        // vector of R0' R1 and R0' (t1 - t0) for a small additive step d on (t, roll, pitch, yaw)
+        ndt::Pose3 p0; p0.x = 0.3; p0.y = -0.2; p0.z = 0.1; p0.roll = 0.2; p0.pitch = -0.3; p0.yaw = 0.7;
+        const double d[6] = {1e-6, -2e-6, 1.5e-6, 2e-6, -1e-6, 1.2e-6};
+        ndt::Pose3 p1 = p0; p1.x += d[0]; p1.y += d[1]; p1.z += d[2]; p1.roll += d[3]; p1.pitch += d[4]; p1.yaw += d[5];
+        const auto R0 = ndt::rotationOf(p0), R1 = ndt::rotationOf(p1);
+        double M[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { M[3 * i + j] = 0; for (int k = 0; k < 3; ++k) M[3 * i + j] += R0[3 * k + i] * R1[3 * k + j]; }
+        const double want[6] = {0.5 * (M[7] - M[5]), 0.5 * (M[2] - M[6]), 0.5 * (M[3] - M[1]),
+                                R0[0] * d[0] + R0[3] * d[1] + R0[6] * d[2], R0[1] * d[0] + R0[4] * d[1] + R0[7] * d[2],
+                                R0[2] * d[0] + R0[5] * d[1] + R0[8] * d[2]};
+        std::array<double, 36> dd{};                         // covariance of a deterministic step: d d'
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) dd[6 * i + j] = d[i] * d[j];
+        const auto loc3 = ndt::covarianceInLocalFrame3(p0, dd);
+        double worst = 0.0;
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) worst = std::max(worst, std::fabs(loc3[6 * i + j] - want[i] * want[j]));
+        std::printf("localcov3 %.3g\n", worst / 1e-12);       // relative to |d|^2
+      }
       // the same pair twice through the 3D batch (one of them from a displaced guess): both must land on the single-pair pose
       ndt::NdtBatchHip3 b3;
       const ndt::NdtBatchHip3::Cloud tc{x.data(), y.data(), z.data(), x.size()}, sc{qx.data(), qy.data(), qz.data(), qx.size()};

@@ -84,6 +84,7 @@ def test_adapter_matches_oracle(exe, tmp_path, gpu_lib):
     assert int(lines["three_d"][7]) in (0, 1)
     assert np.abs(p3 - np.array([0.20, -0.15, 0.05, 0.0, 0.0, 0.02])).max() < 2e-2, p3
     assert abs(float(lines["three_d"][8]) - 1.0) < 1e-6
+    assert float(lines["localcov3"][0]) < 1e-4          # J d d' J' equals the finite step's tangent vector squared to first order
     # ... and through the 3D batch (NdtBatchHip3), from the identity and from a displaced guess
     b0, b1 = (np.array([float(v) for v in lines[k][:6]]) for k in ("three_d_batch0", "three_d_batch1"))
     assert int(lines["three_d_batch0"][7]) in (0, 1) and int(lines["three_d_batch1"][7]) in (0, 1)
