@@ -477,7 +477,8 @@ int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
  * keeps the pair's tables in global memory (up to 2^20 voxels - e.g. 256 x 256 x 16 - and 32 767 occupied; a pair
  * that only has a few more occupied voxels than fit stays on chip with its last records in global memory).
  * Beyond that a pair gets status NDT_ERR_CAPACITY from the _dev entry point, and the host-pointer entry
- * point re-runs it through the single-pair path transparently.  Stream semantics as ndt2d_batch_align_dev. */
+ * point re-runs it through the single-pair path transparently.  Stream semantics as ndt2d_batch_align_dev.
+ * A context holds about 0.6 GB of device memory (per-workgroup slabs of the build and of the global-memory variant). */
 typedef struct ndt3d_batch ndt3d_batch;
 int32_t ndt3d_batch_create(const ndt3d_params* p, int32_t device_id, ndt3d_batch** out);
 /* coarse-to-fine over the batch, as ndt2d_batch_create_pyramid (levels coarse to fine, at most 8) */
