@@ -183,6 +183,12 @@ SIGNATURES = {
     "ndt3d_batch_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "ndt3d_batch_stream": (_vp, [_vp]),
     "ndt3d_batch_wait_stream": (C.c_int32, [_vp, _vp]),
+    "ndt3d_multi_create": (C.c_int32, [C.POINTER(Params2D), _vp, C.c_int32, C.POINTER(_vp)]),
+    "ndt3d_multi_create_pyramid": (C.c_int32, [C.POINTER(Params2D), C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),
+    "ndt3d_multi_destroy": (C.c_int32, [_vp]),
+    "ndt3d_multi_device_count": (C.c_int32, [_vp]),
+    "ndt3d_multi_align": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ndt3d_multi_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_size_t), _vp]),
 }
 
 _lib = None

@@ -799,6 +799,93 @@ class NdtBatch3D:
         return cls._results(a.reshape(-1), a.shape[0])
 
 
+class NdtMulti3D:
+    """The 3D loop-closure batch over several devices from one process (ndt3d_multi_* of include/ndt_hip.h): one
+    NdtBatch3D-like context and one host thread per device; `align` takes host pairs, `align_dev` device-resident
+    shards whose result rows are exchanged with one RCCL all-gather."""
+
+    def __init__(self, devices=None, levels=None, **overrides):
+        self._lib = L.load()
+        self.params = default_params3d(**overrides)
+        h = C.c_void_p()
+        ids, n = (None, 0) if devices is None else ((C.c_int32 * len(devices))(*[int(d) for d in devices]), len(devices))
+        if levels is not None:
+            self._levels, nl = _as_levels(levels)
+            self.params = self._levels[nl - 1]
+            L.check(self._lib.ndt3d_multi_create_pyramid(self._levels, nl, ids, n, C.byref(h)), "ndt3d_multi_create_pyramid")
+        else:
+            L.check(self._lib.ndt3d_multi_create(C.byref(self.params), ids, n, C.byref(h)), "ndt3d_multi_create")
+        self._h = h
+        self.last_shard_stride = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndt3d_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def device_count(self) -> int:
+        return int(self._lib.ndt3d_multi_device_count(self._h))
+
+    def align(self, targets, sources, inits):
+        """targets / sources: lists of (x, y, z) numpy triples; inits [n][6]; results in pair order."""
+        n = len(targets)
+        toff = np.zeros(n + 1, dtype=np.uint64)
+        soff = np.zeros(n + 1, dtype=np.uint64)
+        toff[1:] = np.cumsum([len(t[0]) for t in targets])
+        soff[1:] = np.cumsum([len(s[0]) for s in sources])
+        t = [np.concatenate([_host_f32(c[a]) for c in targets]) for a in range(3)]
+        s = [np.concatenate([_host_f32(c[a]) for c in sources]) for a in range(3)]
+        init = np.ascontiguousarray(inits, dtype=np.float64).reshape(n, 6)
+        out = np.zeros(n * RESULT3_DOUBLES, dtype=np.float64)
+        L.check(self._lib.ndt3d_multi_align(self._h, t[0].ctypes.data, t[1].ctypes.data, t[2].ctypes.data, toff.ctypes.data,
+                                            s[0].ctypes.data, s[1].ctypes.data, s[2].ctypes.data, soff.ctypes.data,
+                                            init.ctypes.data, n, out.ctypes.data), "ndt3d_multi_align")
+        return NdtBatch3D._results(out, n)
+
+    def align_dev(self, shards):
+        """shards[d] = dict(t=(x, y, z), toff, s=(x, y, z), soff, init) of torch tensors resident on device d (the layout
+        of NdtBatch3D.align_dev; None for an empty shard).  Returns the results in global pair order."""
+        import torch
+        nd = self.device_count
+        if len(shards) != nd:
+            raise ValueError("one shard per device context")
+        keys = ("tx", "ty", "tz", "toff", "sx", "sy", "sz", "soff", "init")
+        ptr = {k: (C.c_void_p * nd)() for k in keys}
+        n_pairs = (C.c_size_t * nd)()
+        for d, sh in enumerate(shards):
+            n_pairs[d] = 0 if sh is None else int(sh["toff"].numel()) - 1
+            if sh is None:
+                continue
+            flat = {"tx": sh["t"][0], "ty": sh["t"][1], "tz": sh["t"][2], "toff": sh["toff"], "sx": sh["s"][0], "sy": sh["s"][1],
+                    "sz": sh["s"][2], "soff": sh["soff"], "init": sh["init"]}
+            for k, t in flat.items():
+                want = torch.int64 if k in ("toff", "soff") else (torch.float64 if k == "init" else torch.float32)
+                if not (t.is_cuda and t.dtype == want and t.is_contiguous()):
+                    raise ValueError("shard tensors must be contiguous CUDA tensors of the documented dtypes")
+                ptr[k][d] = t.data_ptr()
+            torch.cuda.synchronize(flat["tx"].device)        # the contexts' streams are not torch's: finish the producers
+        total = sum(n_pairs)
+        out = np.zeros(total * RESULT3_DOUBLES, dtype=np.float64)
+        stride = C.c_size_t(0)
+        L.check(self._lib.ndt3d_multi_align_dev(self._h, *[ptr[k] for k in keys], n_pairs, None, C.byref(stride), out.ctypes.data),
+                "ndt3d_multi_align_dev")
+        self.last_shard_stride = int(stride.value)
+        return NdtBatch3D._results(out, total)
+
+
 def magnusson_constants(outlier_ratio: float, cell_size: float, dim: int = 2):
     """(d1, d2) of Magnusson's outlier-mixture score for ndt2d_params / ndt3d_params."""
     d1, d2 = C.c_double(), C.c_double()

@@ -493,6 +493,27 @@ int32_t ndt3d_batch_align_dev(ndt3d_batch* b, const float* d_tx, const float* d_
 void* ndt3d_batch_stream(ndt3d_batch* b);
 int32_t ndt3d_batch_wait_stream(ndt3d_batch* b, void* producer_stream);
 
+/* The 3D batch over several devices from ONE host process: ndt2d_multi_* for ndt3d_batch contexts (one context and one
+ * host thread per device, contiguous work-balanced shards by ndt2d_multi_plan's rule).  ndt3d_multi_align takes host
+ * pointers laid out as ndt3d_batch_align; ndt3d_multi_align_dev takes per-device device pointers (arrays of n_devices
+ * pointers, shard d on device d, n_pairs[d] pairs, 0 allowed), aligns every shard on its context's stream and
+ * exchanges the 408-byte result rows with ONE grouped ncclAllGather - layout, ownership and error codes as
+ * ndt2d_multi_align_dev. */
+typedef struct ndt3d_multi ndt3d_multi;
+int32_t ndt3d_multi_create(const ndt3d_params* p, const int32_t* device_ids, int32_t n_devices, ndt3d_multi** out);
+int32_t ndt3d_multi_create_pyramid(const ndt3d_params* levels, int32_t n_levels, const int32_t* device_ids,
+                                   int32_t n_devices, ndt3d_multi** out);
+int32_t ndt3d_multi_destroy(ndt3d_multi* m);
+int32_t ndt3d_multi_device_count(const ndt3d_multi* m);
+int32_t ndt3d_multi_align(ndt3d_multi* m, const float* tx, const float* ty, const float* tz, const uint64_t* toff,
+                          const float* sx, const float* sy, const float* sz, const uint64_t* soff, const double* init,
+                          size_t n_pairs, ndt3d_result* results);
+int32_t ndt3d_multi_align_dev(ndt3d_multi* m, const float* const* d_tx, const float* const* d_ty, const float* const* d_tz,
+                              const uint64_t* const* d_toff, const float* const* d_sx, const float* const* d_sy,
+                              const float* const* d_sz, const uint64_t* const* d_soff, const double* const* d_init,
+                              const size_t* n_pairs, ndt3d_result** d_results_all, size_t* shard_stride,
+                              ndt3d_result* results);
+
 #ifdef __cplusplus
 }
 #endif

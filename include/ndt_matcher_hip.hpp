@@ -612,5 +612,23 @@ class NdtBatchHip3 {
   ndt3d_batch* b_ = nullptr;
 };
 
+// The 3D candidates over several GPUs owned by this process (ndt3d_multi_*): host pairs split into contiguous
+// work-balanced shards, one context and one host thread per device.
+class NdtMultiHip3 {
+ public:
+  explicit NdtMultiHip3(const ndt3d_params& params = NdtMatcherHip3::defaultParams(), const std::vector<int32_t>& devices = {}) {
+    const int32_t st = ndt3d_multi_create(&params, devices.empty() ? nullptr : devices.data(), static_cast<int32_t>(devices.size()), &m_);
+    if (st != NDT_OK) throw NdtError(st, "ndt3d_multi_create");
+  }
+  ~NdtMultiHip3() { ndt3d_multi_destroy(m_); }
+  NdtMultiHip3(const NdtMultiHip3&) = delete;
+  NdtMultiHip3& operator=(const NdtMultiHip3&) = delete;
+  int deviceCount() const { return ndt3d_multi_device_count(m_); }
+  ndt3d_multi* raw() { return m_; }     // ndt3d_multi_align / ndt3d_multi_align_dev (RCCL gather) take it
+
+ private:
+  ndt3d_multi* m_ = nullptr;
+};
+
 }  // namespace ndt
 #endif  // NDT_MATCHER_HIP_HPP_

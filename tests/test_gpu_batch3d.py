@@ -211,3 +211,35 @@ def test_batch3d_records_beyond_the_carve_overflow_to_the_slab(gpu_lib, mode):
         assert x.status == y.status and x.status in (0, 1)
         _same(x, y, pose_tol=1e-5, h_tol=3e-3)
         assert x.pose == x2.pose and np.array_equal(x.H, x2.H)
+
+
+def test_multi_device_3d_context_host_shards_and_rccl_gather(gpu_lib):
+    """ndt3d_multi_*: the host-pointer form with device 0 listed twice (two contexts, two host threads, work-balanced
+    contiguous shards) and the device-resident form with its RCCL all-gather (one GPU here: one rank) equal the
+    single-context batch bit for bit."""
+    import torch
+    from gtsam_ndt_amd import _lib as L, dist as nd
+    from gtsam_ndt_amd.matcher import NdtBatch3D, NdtMulti3D
+    ds, T, S = _pairs()
+    inits = [d["init"] for d in ds]
+    with NdtBatch3D() as b:
+        want = b.align(T, S, inits)
+    with NdtMulti3D(devices=[0, 0]) as m:
+        assert m.device_count == 2
+        got = m.align(T, S, inits)
+    for a, w in zip(got, want):
+        assert a.status == w.status and a.pose == w.pose and np.array_equal(a.H, w.H) and a.iterations == w.iterations
+    b3 = nd.pack_pairs3d(ds)
+    cu = lambda v: torch.from_numpy(v).cuda()
+    shard = {"t": [cu(v) for v in b3["t"]], "toff": cu(b3["toff"]), "s": [cu(v) for v in b3["s"]], "soff": cu(b3["soff"]),
+             "init": cu(b3["init"])}
+    with NdtMulti3D(devices=[0]) as m:
+        got = m.align_dev([shard])
+        assert m.last_shard_stride == len(ds)
+        again = m.align_dev([shard])                  # communicator and buffers are reused
+    for a, w, c in zip(got, want, again):
+        assert a.status == w.status and a.pose == w.pose == c.pose and np.array_equal(a.H, w.H)
+    with NdtMulti3D(devices=[0, 0]) as m:             # a device cannot gather with itself
+        with pytest.raises(L.NdtError) as e:
+            m.align_dev([shard, None])
+        assert e.value.code == L.NDT_ERR_INVALID_ARG
