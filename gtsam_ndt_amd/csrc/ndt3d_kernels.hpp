@@ -260,6 +260,11 @@ __global__ __launch_bounds__(kBlock) void k_finalise3(Grid3Dev g, int min_points
 
 // ---------------------------------------------------------------------------- solve (6x6)
 __device__ __forceinline__ bool solve6(const double* A /*6x6 row-major, symmetric*/, const double* g, double* x) {
+#if defined(NDT_EXP_DIAG_SOLVE3)      // tools only: what the 6x6 factorisation costs per launch (wrong steps, right timing)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = -g[i] / fmax(fabs(A[7 * i]), 1e-12);
+  return true;
+#endif
   double dg[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) dg[i] = fmax(fabs(A[7 * i]), 1e-12);
