@@ -123,6 +123,7 @@ SIGNATURES = {
     "ndt2d_get_grid_info": (C.c_int32, [_vp, C.POINTER(GridInfo2D)]),
     "ndt2d_get_grid": (C.c_int32, [_vp, _vp, _vp, _vp]),
     "ndt2d_evaluate": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval2D)]),
+    "ndt2d_evaluate_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval2D)]),
     "ndt2d_align": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result2D)]),
     "ndt2d_align_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result2D)]),
     "ndt2d_align_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp]),
@@ -168,6 +169,7 @@ SIGNATURES = {
     "ndt3d_get_grid_info": (C.c_int32, [_vp, C.POINTER(GridInfo3D)]),
     "ndt3d_get_grid": (C.c_int32, [_vp, _vp, _vp, _vp]),
     "ndt3d_evaluate": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval3D)]),
+    "ndt3d_evaluate_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval3D)]),
     "ndt3d_align": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result3D)]),
     "ndt3d_align_dev_async": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp]),
     "ndt3d_align_finish": (C.c_int32, [_vp, C.POINTER(Result3D)]),

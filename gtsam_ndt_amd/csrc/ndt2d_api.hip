@@ -1018,6 +1018,24 @@ int32_t ndt2d_evaluate(ndt2d_handle* h, const float* sx, const float* sy, size_t
   return NDT_OK;
 }
 
+// the same with the scan already on the device (order the handle behind its producer with ndt2d_wait_stream first)
+int32_t ndt2d_evaluate_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n, const double pose[3],
+                           ndt2d_eval* out) {
+  if (!h || !d_sx || !d_sy || !pose || !out || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  int32_t st = run_align(h, d_sx, d_sy, n, pose, /*fixed_override=*/1, /*check_every=*/0);
+  if (st != NDT_OK) return st;
+  st = fetch_state(h);
+  if (st != NDT_OK) return st;
+  std::memset(out, 0, sizeof(*out));
+  sym6_to_9(h->h_state->H, out->H);
+  for (int j = 0; j < 3; ++j) out->g[j] = h->h_state->g[j];
+  out->score = h->h_state->score;
+  out->n_hit = h->h_state->n_hit;
+  return NDT_OK;
+}
+
 int32_t ndt2d_align_trace(ndt2d_handle* h, const float* sx, const float* sy, size_t n, const double init_pose[3],
                           ndt2d_result* rows, int32_t capacity, int32_t* n_rows, ndt2d_result* out) {
   if (!h || !sx || !sy || !init_pose || !rows || capacity < 1 || !n_rows || n == 0 || n > kMaxSourcePoints)

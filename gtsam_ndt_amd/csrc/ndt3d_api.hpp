@@ -566,6 +566,21 @@ int32_t ndt3d_evaluate(ndt3d_handle* h, const float* sx, const float* sy, const 
   return NDT_OK;
 }
 
+int32_t ndt3d_evaluate_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                           const double pose[6], ndt3d_eval* out) {
+  if (!h || !d_sx || !d_sy || !d_sz || !pose || !out || n == 0) return NDT_ERR_INVALID_ARG;
+  if (!h->has_target) return NDT_ERR_NO_TARGET;
+  HIP_TRY(hipSetDevice(h->device));
+  const int32_t st = run_align3(h, d_sx, d_sy, d_sz, n, pose, 1);
+  if (st != NDT_OK) return st;
+  std::memset(out, 0, sizeof(*out));
+  unpack_h21(h->h_state->H, out->H);
+  for (int j = 0; j < 6; ++j) out->g[j] = h->h_state->g[j];
+  out->score = h->h_state->score;
+  out->n_hit = h->h_state->n_hit;
+  return NDT_OK;
+}
+
 int32_t ndt3d_align_dev_async(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
                               const double init_pose[6]) {
   if (!h || !d_sx || !d_sy || !d_sz || !init_pose) return NDT_ERR_INVALID_ARG;

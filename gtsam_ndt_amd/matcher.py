@@ -179,11 +179,16 @@ class NdtMatcher2D:
 
     # ---- (ii)+(iii) one evaluation
     def evaluate(self, sx, sy, pose):
-        sx, sy = _host_f32(sx), _host_f32(sy)
         p = (C.c_double * 3)(*[float(v) for v in pose])
         out = L.Eval2D()
-        L.check(self._lib.ndt2d_evaluate(self._h, sx.ctypes.data, sy.ctypes.data, sx.size, p, C.byref(out)),
-                "ndt2d_evaluate")
+        if _is_dev(sx):
+            n = sx.numel()
+            self.wait_stream()
+            L.check(self._lib.ndt2d_evaluate_dev(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), n, p, C.byref(out)), "ndt2d_evaluate_dev")
+        else:
+            sx, sy = _host_f32(sx), _host_f32(sy)
+            L.check(self._lib.ndt2d_evaluate(self._h, sx.ctypes.data, sy.ctypes.data, sx.size, p, C.byref(out)),
+                    "ndt2d_evaluate")
         return (np.array(out.H, dtype=np.float64).reshape(3, 3), np.array(out.g, dtype=np.float64),
                 float(out.score), int(out.n_hit))
 
@@ -613,11 +618,18 @@ class NdtMatcher3D:
         return count, mean, icov
 
     def evaluate(self, sx, sy, sz, pose):
-        sx, sy, sz = _host_f32(sx), _host_f32(sy), _host_f32(sz)
         p = (C.c_double * 6)(*[float(v) for v in pose])
         out = L.Eval3D()
-        L.check(self._lib.ndt3d_evaluate(self._h, sx.ctypes.data, sy.ctypes.data, sz.ctypes.data, sx.size, p,
-                                         C.byref(out)), "ndt3d_evaluate")
+        if _is_dev(sx):
+            import torch
+            n = sx.numel()
+            L.check(self._lib.ndt3d_wait_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ndt3d_wait_stream")
+            L.check(self._lib.ndt3d_evaluate_dev(self._h, _dev_ptr(sx, n), _dev_ptr(sy, n), _dev_ptr(sz, n), n, p, C.byref(out)),
+                    "ndt3d_evaluate_dev")
+        else:
+            sx, sy, sz = _host_f32(sx), _host_f32(sy), _host_f32(sz)
+            L.check(self._lib.ndt3d_evaluate(self._h, sx.ctypes.data, sy.ctypes.data, sz.ctypes.data, sx.size, p,
+                                             C.byref(out)), "ndt3d_evaluate")
         return (np.array(out.H, dtype=np.float64).reshape(6, 6), np.array(out.g, dtype=np.float64),
                 float(out.score), int(out.n_hit))
 

@@ -164,6 +164,10 @@ int32_t ndt2d_get_grid(ndt2d_handle* h, int32_t* count, float* mean_xy, float* i
 int32_t ndt2d_evaluate(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
                        const double pose[3], ndt2d_eval* out);
 
+/* the scan already on the device (ndt2d_wait_stream orders the handle behind its producer) */
+int32_t ndt2d_evaluate_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n, const double pose[3],
+                           ndt2d_eval* out);
+
 /* ---- full alignment: rows a4-a9 ------------------------------------------------------ */
 int32_t ndt2d_align(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
                     const double init_pose[3], ndt2d_result* out);
@@ -431,6 +435,8 @@ int32_t ndt3d_get_grid_info(ndt3d_handle* h, ndt3d_grid_info* info);
 int32_t ndt3d_get_grid(ndt3d_handle* h, int32_t* count, float* mean_xyz, float* icov6);
 int32_t ndt3d_evaluate(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n,
                        const double pose[6], ndt3d_eval* out);
+int32_t ndt3d_evaluate_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,
+                           const double pose[6], ndt3d_eval* out);
 int32_t ndt3d_align(ndt3d_handle* h, const float* sx, const float* sy, const float* sz, size_t n,
                     const double init_pose[6], ndt3d_result* out);
 int32_t ndt3d_align_dev(ndt3d_handle* h, const float* d_sx, const float* d_sy, const float* d_sz, size_t n,

@@ -89,3 +89,23 @@ def test_3d_align_waits_for_the_producer(gpu_lib):
         late = [v + 0.0 for v in s]
         got = m.align(*late, d["init"])
     assert got.pose == want.pose
+
+
+def test_evaluate_takes_device_arrays(gpu_lib):
+    """ndt2d_evaluate_dev / ndt3d_evaluate_dev: the evaluation of a scan that is already on the device equals the one of
+    its host copy bit for bit (same kernels, no upload)."""
+    import torch
+    from gtsam_ndt_amd import synth, synth3d
+    from gtsam_ndt_amd.matcher import NdtMatcher2D, NdtMatcher3D
+    d = synth.make_pair(2, n_tgt=30000, n_src=20000)
+    with NdtMatcher2D() as m:
+        m.set_target(d["tx"], d["ty"])
+        a = m.evaluate(d["sx"], d["sy"], d["pose"])
+        b = m.evaluate(torch.from_numpy(d["sx"]).cuda(), torch.from_numpy(d["sy"]).cuda(), d["pose"])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    d3 = synth3d.make_pair3d(n_elev=16, n_azim=256)
+    with NdtMatcher3D() as m:
+        m.set_target(d3["tx"], d3["ty"], d3["tz"])
+        a = m.evaluate(d3["sx"], d3["sy"], d3["sz"], d3["pose"])
+        b = m.evaluate(*(torch.from_numpy(d3[k]).cuda() for k in ("sx", "sy", "sz")), d3["pose"])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
