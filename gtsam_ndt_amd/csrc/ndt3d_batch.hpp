@@ -5,15 +5,17 @@
 //     table takes 2 bytes per voxel, the records get the rest (config 5: 44 x 44 x 9 = 17 424
 //     voxels, 2 706 occupied: 35 KB + 97 KB of the 160 KB; up to 3 494 occupied voxels fit that grid);
 //   - the nine exact fixed-point sums of a voxel (72 bytes per slot) do not fit next to the table,
-//     so the build adds them up in LDS four at a time (the records' 36 bytes per slot hold
-//     four; two passes over the target) and parks each pass in a per-workgroup slab of global memory;
-//     the finalise reads them back once and writes the records into LDS;
+//     so the build adds them up in LDS as many at a time as the records' region holds (five for
+//     config 5: two passes over the target; four for a grid that fills the carve: three) and parks
+//     each pass in a per-workgroup slab of global memory; the finalise reads them back once and
+//     writes the records into LDS (a pair with a few more occupied voxels than records fit keeps
+//     the rest in the slab; bigger grids go to k_batch3_fallback, every table in global memory);
 //   - source points stream from HBM/L2 once per iteration; the 29 (Newton: 38) sums are reduced
 //     per wave (DPP) -> LDS -> wave 0, which also does the 6x6 solve: two workgroup barriers per
 //     iteration, no kernel boundary.
 // Records and update rule are the single-pair 3D path's: finalise_sums3 and gn_update3 are the functions
 // k_finalise3 / k_iterate3 use, the slab sums are the integers k_accumulate3 forms.  The per-point sums are
-// taken in the map frame (accumulate_point3_map below: the same Hessian and gradient with a fifth fewer
+// taken in the map frame (accumulate_point3_map below: the same Hessian and gradient with a quarter fewer
 // instructions), so a pair agrees with its single-pair alignment to float32 rounding, not bit for bit.
 #pragma once
 #include "ndt2d_batch.hpp"
