@@ -1,0 +1,62 @@
+"""Soak of the 3D batch (k_batch3 with its overflow records, k_batch3_fallback): random batches - 1..24 pairs, clouds of
+0..30000 points cut from ray-cast scans, random voxel sizes so that all three table placements occur, NaN-laced
+points, both Hessian forms - each run twice (determinism) and spot-checked against the single-pair path."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+from gtsam_ndt_amd import synth3d, synth_dev
+from gtsam_ndt_amd.matcher import NdtBatch3D, NdtMatcher3D
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(1)
+base = []
+for k in range(6):
+    p = tuple(np.array(synth3d.T_STAR_3D) * rng.uniform(-0.5, 0.5, 6))
+    t = synth_dev.lidar_scan3d(100 + 2 * k, (0.0,) * 6, 32, 1024, 0.02, scene_seed=5 + k)
+    s = synth_dev.lidar_scan3d(101 + 2 * k, p, 32, 1024, 0.02, scene_seed=5 + k)
+    base.append((tuple(c.cpu().numpy() for c in t), tuple(c.cpu().numpy() for c in s)))
+t0, checked, kinds = time.time(), 0, {}
+for it in range(N):
+    cell = float(rng.choice([2.0, 1.0, 0.9, 0.7, 0.5, 0.35]))
+    mode = int(rng.integers(0, 2))
+    kw = dict(cell_size=cell, step_max_trans=cell, hessian_mode=mode, min_points=int(rng.integers(3, 7)))
+    if mode == 1:
+        kw["fixed_iterations"] = int(rng.integers(1, 4))
+    npairs = int(rng.integers(1, 25))
+    T, S = [], []
+    for _ in range(npairs):
+        bt, bs = base[int(rng.integers(0, 6))]
+        nt, ns = int(rng.choice([0, 3, 500, 8000, 30000])), int(rng.choice([0, 1, 700, 9000, 30000]))
+        it_, is_ = rng.permutation(bt[0].size)[:nt], rng.permutation(bs[0].size)[:ns]
+        tt, ss = [c[it_].copy() for c in bt], [c[is_].copy() for c in bs]
+        if ns > 10 and rng.random() < 0.3:
+            ss[int(rng.integers(0, 3))][rng.integers(0, ns, ns // 10)] = np.nan
+        if nt > 10 and rng.random() < 0.3:
+            tt[int(rng.integers(0, 3))][rng.integers(0, nt, nt // 10)] = np.inf
+        T.append(tuple(tt)); S.append(tuple(ss))
+    inits = [(0.0,) * 6] * npairs
+    nonempty = [k for k in range(npairs) if T[k][0].size > 0]
+    if not nonempty:
+        continue
+    # the host entry point refuses nothing here: empty clouds are legal pairs (status 4 / 3)
+    with NdtBatch3D(**kw) as b:
+        r1 = b.align(T, S, inits)
+        r2 = b.align(T, S, inits)
+    for a, c in zip(r1, r2):
+        assert a.status == c.status and (a.pose == c.pose or (np.isnan(a.pose).any() and np.isnan(c.pose).any())), (it, kw, a, c)
+        assert a.status in (0, 1, 2, 3, 4), (it, kw, a)
+        assert np.isfinite(a.pose).all() and np.isfinite(a.H).all(), (it, kw, a)
+        kinds[a.status] = kinds.get(a.status, 0) + 1
+    k = nonempty[int(rng.integers(0, len(nonempty)))]
+    finite = np.isfinite(T[k][0]) & np.isfinite(T[k][1]) & np.isfinite(T[k][2])
+    if finite.sum() > 0 and mode == 0:
+        with NdtMatcher3D(**kw) as m:
+            m.set_target(*(c[finite] for c in T[k]))
+            if S[k][0].size > 0:
+                r = m.align(*S[k], inits[k])
+                if r.status == 0 and r1[k].status == 0:
+                    assert np.abs(np.array(r.pose) - np.array(r1[k].pose)).max() < 1e-4, (it, kw, r, r1[k])
+                    checked += 1
+                else:
+                    assert r.status == r1[k].status or {r.status, r1[k].status} <= {0, 1}, (it, kw, r.status, r1[k].status)
+print(f"{N} random 3D batches ok, {checked} converged pairs cross-checked against the single-pair path, statuses {kinds}, {time.time() - t0:.1f}s")
