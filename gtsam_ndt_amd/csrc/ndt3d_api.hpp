@@ -310,8 +310,12 @@ int32_t multi_align3(ndt3d_handle* h, const float* const* sxs, const float* cons
   hipGraphExec_t exec = nullptr;
   const void* fs = newton ? (const void*)&k_multi_solve3<1> : (const void*)&k_multi_solve3<0>;
   const void* fb = newton ? (const void*)&k_multi_body3<1> : (const void*)&k_multi_body3<0>;
-  HIP_TRY(h->graphs.get2(fs, dim3(m), dim3(kBlock), fb, dim3(kMaxBlocks, m), dim3(kBlock), (void*)h->d_static, (void*)h->d_call,
-                         (void*)h->d_dyn_multi, steps, 0x100000 | (m << 8) | h->prm.hessian_mode, h->stream, &exec));
+  // launch shapes in powers of two (slots >= m are born finished: their workgroups return at once), so that a caller
+  // whose m varies from call to call replays one of seven cached graphs instead of instantiating a new one each time
+  int mg = 1;
+  while (mg < m) mg <<= 1;
+  HIP_TRY(h->graphs.get2(fs, dim3(mg), dim3(kBlock), fb, dim3(kMaxBlocks, mg), dim3(kBlock), (void*)h->d_static, (void*)h->d_call,
+                         (void*)h->d_dyn_multi, steps, 0x100000 | (mg << 8) | h->prm.hessian_mode, h->stream, &exec));
   if (converged_mode) {
     bool seen = false;
     HIP_TRY(run_chunks_until_flag(exec, h->stream, h->h_flag, steps, K + 1, h->call_seq, &seen));
