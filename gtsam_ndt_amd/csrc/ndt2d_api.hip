@@ -1232,10 +1232,15 @@ int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const
   if (!split)
     HIP_TRY(h->graphs.get(func, dim3(kMaxBlocks, subsets), dim3(wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static,
                           (void*)h->d_call, (void*)h->d_dyn_multi, launches, key, h->stream, &exec));
-  else
-    HIP_TRY(h->graphs.get2((const void*)&k_multi_solve, dim3(m), dim3(kBlock), func, dim3(kMaxBlocks, subsets),
+  else {
+    // launch shapes in powers of two (slots >= m are born finished: their workgroups return at once): a caller whose m
+    // varies from call to call replays one of three cached graphs (16, 32, 64 starts) instead of instantiating new ones
+    int mg = 1;
+    while (mg < m) mg <<= 1;
+    HIP_TRY(h->graphs.get2((const void*)&k_multi_solve, dim3(mg), dim3(kBlock), func, dim3(kMaxBlocks, mg),
                            dim3(wide ? kIterThreadsWide : kIterThreads), (void*)h->d_static, (void*)h->d_call,
-                           (void*)h->d_dyn_multi, launches, key | (m << 20), h->stream, &exec));
+                           (void*)h->d_dyn_multi, launches, (key & ~(0xff << 8)) | (mg << 8) | (mg << 20), h->stream, &exec));
+  }
   if (converged_mode) {
     bool seen = false;
     HIP_TRY(run_chunks_until_flag(exec, h->stream, h->h_flag, launches, K + 1, h->call_seq, &seen));

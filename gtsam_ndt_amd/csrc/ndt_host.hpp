@@ -107,7 +107,7 @@ inline hipError_t build_chain_graph2(const void* fa, dim3 ga, dim3 ba, const voi
 // timing run, the 2-launch chain of an evaluation): keep the last few instantiated graphs instead
 // of rebuilding one on every change.
 struct ChainGraphCache {
-  static constexpr int kSlots = 8;
+  static constexpr int kSlots = 16;
   struct Slot { int launches = 0, blocks = 0, mode = -1; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long stamp = 0; };
   Slot slot[kSlots];
   unsigned long clock = 0;
