@@ -102,3 +102,53 @@ def test_overlapping_grids_match_oracle(gpu_lib, pair, mode):
     assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 1e-4
     with pytest.raises(L.NdtError):
         NdtBatch2D(overlap_grids=4)
+
+
+CASES3 = [
+    dict(cell_size=0.7),
+    dict(cell_size=2.0, eig_ratio=0.01),
+    dict(cell_size=1.3, min_points=8),
+    dict(cell_size=1.0, d1=2.0, d2=0.5),
+    dict(cell_size=1.0, step_max_trans=0.05, step_max_rot=0.004, max_iterations=200),
+    dict(cell_size=1.0, eps_trans=1e-4, eps_rot=1e-4, min_hits=50),
+]
+
+
+@pytest.fixture(scope="module")
+def pair3():
+    from gtsam_ndt_amd import synth3d
+    return synth3d.make_pair3d(n_elev=32, n_azim=512, pose=tuple(0.5 * np.array(synth3d.T_STAR_3D)))
+
+
+@pytest.mark.parametrize("kw", CASES3, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+def test_3d_single_batch_and_multi_match_oracle(gpu_lib, pair3, kw):
+    """The 3D paths across parameter settings (voxel sizes that are not powers of two, validity and clamp thresholds, score
+    constants, step limits): voxel grid, single-pair alignment, the batch kernel and the multi-scan chain against the
+    oracle."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtBatch3D, NdtMatcher3D
+    from oracle import ndt3d as o3
+    d = pair3
+    prm = o3.Ndt3Params(**kw)
+    g = o3.build_grid3(d["tx"], d["ty"], d["tz"], prm)
+    ref = o3.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm)
+    with NdtMatcher3D(**kw) as m:
+        info = m.set_target(d["tx"], d["ty"], d["tz"])
+        assert (info.width, info.height, info.depth, info.n_valid) == (*g.dims, g.n_valid)
+        count, mean, icov = m.grid()
+        np.testing.assert_array_equal(count.astype(np.int64), g.count)
+        v = g.valid
+        nrm = np.linalg.norm(g.icov[v], axis=1, keepdims=True)
+        assert np.max(np.abs(icov[v] - g.icov[v]) / nrm) < 1e-4
+        r = m.align(d["sx"], d["sy"], d["sz"], d["init"])
+        s = tuple(torch.from_numpy(d[k]).cuda() for k in ("sx", "sy", "sz"))
+        rm = m.align_multi_scan([s, s], [d["init"], d["init"]])[1]
+    with NdtBatch3D(**kw) as b:
+        rb = b.align([(d["tx"], d["ty"], d["tz"])], [(d["sx"], d["sy"], d["sz"])], [d["init"]])[0]
+    assert ref["status"] == r.status == rb.status == rm.status
+    assert rm.pose == r.pose and rm.iterations == r.iterations
+    for got in (r, rb):
+        e = np.abs(np.array(got.pose) - np.array(ref["pose"]))
+        assert e.max() < 1e-4, (kw, got.pose, ref["pose"])
+        assert abs(got.iterations - ref["iterations"]) <= 4
+        assert abs(got.score - ref["score"]) / ref["score"] < 2e-3
