@@ -78,3 +78,47 @@ def test_eight_busy_threads_give_the_single_thread_results(gpu_lib):
             t.join(timeout=120)
     assert not errs, repr(errs)
     assert not bad, bad[:3]
+
+
+def test_3d_contexts_on_four_threads(gpu_lib):
+    """The same contract for the 3D entry points: four host threads, each with its own NdtMatcher3D (single calls and a
+    multi-scan chain) and NdtBatch3D, all at once - every result must be the one a single thread gets."""
+    import torch
+    from gtsam_ndt_amd import synth3d
+    from gtsam_ndt_amd.matcher import NdtBatch3D, NdtMatcher3D
+    poses = [(0.15, -0.1, 0.02, 0.005, -0.005, 0.015), (-0.12, 0.08, -0.02, -0.004, 0.006, -0.01),
+             (0.05, 0.14, 0.01, 0.0, 0.007, 0.017), (-0.06, -0.11, 0.03, 0.006, 0.0, -0.015)]
+    ds = [synth3d.make_pair3d(n_elev=16, n_azim=256 + 64 * k, pose=p) for k, p in enumerate(poses)]
+    zero = (0.0,) * 6
+    serial = []
+    for d in ds:
+        with NdtMatcher3D() as m:
+            m.set_target(d["tx"], d["ty"], d["tz"])
+            serial.append(m.align(d["sx"], d["sy"], d["sz"], zero))
+    with NdtBatch3D() as b:
+        serial_b = b.align([(d["tx"], d["ty"], d["tz"]) for d in ds], [(d["sx"], d["sy"], d["sz"]) for d in ds], [zero] * 4)
+    bad, errs = [], []
+
+    def work(k):
+        try:
+            d = ds[k]
+            s = tuple(torch.from_numpy(d[c]).cuda() for c in ("sx", "sy", "sz"))
+            with NdtMatcher3D() as m, NdtBatch3D() as b:
+                for rep in range(6):
+                    m.set_target(d["tx"], d["ty"], d["tz"])
+                    a = m.align(d["sx"], d["sy"], d["sz"], zero)
+                    mm = m.align_multi_scan([s, s, s], [zero] * 3)
+                    rb = b.align([(x["tx"], x["ty"], x["tz"]) for x in ds], [(x["sx"], x["sy"], x["sz"]) for x in ds], [zero] * 4)
+                    if not (a.pose == serial[k].pose and all(q.pose == serial[k].pose for q in mm)
+                            and all(p.pose == q.pose for p, q in zip(rb, serial_b))):
+                        bad.append((k, rep))
+        except Exception as e:      # surfaced below
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, repr(errs)
+    assert not bad, bad
