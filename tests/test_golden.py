@@ -228,3 +228,27 @@ def test_hip_3d_per_iteration_trace_follows_the_golden_trace(gpu_lib):
         gs = np.sqrt(np.abs(np.diag(tH[j])) * max(ts[j], 1.0))
         assert np.max(np.abs(r.g - tg[j]) / gs) < 5e-3, j
         assert np.abs(np.array(r.pose) - tp[j + 1]).max() < 1e-4, j    # pose after update j+1 = pose of evaluation j+1
+
+
+@pytest.mark.gpu
+def test_hip_3d_batch_and_multi_scan_match_golden(gpu_lib):
+    """The committed 3D vectors through the other two 3D drivers: the on-chip batch kernel (k_batch3) and the multi-scan
+    launch chain must land on the golden final pose as well (1e-4 m / rad), the fixed-5 pose included."""
+    import torch
+    from gtsam_ndt_amd.matcher import NdtBatch3D, NdtMatcher3D
+    g3 = np.load(GOLD3)
+    T, S = (g3["tx"], g3["ty"], g3["tz"]), (g3["sx"], g3["sy"], g3["sz"])
+    init = tuple(g3["init"])
+    with NdtBatch3D() as b:
+        rb = b.align([T, T], [S, S], [init, init])
+    with NdtBatch3D(fixed_iterations=5) as b:
+        r5 = b.align([T], [S], [init])[0]
+    with NdtMatcher3D() as m:
+        m.set_target(*T)
+        s = tuple(torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in S)
+        rm = m.align_multi_scan([s, s, s], [init] * 3)
+    for r in (*rb, *rm):
+        e = np.abs(np.array(r.pose) - g3["final_pose"])
+        assert r.status == int(g3["final_status"]) and e.max() < 1e-4, (r.pose, g3["final_pose"])
+        assert abs(r.iterations - int(g3["final_iterations"])) <= 3
+    assert r5.iterations == 5 and np.abs(np.array(r5.pose) - g3["fixed5_pose"]).max() < 1e-4
