@@ -384,6 +384,8 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   float4* recB = GLOBAL ? reinterpret_cast<float4*>(slab + kG3RecB) : reinterpret_cast<float4*>(smem + rec_base + 16 * slot_cap);
   float* recC = GLOBAL ? reinterpret_cast<float*>(slab + kG3RecC) : reinterpret_cast<float*>(smem + rec_base + 32 * slot_cap);
 
+  // (voxel keys are formed with 24-bit multiplies - every index and the key itself stay below 2^21 - which issue at
+  // full rate; the 32-bit form compiles to quarter-rate v_mad_u64_u32)
   auto voxel_of = [&](float px, float py, float pz, int& ix, int& iy, int& iz) -> bool {
     const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c, fz = (pz - oz) * inv_c;
     const bool in = (fx >= 0.f) & (fx < fW) & (fy >= 0.f) & (fy < fH) & (fz >= 0.f) & (fz < fD);
@@ -396,7 +398,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   __syncthreads();
   for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
     int ix, iy, iz;
-    if (voxel_of(px, py, pz, ix, iy, iz)) atomicAdd(&cnt[(iz * Hh + iy) * W + ix], 1u);
+    if (voxel_of(px, py, pz, ix, iy, iz)) atomicAdd(&cnt[__mul24(__mul24(iz, Hh) + iy, W) + ix], 1u);
   });
   __syncthreads();
   if constexpr (GLOBAL) __threadfence();           // the counts were added at L2: drop what this CU's L1 holds of the slab
@@ -449,7 +451,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
       int ix, iy, iz;
       if (voxel_of(px, py, pz, ix, iy, iz)) {
-        const int slot = (int)idx[(iz * Hh + iy) * W + ix];
+        const int slot = (int)idx[__mul24(__mul24(iz, Hh) + iy, W) + ix];
         if (slot) {
           const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
           const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
@@ -482,7 +484,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
       for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
         int ix, iy, iz;
         if (voxel_of(px, py, pz, ix, iy, iz)) {
-          const int slot = idx[(iz * Hh + iy) * W + ix];
+          const int slot = idx[__mul24(__mul24(iz, Hh) + iy, W) + ix];
           if (slot) {
             const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
             const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
@@ -600,7 +602,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
                     iz = floor_to_int((pz[u] - oz) * inv_c);
           in[u] = ((base + u * kB3Threads) < ns) & ((unsigned)ix < (unsigned)W) & ((unsigned)iy < (unsigned)Hh) &
                   ((unsigned)iz < (unsigned)D);
-          const int key = in[u] ? ((iz * Hh + iy) * W + ix) : 0;
+          const int key = in[u] ? (__mul24(__mul24(iz, Hh) + iy, W) + ix) : 0;
           int slot = (int)idx[key];
           if (!in[u]) slot = 0;
           if (OV && slot >= slot_cap) { A4[u] = ovA[slot - slot_cap]; B4[u] = ovB[slot - slot_cap]; C1[u] = ovC[slot - slot_cap]; }
