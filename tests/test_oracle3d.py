@@ -125,3 +125,20 @@ def test_3d_oracle_reduces_to_the_2d_oracle_on_planar_data():
     r3 = o.align3(g3, d["sx"], d["sy"], zs, (d["init"][0], d["init"][1], 0.0, 0.0, 0.0, d["init"][2]), p3)
     assert r2["status"] == r3["status"] == 0 and r2["iterations"] == r3["iterations"]
     assert np.abs(np.array(r3["pose"])[idx] - np.array(r2["pose"])).max() < 1e-12 and np.abs(np.array(r3["pose"])[other]).max() == 0.0
+
+
+def test_independent_optimiser_agrees_3d(small):
+    """scipy's BFGS with numerical gradients, on the score alone (it never sees the oracle's gradient, Hessian or update
+    rule), started 2 mm / 1 mrad from the oracle's answer, returns to it: the fixed point of the Gauss-Newton iteration
+    is the local maximum of the score."""
+    from scipy.optimize import minimize
+    d, prm, grid = small
+    r = o.align3(grid, d["sx"], d["sy"], d["sz"], d["init"], prm)
+    assert r["status"] == 0
+    f = lambda p: -o.evaluate3(grid, d["sx"], d["sy"], d["sz"], tuple(p), prm)[2]
+    x0 = np.array(r["pose"]) + np.array([2e-3, -2e-3, 1e-3, 1e-3, -1e-3, 1e-3])
+    m = minimize(f, x0, method="BFGS", options={"gtol": 1e-4, "eps": 1e-6, "maxiter": 200})
+    # (the score is piecewise smooth - points change voxel - so a quasi-Newton search on numerical gradients stalls a few
+    # tenths of a millimetre out; it started ten times farther away and must not find a better optimum)
+    assert np.abs(m.x[:3] - np.array(r["pose"])[:3]).max() < 5e-4 and np.abs(m.x[3:] - np.array(r["pose"])[3:]).max() < 1e-4, (m.x, r["pose"])
+    assert f(m.x) <= f(np.array(r["pose"])) + 1e-6 * abs(f(np.array(r["pose"])))
