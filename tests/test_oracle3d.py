@@ -141,4 +141,4 @@ def test_independent_optimiser_agrees_3d(small):
     # (the score is piecewise smooth - points change voxel - so a quasi-Newton search on numerical gradients stalls a few
     # tenths of a millimetre out; it started ten times farther away and must not find a better optimum)
     assert np.abs(m.x[:3] - np.array(r["pose"])[:3]).max() < 5e-4 and np.abs(m.x[3:] - np.array(r["pose"])[3:]).max() < 1e-4, (m.x, r["pose"])
-    assert f(m.x) <= f(np.array(r["pose"])) + 1e-6 * abs(f(np.array(r["pose"])))
+    assert f(np.array(r["pose"])) <= f(m.x) + 1e-9 * abs(f(m.x))          # and what it found is no better than the oracle's optimum
