@@ -85,3 +85,22 @@ def test_single_sync_build_time_1m_points(gpu_lib):
     print("set_target, 1M points, ms:", out)
     assert out["single_sync"][1] == out["two_round_trips"][1]
     assert out["single_sync"][0] < 2.0 * out["two_round_trips"][0]      # a sanity bound, not a benchmark: 0.107 vs 0.136 ms measured
+
+
+def test_single_sync_build_falls_back_when_the_launch_bound_is_too_small(gpu_lib):
+    """The single-sync build sizes its per-tile launches from the previous grid (twice its tiles + 16).  After a small
+    target a much wider one that still fits the cached storage exceeds that bound: the device says so and the host
+    builds the usual way - same grid as a fresh handle's."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    wide = synth.make_pair(3, n_tgt=200_000, n_src=1000)          # 200 m submap: 404 x 404 cells, 13 x 13 = 169 tiles
+    small = synth.make_pair(1)                                    # 8 m room: one tile -> bound 18
+    with NdtMatcher2D() as m, NdtMatcher2D(tuning={"single_sync_build": 0}) as ref:
+        m.set_target(wide["tx"], wide["ty"])                      # storage for the wide grid
+        m.set_target(small["tx"], small["ty"])                    # single sync; remembers one tile
+        m.set_target(wide["tx"], wide["ty"])                      # fits the storage, not the launch bound
+        ref.set_target(wide["tx"], wide["ty"])
+        _equal(_grid_state(m), _grid_state(ref))
+        m.set_target(wide["tx"], wide["ty"])                      # now within the bound: single sync
+        _equal(_grid_state(m), _grid_state(ref))
+        a, b = m.align(wide["sx"], wide["sy"], wide["init"]), ref.align(wide["sx"], wide["sy"], wide["init"])
+        assert a.pose == b.pose and a.iterations == b.iterations
