@@ -118,7 +118,10 @@ using BatchSmall = BatchCfg<256, 16384, 768, 8192, true, true>;
 // produce (a scan against a large submap); it runs on kBatchGlobalBlocks workgroups and only on the pairs
 // the large variant handed over.
 using BatchGlobal = BatchCfg<1024, 1 << 18, 32768, 0, false, false, true>;
-constexpr int kBatchGlobalBlocks = 64;
+#ifndef NDT_BATCH_GLOBAL_BLOCKS
+#define NDT_BATCH_GLOBAL_BLOCKS 64
+#endif
+constexpr int kBatchGlobalBlocks = NDT_BATCH_GLOBAL_BLOCKS;
 constexpr int kBatchThreads = BatchLarge::kThreads;       // names the host code and tools/ use
 constexpr int kBatchMaxCells = BatchLarge::kMaxCells;
 constexpr int kBatchMaxSlots = BatchLarge::kMaxSlots;
