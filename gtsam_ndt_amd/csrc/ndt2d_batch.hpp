@@ -58,7 +58,7 @@ struct BatchArgs {
 
 // Workgroup shape and on-chip capacities of one kernel variant.  LDS carve in bytes: everything in
 // one dynamic array, every offset a multiple of 16.
-//   Large  1024 threads, one workgroup per CU: 128 x 128 cells, 2303 occupied - the BASELINE config-4
+//   Large  1024 threads, one workgroup per CU: 20480 cells (143 x 143), 2559 occupied (159.8 KB of LDS) - the BASELINE config-4
 //          pairs (100k-point submap scans); sums reduced by DPP (no LDS left for anything else)
 //   Small   256 threads, two workgroups per CU (2 x 78.7 KB of LDS): 128 x 128 cells, 767 occupied, clouds of up to 8192
 //          points - single lidar scans; the per-iteration fixed costs of a 16-wave workgroup (DPP
@@ -111,7 +111,7 @@ struct BatchCfg {
   static_assert(GLOBALTABLES || (MAXSLOTS - 1 <= 0xffff && MAXCELLS <= 0x10000), "u16 slot indices and cell keys");
   static_assert(MAXCELLS <= (1 << 24), "24-bit key multiply");
 };
-using BatchLarge = BatchCfg<NDT_BATCH_THREADS, 16384, 2304, 0, false, false>;
+using BatchLarge = BatchCfg<NDT_BATCH_THREADS, 20480, 2560, 0, false, false>;
 using BatchSmall = BatchCfg<256, 16384, 768, 8192, true, true>;
 // Third variant: 512 x 512 cells (256 m x 256 m at 0.5 m cells), 32767 occupied, tables in global memory.
 // It exists so that the device-pointer entry point never fails a pair a SLAM front end may legally

@@ -296,8 +296,8 @@ int32_t ndt2d_polar_to_points_dev(const float* d_ranges, size_t n, double angle_
  * from a queue, builds the pair's target grid in LDS and runs its whole Gauss-Newton loop on
  * chip.  Clouds are concatenated SoA arrays; pair k owns target points [toff[k], toff[k+1])
  * and source points [soff[k], soff[k+1]); init is [n_pairs][3]; results is [n_pairs].
- * A pair whose grid exceeds the on-chip capacity (more than 16384 cells or 2303 occupied cells, e.g. a
- * scan against a submap wider than 64 m at 0.5 m cells) is handed, on the device and within the same
+ * A pair whose grid exceeds the on-chip capacity (more than 20480 cells or 2559 occupied cells, e.g. a
+ * scan against a submap wider than 71 m at 0.5 m cells) is handed, on the device and within the same
  * call, to a third variant of the kernel that keeps the pair's tables in global memory (up to 512 x 512
  * cells, 32767 occupied: 256 m x 256 m at 0.5 m cells).  Beyond that a pair gets status
  * NDT_ERR_CAPACITY from the _dev entry point, and the host-pointer entry point re-runs it through the
