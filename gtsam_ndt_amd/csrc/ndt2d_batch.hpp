@@ -101,7 +101,12 @@ struct BatchCfg {
   static constexpr int kLdsLs = kLdsScan + 16 * 4;                         // LineSearch (line-search state)
   static constexpr int kLdsT = kLdsLs + 80;                                // float [Waves][11 * 68] if kSumsViaLds
   static_assert(sizeof(LineSearch) <= 80, "LineSearch slot");
-  static constexpr int kLdsBytes = kLdsT + (LDSSUMS ? kWaves * (kNumAcc - 1) * kSumRowStride * 4 : 0);
+  static constexpr int kLdsEnd = kLdsT + (LDSSUMS ? kWaves * (kNumAcc - 1) * kSumRowStride * 4 : 0);
+  // global tables: the rest of the LDS is the build's sum buffer - u64 [5][kPassSlots], a range of slots per pass over
+  // the target (LDS atomics instead of five 64-bit atomics at L2 per point, which is what bounded this variant)
+  static constexpr int kLdsPass = (kLdsEnd + 15) / 16 * 16;
+  static constexpr int kPassSlots = GLOBALTABLES ? (160 * 1024 - kLdsPass) / 40 : 0;
+  static constexpr int kLdsBytes = GLOBALTABLES ? kLdsPass + 40 * kPassSlots : kLdsEnd;
   static_assert(PACKEDCOUNT || MAXCELLS * 4 <= 5 * MAXSLOTS * 8, "cnt must fit in the sums region");
   static_assert(!PACKEDCOUNT || (MAXPOINTS > 0 && MAXPOINTS < 65536), "packed counts are 16-bit");
   static_assert(MAXSLOTS * 32 <= 5 * MAXSLOTS * 8, "records must fit in the sums region");
@@ -334,24 +339,46 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     }
 
     // ---- a2 (1/2): per-cell counts
-    unsigned int* cnt_pairs = reinterpret_cast<unsigned int*>(idx);      // kPackedCount: two u16 counters per word
-    if (Cfg::kPackedCount) {
-      for (int k = tid; k < (ncell + 1) / 2; k += Cfg::kThreads) cnt_pairs[k] = 0u;
-    } else {
-      for (int k = tid; k < ncell; k += Cfg::kThreads) cnt[k] = 0u;
-    }
-    __syncthreads();
-    for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
-      const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
-      if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
-        const int key = (int)fy * W + (int)fx;
-        if (Cfg::kPackedCount) atomicAdd(&cnt_pairs[key >> 1], (key & 1) ? 0x10000u : 1u);   // nt < 65536: no carry
-        else atomicAdd(&cnt[key], 1u);
+    if constexpr (Cfg::kGlobalTables) {
+      // global tables: a range of kPassCells cells at a time in LDS (one pass over the target per range), stored to the
+      // slab with plain stores - instead of one atomic at L2 per point
+      unsigned int* pc = reinterpret_cast<unsigned int*>(smem + Cfg::kLdsPass);
+      constexpr int kPassCells = 10 * Cfg::kPassSlots;                // the same buffer as 32-bit counters
+#pragma unroll 1
+      for (int c0 = 0; c0 < ncell; c0 += kPassCells) {
+        const int np = ncell - c0 < kPassCells ? ncell - c0 : kPassCells;
+        for (int k = tid; k < np; k += Cfg::kThreads) pc[k] = 0u;
+        __syncthreads();
+        for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
+          const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
+          if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
+            const int r = (int)fy * W + (int)fx - c0;
+            if ((unsigned)r < (unsigned)np) atomicAdd(&pc[r], 1u);
+          }
+        });
+        __syncthreads();
+        for (int k = tid; k < np; k += Cfg::kThreads) cnt[c0 + k] = pc[k];
+        __syncthreads();
       }
-    });
-    __syncthreads();
-    // global tables: the counts were added at L2; drop what this CU's L1 still holds of the slab
-    if constexpr (Cfg::kGlobalTables) __threadfence();
+      __threadfence();                                  // the slab's words were written by other waves of this workgroup
+    } else {
+      unsigned int* cnt_pairs = reinterpret_cast<unsigned int*>(idx);      // kPackedCount: two u16 counters per word
+      if (Cfg::kPackedCount) {
+        for (int k = tid; k < (ncell + 1) / 2; k += Cfg::kThreads) cnt_pairs[k] = 0u;
+      } else {
+        for (int k = tid; k < ncell; k += Cfg::kThreads) cnt[k] = 0u;
+      }
+      __syncthreads();
+      for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
+        const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
+        if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
+          const int key = (int)fy * W + (int)fx;
+          if (Cfg::kPackedCount) atomicAdd(&cnt_pairs[key >> 1], (key & 1) ? 0x10000u : 1u);   // nt < 65536: no carry
+          else atomicAdd(&cnt[key], 1u);
+        }
+      });
+      __syncthreads();
+    }
     // the count of cell k, whichever table holds it (the u16 view of the packed words is idx itself)
     auto cell_count = [&](int k) -> unsigned int { return Cfg::kPackedCount ? (unsigned int)idx[k] : cnt[k]; };
 
@@ -385,28 +412,59 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       }
     }
     __syncthreads();                                 // cnt is dead; its bytes become the sums
-    for (int j = tid; j < 5 * Cfg::kMaxSlots; j += Cfg::kThreads)
-      if ((j % Cfg::kMaxSlots) < nslot) sums[j] = 0ull;
-    __syncthreads();
-
-    // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics)
-    for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
-      const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
-      if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
-        const int ix = (int)fx, iy = (int)fy;
-        const int slot = idx[iy * W + ix];
-        if (slot) {
-          const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
-          const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
-          unsigned long long* q = sums + (slot - 1);
-          atomicAdd(q, (unsigned long long)(long long)ux);
-          atomicAdd(q + Cfg::kMaxSlots, (unsigned long long)(long long)uy);
-          atomicAdd(q + 2 * Cfg::kMaxSlots, prod64(ux, ux));
-          atomicAdd(q + 3 * Cfg::kMaxSlots, prod64(ux, uy));
-          atomicAdd(q + 4 * Cfg::kMaxSlots, prod64(uy, uy));
-        }
+    if constexpr (Cfg::kGlobalTables) {
+      // ---- a2 (2/2), global tables: the sums of kPassSlots slots at a time in LDS, one pass over the target per range
+      unsigned long long* ps = reinterpret_cast<unsigned long long*>(smem + Cfg::kLdsPass);
+#pragma unroll 1
+      for (int s0 = 0; s0 < nslot; s0 += Cfg::kPassSlots) {
+        const int np = nslot - s0 < Cfg::kPassSlots ? nslot - s0 : Cfg::kPassSlots;
+        for (int j = tid; j < 5 * np; j += Cfg::kThreads) ps[j] = 0ull;
+        __syncthreads();
+        for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
+          const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
+          if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
+            const int ix = (int)fx, iy = (int)fy;
+            const int r = (int)idx[iy * W + ix] - 1 - s0;               // slot 0 (no record) gives r < 0
+            if ((unsigned)r < (unsigned)np) {
+              const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
+              const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
+              unsigned long long* q = ps + r;
+              atomicAdd(q, (unsigned long long)(long long)ux);
+              atomicAdd(q + np, (unsigned long long)(long long)uy);
+              atomicAdd(q + 2 * np, prod64(ux, ux));
+              atomicAdd(q + 3 * np, prod64(ux, uy));
+              atomicAdd(q + 4 * np, prod64(uy, uy));
+            }
+          }
+        });
+        __syncthreads();
+        for (int j = tid; j < 5 * np; j += Cfg::kThreads) sums[(size_t)(j / np) * Cfg::kMaxSlots + s0 + (j % np)] = ps[j];
+        __syncthreads();
       }
-    });
+    } else {
+      for (int j = tid; j < 5 * Cfg::kMaxSlots; j += Cfg::kThreads)
+        if ((j % Cfg::kMaxSlots) < nslot) sums[j] = 0ull;
+      __syncthreads();
+
+      // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics)
+      for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
+        const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
+        if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
+          const int ix = (int)fx, iy = (int)fy;
+          const int slot = idx[iy * W + ix];
+          if (slot) {
+            const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
+            const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
+            unsigned long long* q = sums + (slot - 1);
+            atomicAdd(q, (unsigned long long)(long long)ux);
+            atomicAdd(q + Cfg::kMaxSlots, (unsigned long long)(long long)uy);
+            atomicAdd(q + 2 * Cfg::kMaxSlots, prod64(ux, ux));
+            atomicAdd(q + 3 * Cfg::kMaxSlots, prod64(ux, uy));
+            atomicAdd(q + 4 * Cfg::kMaxSlots, prod64(uy, uy));
+          }
+        }
+      });
+    }
     if (tid == 0) misc[6] = 0;
     __syncthreads();
     if constexpr (Cfg::kGlobalTables) __threadfence();       // as above, for the sums

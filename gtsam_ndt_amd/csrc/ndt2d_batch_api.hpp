@@ -179,6 +179,10 @@ int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels,
                           ndt::kBatchLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::kBatchLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch_fallback<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::BatchGlobal::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch_fallback<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::BatchGlobal::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
   *out = b;
   return NDT_OK;
 }
