@@ -394,14 +394,37 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   };
 
   // ---- a2 (1/2): per-voxel counts
-  for (int k = tid; k < ncell; k += kB3Threads) cnt[k] = 0u;
-  __syncthreads();
-  for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
-    int ix, iy, iz;
-    if (voxel_of(px, py, pz, ix, iy, iz)) atomicAdd(&cnt[__mul24(__mul24(iz, Hh) + iy, W) + ix], 1u);
-  });
-  __syncthreads();
-  if constexpr (GLOBAL) __threadfence();           // the counts were added at L2: drop what this CU's L1 holds of the slab
+  if constexpr (GLOBAL) {
+    // global tables: a range of voxels at a time in LDS (the kernel has the CU's LDS to itself; one pass over the target
+    // per range), stored to the slab with plain stores - instead of one atomic at L2 per point
+    unsigned int* pc = reinterpret_cast<unsigned int*>(smem + kB3Idx);
+    constexpr int kPassCells = (kB3LdsBytes - kB3Idx) / 4;
+#pragma unroll 1
+    for (int c0 = 0; c0 < ncell; c0 += kPassCells) {
+      const int np = ncell - c0 < kPassCells ? ncell - c0 : kPassCells;
+      for (int k = tid; k < np; k += kB3Threads) pc[k] = 0u;
+      __syncthreads();
+      for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+        int ix, iy, iz;
+        if (voxel_of(px, py, pz, ix, iy, iz)) {
+          const int r = __mul24(__mul24(iz, Hh) + iy, W) + ix - c0;
+          if ((unsigned)r < (unsigned)np) atomicAdd(&pc[r], 1u);
+        }
+      });
+      __syncthreads();
+      for (int k = tid; k < np; k += kB3Threads) cnt[c0 + k] = pc[k];
+      __syncthreads();
+    }
+    __threadfence();                                 // the slab's words were written by other waves of this workgroup
+  } else {
+    for (int k = tid; k < ncell; k += kB3Threads) cnt[k] = 0u;
+    __syncthreads();
+    for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+      int ix, iy, iz;
+      if (voxel_of(px, py, pz, ix, iy, iz)) atomicAdd(&cnt[__mul24(__mul24(iz, Hh) + iy, W) + ix], 1u);
+    });
+    __syncthreads();
+  }
 
   // ---- compaction: voxels with n >= min_points get a slot, in voxel order (deterministic)
   const int chunk = (ncell + kB3Threads - 1) / kB3Threads;
@@ -443,33 +466,40 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   __syncthreads();                                 // cnt is dead; its bytes become the pass sums
 
   if constexpr (GLOBAL) {
-    // ---- a2 (2/2), global variant: the nine exact sums per slot by 64-bit atomics at L2, one pass
-    for (int j = tid; j < 9 * kS; j += kB3Threads)
-      if ((j % kS) < nslot) gsums[j] = 0ull;
-    __threadfence();
-    __syncthreads();
-    for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
-      int ix, iy, iz;
-      if (voxel_of(px, py, pz, ix, iy, iz)) {
-        const int slot = (int)idx[__mul24(__mul24(iz, Hh) + iy, W) + ix];
-        if (slot) {
-          const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
-          const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
-          const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
-          unsigned long long* q = gsums + (slot - 1);
-          atomicAdd(q, (unsigned long long)(long long)ux);
-          atomicAdd(q + kS, (unsigned long long)(long long)uy);
-          atomicAdd(q + 2 * kS, (unsigned long long)(long long)uz);
-          atomicAdd(q + 3 * kS, prod64(ux, ux));
-          atomicAdd(q + 4 * kS, prod64(ux, uy));
-          atomicAdd(q + 5 * kS, prod64(ux, uz));
-          atomicAdd(q + 6 * kS, prod64(uy, uy));
-          atomicAdd(q + 7 * kS, prod64(uy, uz));
-          atomicAdd(q + 8 * kS, prod64(uz, uz));
+    // ---- a2 (2/2), global variant: the nine exact sums of a range of slots at a time in LDS, one pass over the target
+    // per range (LDS atomics; the first version added them with 64-bit atomics at L2, which bounded the variant)
+    unsigned long long* ps = reinterpret_cast<unsigned long long*>(smem + kB3Idx);
+    constexpr int kPassSlots = (kB3LdsBytes - kB3Idx) / 72;
+#pragma unroll 1
+    for (int s0 = 0; s0 < nslot; s0 += kPassSlots) {
+      const int np = nslot - s0 < kPassSlots ? nslot - s0 : kPassSlots;
+      for (int j = tid; j < 9 * np; j += kB3Threads) ps[j] = 0ull;
+      __syncthreads();
+      for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+        int ix, iy, iz;
+        if (voxel_of(px, py, pz, ix, iy, iz)) {
+          const int r = (int)idx[__mul24(__mul24(iz, Hh) + iy, W) + ix] - 1 - s0;      // no slot: r < 0
+          if ((unsigned)r < (unsigned)np) {
+            const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
+            const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
+            const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
+            unsigned long long* q = ps + r;
+            atomicAdd(q, (unsigned long long)(long long)ux);
+            atomicAdd(q + np, (unsigned long long)(long long)uy);
+            atomicAdd(q + 2 * np, (unsigned long long)(long long)uz);
+            atomicAdd(q + 3 * np, prod64(ux, ux));
+            atomicAdd(q + 4 * np, prod64(ux, uy));
+            atomicAdd(q + 5 * np, prod64(ux, uz));
+            atomicAdd(q + 6 * np, prod64(uy, uy));
+            atomicAdd(q + 7 * np, prod64(uy, uz));
+            atomicAdd(q + 8 * np, prod64(uz, uz));
+          }
         }
-      }
-    });
-    __syncthreads();
+      });
+      __syncthreads();
+      for (int j = tid; j < 9 * np; j += kB3Threads) gsums[(size_t)(j / np) * kS + s0 + (j % np)] = ps[j];
+      __syncthreads();
+    }
   } else {
     // ---- a2 (2/2): exact fixed-point sums per slot (LDS 64-bit integer atomics).  The records' region (36 B per slot
     // of capacity) holds `per` of the nine 64-bit sums of every occupied slot at a time: config 5 (2 706 slots) five, so

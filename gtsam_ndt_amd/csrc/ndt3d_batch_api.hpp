@@ -79,9 +79,9 @@ int32_t batch3_launch(ndt3d_batch* b, const float* const d_t[3], const unsigned 
     HIP_TRY(hipGetLastError());
     // pairs whose voxel grid does not fit the LDS carve (handed over through fb_marks): tables in global memory
     if (newton)
-      hipLaunchKernelGGL((ndt::k_batch3_fallback<1>), dim3(blocks_fb), dim3(ndt::kB3Threads), ndt::kB3Idx, st, a);
+      hipLaunchKernelGGL((ndt::k_batch3_fallback<1>), dim3(blocks_fb), dim3(ndt::kB3Threads), ndt::kB3LdsBytes, st, a);
     else
-      hipLaunchKernelGGL((ndt::k_batch3_fallback<0>), dim3(blocks_fb), dim3(ndt::kB3Threads), ndt::kB3Idx, st, a);
+      hipLaunchKernelGGL((ndt::k_batch3_fallback<0>), dim3(blocks_fb), dim3(ndt::kB3Threads), ndt::kB3LdsBytes, st, a);
     HIP_TRY(hipGetLastError());
   }
   return NDT_OK;
@@ -133,6 +133,10 @@ int32_t ndt3d_batch_create_pyramid(const ndt3d_params* levels, int32_t n_levels,
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch3<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::kB3LdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch3<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::kB3LdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch3_fallback<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::kB3LdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch3_fallback<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::kB3LdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
   *out = b;
   return NDT_OK;
