@@ -120,13 +120,11 @@ using BatchLarge = BatchCfg<NDT_BATCH_THREADS, 20480, 2560, 0, false, false>;
 using BatchSmall = BatchCfg<256, 16384, 768, 8192, true, true>;
 // Third variant: 512 x 512 cells (256 m x 256 m at 0.5 m cells), 32767 occupied, tables in global memory.
 // It exists so that the device-pointer entry point never fails a pair a SLAM front end may legally
-// produce (a scan against a large submap); it runs on kBatchGlobalBlocks workgroups and only on the pairs
+// produce (a scan against a large submap); it runs on the context's global_blocks workgroups and only on the pairs
 // the large variant handed over.
 using BatchGlobal = BatchCfg<1024, 1 << 18, 32768, 0, false, false, true>;
-#ifndef NDT_BATCH_GLOBAL_BLOCKS
-#define NDT_BATCH_GLOBAL_BLOCKS 64
-#endif
-constexpr int kBatchGlobalBlocks = NDT_BATCH_GLOBAL_BLOCKS;
+constexpr int kBatchGlobalBlocks = 256;      // default: one workgroup and one 3.7 MB table slab per CU (0.95 GB per context);
+constexpr int kBatchGlobalBlocksMax = 256;   // NDT_TUNE_BATCH_GLOBAL_WORKGROUPS trades the memory against the variant's rate
 constexpr int kBatchThreads = BatchLarge::kThreads;       // names the host code and tools/ use
 constexpr int kBatchMaxCells = BatchLarge::kMaxCells;
 constexpr int kBatchMaxSlots = BatchLarge::kMaxSlots;

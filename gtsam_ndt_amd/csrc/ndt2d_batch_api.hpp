@@ -24,7 +24,8 @@ struct ndt2d_batch {
   int* d_marks = nullptr;                // [n_pairs]: pairs the small variant left to the large one
   int* d_fb_list = nullptr;              // [n_pairs]: marks of the pairs the large variant left to the global-table one
   size_t marks_cap = 0;
-  unsigned char* d_slab = nullptr;       // [kBatchGlobalBlocks][BatchGlobal::kTabBytes]
+  unsigned char* d_slab = nullptr;       // [global_blocks][BatchGlobal::kTabBytes]
+  int global_blocks = ndt::kBatchGlobalBlocks;   // workgroups (and table slabs) of the global-table variant (NDT_TUNE_BATCH_GLOBAL_WORKGROUPS)
   bool use_small = true;                 // lidar-sized pairs run on the 256-thread variant first (ndt2d_batch_set_tuning)
   int64_t last_large = -1;               // pairs the last host-pointer call's final level ran on the large variant
 };
@@ -102,7 +103,7 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
       hipLaunchKernelGGL((ndt::k_batch<0, ndt::BatchLarge>), dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
     HIP_TRY(hipGetLastError());
     // pairs whose grid does not fit on chip (handed over through fb_marks): tables in global memory
-    const int blocks_fb = (int)(n_pairs < (size_t)ndt::kBatchGlobalBlocks ? n_pairs : (size_t)ndt::kBatchGlobalBlocks);
+    const int blocks_fb = (int)(n_pairs < (size_t)b->global_blocks ? n_pairs : (size_t)b->global_blocks);
     if (newton)
       hipLaunchKernelGGL((ndt::k_batch_fallback<1>), dim3(blocks_fb), dim3(ndt::BatchGlobal::kThreads), ndt::BatchGlobal::kLdsBytes, st, a);
     else
@@ -169,7 +170,7 @@ int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels,
   b->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipMalloc((void**)&b->d_queue, 16) != hipSuccess) return fail(NDT_ERR_ALLOC);
-  if (hipMalloc((void**)&b->d_slab, (size_t)ndt::kBatchGlobalBlocks * ndt::BatchGlobal::kTabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&b->d_slab, (size_t)b->global_blocks * ndt::BatchGlobal::kTabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
   // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<0, ndt::BatchSmall>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::BatchSmall::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
@@ -210,10 +211,19 @@ void* ndt2d_batch_stream(ndt2d_batch* b) { return b ? (void*)b->stream : nullptr
 
 int32_t ndt2d_batch_set_tuning(ndt2d_batch* b, int32_t knob, int64_t value) {
   if (!b) return NDT_ERR_INVALID_ARG;
-  if (knob != NDT_TUNE_BATCH_SMALL_VARIANT) return NDT_ERR_INVALID_ARG;
+  if (knob != NDT_TUNE_BATCH_SMALL_VARIANT && knob != NDT_TUNE_BATCH_GLOBAL_WORKGROUPS) return NDT_ERR_INVALID_ARG;
+  if (knob == NDT_TUNE_BATCH_GLOBAL_WORKGROUPS && (value < 1 || value > ndt::kBatchGlobalBlocksMax)) return NDT_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
-  b->use_small = value != 0;
+  if (knob == NDT_TUNE_BATCH_SMALL_VARIANT) {
+    b->use_small = value != 0;
+  } else if ((int)value != b->global_blocks) {       // one table slab per workgroup: re-allocate
+    unsigned char* slab = nullptr;
+    if (hipMalloc((void**)&slab, (size_t)value * ndt::BatchGlobal::kTabBytes) != hipSuccess) { (void)hipGetLastError(); return NDT_ERR_ALLOC; }
+    (void)hipFree(b->d_slab);
+    b->d_slab = slab;
+    b->global_blocks = (int)value;
+  }
   return NDT_OK;
 }
 

@@ -38,7 +38,7 @@ struct Batch3Args {
   Result3Dev* out;           // [n_pairs]
   unsigned int* queue;       // zeroed before the launch
   unsigned char* slab;       // [gridDim.x][kB3SlabBytes]
-  unsigned char* gslab;      // tables of the global-memory variant: [kG3Blocks][kG3SlabBytes]
+  unsigned char* gslab;      // tables of the global-memory variant: [global_blocks][kG3SlabBytes]
   int* fb_marks;             // [n_pairs], zeroed before the launches: k_batch3 sets 1 for a pair over the LDS carve,
                              // k_batch3_fallback processes exactly those (null: such pairs get NDT_ERR_CAPACITY at once)
   int n_pairs;
@@ -82,12 +82,12 @@ constexpr int kB3SlabBytes = kB3SlabRecC + kB3MaxSlots * 4;
 
 // Second variant, for the pairs whose voxel grid does not fit the LDS carve (a scan against a wide or finely
 // gridded map): the same code with every table in a per-workgroup slab of global memory - u32 voxel -> slot
-// table (also the counts of the build), per-slot counts / keys / nine sums (global 64-bit atomics, one pass),
-// 40-byte records gathered through L2.  It runs on kG3Blocks workgroups and only on the pairs k_batch3 handed over.
+// table (also the counts of the build), per-slot counts / keys / nine sums (counted and added up a range at a time in LDS),
+// 36-byte records gathered through L2.  It runs on the context's global_blocks workgroups and only on the pairs k_batch3 handed over.
 constexpr int kG3MaxCells = 1 << 20;                    // 1 048 576 voxels (e.g. 256 x 256 x 16)
 constexpr int kG3MaxSlots = 1 << 15;                    // occupied voxels (slot 0 is the dummy record)
-constexpr int kG3Blocks = 64;                           // a pair costs a workgroup here about twice what it costs on chip: the
-                                                        // variant is slow per batch only for lack of workgroups (slab memory)
+constexpr int kG3Blocks = 256;                          // default: one workgroup and one 7.9 MB slab per CU (2.0 GB per context);
+constexpr int kG3BlocksMax = 256;                       // NDT_TUNE_BATCH_GLOBAL_WORKGROUPS trades the memory against the variant's rate
 constexpr size_t kG3Idx = 0;                                                  // u32 [MaxCells]
 constexpr size_t kG3SlotN = kG3Idx + (size_t)kG3MaxCells * 4;                 // u32 [MaxSlots]
 constexpr size_t kG3SlotKey = kG3SlotN + (size_t)kG3MaxSlots * 4;             // u32 [MaxSlots]

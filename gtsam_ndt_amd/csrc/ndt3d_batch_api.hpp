@@ -11,7 +11,8 @@ struct ndt3d_batch {
   int n_cu = 0;
   unsigned int* d_queue = nullptr;
   unsigned char* d_slab = nullptr;    // [n_cu][kB3SlabBytes]
-  unsigned char* d_gslab = nullptr;   // [kG3Blocks][kG3SlabBytes]: tables of the global-memory variant
+  unsigned char* d_gslab = nullptr;   // [global_blocks][kG3SlabBytes]: tables of the global-memory variant
+  int global_blocks = ndt::kG3Blocks; // its workgroups (NDT_TUNE_BATCH_GLOBAL_WORKGROUPS)
   int* d_fb = nullptr;                // [n_pairs]: marks of the pairs k_batch3 left to the global-memory variant
   size_t fb_cap = 0;
   // staging for the host-pointer entry point (one capacity per buffer)
@@ -45,7 +46,7 @@ int32_t batch3_launch(ndt3d_batch* b, const float* const d_t[3], const unsigned 
   a.gslab = b->d_gslab;
   a.n_pairs = (int)n_pairs;
   const int blocks = (int)(n_pairs < (size_t)b->n_cu ? n_pairs : (size_t)b->n_cu);
-  const int blocks_fb = (int)(n_pairs < (size_t)ndt::kG3Blocks ? n_pairs : (size_t)ndt::kG3Blocks);
+  const int blocks_fb = (int)(n_pairs < (size_t)b->global_blocks ? n_pairs : (size_t)b->global_blocks);
   if (n_pairs > b->fb_cap) {
     if (b->d_fb) (void)hipFree(b->d_fb);
     b->d_fb = nullptr; b->fb_cap = 0;
@@ -128,7 +129,7 @@ int32_t ndt3d_batch_create_pyramid(const ndt3d_params* levels, int32_t n_levels,
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipMalloc((void**)&b->d_queue, 16) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&b->d_slab, (size_t)b->n_cu * ndt::kB3SlabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
-  if (hipMalloc((void**)&b->d_gslab, (size_t)ndt::kG3Blocks * ndt::kG3SlabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&b->d_gslab, (size_t)b->global_blocks * ndt::kG3SlabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
   // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch3<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::kB3LdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
@@ -148,6 +149,20 @@ int32_t ndt3d_batch_create(const ndt3d_params* p, int32_t device_id, ndt3d_batch
 }
 
 void* ndt3d_batch_stream(ndt3d_batch* b) { return b ? (void*)b->stream : nullptr; }
+
+int32_t ndt3d_batch_set_tuning(ndt3d_batch* b, int32_t knob, int64_t value) {
+  if (!b || knob != NDT_TUNE_BATCH_GLOBAL_WORKGROUPS || value < 1 || value > ndt::kG3BlocksMax) return NDT_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if ((int)value != b->global_blocks) {                // one table slab per workgroup: re-allocate
+    unsigned char* slab = nullptr;
+    if (hipMalloc((void**)&slab, (size_t)value * ndt::kG3SlabBytes) != hipSuccess) { (void)hipGetLastError(); return NDT_ERR_ALLOC; }
+    (void)hipFree(b->d_gslab);
+    b->d_gslab = slab;
+    b->global_blocks = (int)value;
+  }
+  return NDT_OK;
+}
 
 int32_t ndt3d_batch_wait_stream(ndt3d_batch* b, void* producer_stream) {
   if (!b) return NDT_ERR_INVALID_ARG;

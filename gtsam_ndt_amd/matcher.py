@@ -421,9 +421,10 @@ class NdtBatch2D:
     ndt2d_batch_* of include/ndt_hip.h."""
 
     def __init__(self, device: int = 0, params: L.Params2D | None = None, levels=None, small_variant: bool = True,
-                 **overrides):
+                 global_workgroups: int | None = None, **overrides):
         """levels: coarse-to-fine list of Params2D (e.g. pyramid_params()); otherwise one level.
-        small_variant=False: every pair on the 1024-thread kernel (ndt2d_batch_set_tuning)."""
+        small_variant=False: every pair on the 1024-thread kernel (ndt2d_batch_set_tuning).
+        global_workgroups: workgroups (and 3.7 MB table slabs) of the global-table variant, 1..256 (default 256)."""
         self._lib = L.load()
         self.params = params if params is not None else default_params(**overrides)
         if params is not None:
@@ -441,6 +442,11 @@ class NdtBatch2D:
         self._keep = None
         if not small_variant:
             L.check(self._lib.ndt2d_batch_set_tuning(self._h, L.TUNING["batch_small_variant"], 0), "ndt2d_batch_set_tuning")
+        if global_workgroups is not None:
+            self.set_tuning("batch_global_workgroups", global_workgroups)
+
+    def set_tuning(self, knob: str, value: int):
+        L.check(self._lib.ndt2d_batch_set_tuning(self._h, L.TUNING[knob], int(value)), "ndt2d_batch_set_tuning")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -722,7 +728,8 @@ class NdtBatch3D:
     """3D loop-closure candidate batch (ndt3d_batch_* of include/ndt_hip.h): independent 3D scan pairs
     aligned concurrently, one persistent workgroup per CU with the pair's voxel grid in LDS."""
 
-    def __init__(self, device: int = 0, levels=None, **overrides):
+    def __init__(self, device: int = 0, levels=None, global_workgroups: int | None = None, **overrides):
+        """global_workgroups: workgroups (and 7.9 MB table slabs) of the global-table variant, 1..256 (default 256)."""
         self._lib = L.load()
         self.params = default_params3d(**overrides)
         h = C.c_void_p()
@@ -735,6 +742,11 @@ class NdtBatch3D:
             L.check(self._lib.ndt3d_batch_create(C.byref(self.params), int(device), C.byref(h)), "ndt3d_batch_create")
         self._h = h
         self._keep = None
+        if global_workgroups is not None:
+            self.set_tuning("batch_global_workgroups", global_workgroups)
+
+    def set_tuning(self, knob: str, value: int):
+        L.check(self._lib.ndt3d_batch_set_tuning(self._h, L.TUNING[knob], int(value)), "ndt3d_batch_set_tuning")
 
     def close(self):
         if getattr(self, "_h", None):

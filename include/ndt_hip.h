@@ -231,7 +231,11 @@ int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const fl
  *                               it falls back by itself when the new grid does not fit the cached storage).
  *                               0: bounding box to the host first, then the build (two round trips)
  *   NDT_TUNE_BATCH_SMALL_VARIANT (batch contexts) 1 (default): lidar-sized pairs run on the 256-thread
- *                               variant of the batch kernel first; 0: every pair on the 1024-thread one */
+ *                               variant of the batch kernel first; 0: every pair on the 1024-thread one
+ *   NDT_TUNE_BATCH_GLOBAL_WORKGROUPS (batch contexts, 2D and 3D) workgroups of the global-table variant, each with its own
+ *                               table slab in device memory: 1..256, default 256 (0.95 GB per 2D context, 2.0 GB per 3D
+ *                               context; 64 of them: a quarter of that, and a batch of over-capacity pairs about 2.8x slower).
+ *                               Results do not depend on it */
 enum {
   NDT_TUNE_LAUNCH_GRAPHS = 1,
   NDT_TUNE_WIDE_THRESHOLD = 2,
@@ -241,7 +245,8 @@ enum {
   NDT_TUNE_BATCH_SMALL_VARIANT = 6,
   NDT_TUNE_TEAM_KERNEL = 7,
   NDT_TUNE_SPLIT_FROM = 8,
-  NDT_TUNE_SINGLE_SYNC_BUILD = 9
+  NDT_TUNE_SINGLE_SYNC_BUILD = 9,
+  NDT_TUNE_BATCH_GLOBAL_WORKGROUPS = 10
 };
 int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value);
 /* Diagnostic: calls on this handle whose team kernel could not assemble its 32-workgroup teams (the GPU
@@ -324,7 +329,7 @@ int32_t ndt2d_batch_align_dev(ndt2d_batch* b, const float* d_tx, const float* d_
                               const float* d_sx, const float* d_sy, const uint64_t* d_soff,
                               const double* d_init, size_t n_pairs, ndt2d_result* d_results, void* stream);
 void* ndt2d_batch_stream(ndt2d_batch* b);
-int32_t ndt2d_batch_set_tuning(ndt2d_batch* b, int32_t knob, int64_t value);   /* NDT_TUNE_BATCH_SMALL_VARIANT */
+int32_t ndt2d_batch_set_tuning(ndt2d_batch* b, int32_t knob, int64_t value);   /* NDT_TUNE_BATCH_SMALL_VARIANT, _GLOBAL_WORKGROUPS */
 /* as ndt2d_wait_stream, for calls that run on the context's own stream (stream == NULL above) */
 int32_t ndt2d_batch_wait_stream(ndt2d_batch* b, void* producer_stream);
 /* Of the pairs of the last ndt2d_batch_align() call, how many ran on the 1024-thread variant of
@@ -484,7 +489,8 @@ int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
  * that only has a few more occupied voxels than fit stays on chip with its last records in global memory).
  * Beyond that a pair gets status NDT_ERR_CAPACITY from the _dev entry point, and the host-pointer entry
  * point re-runs it through the single-pair path transparently.  Stream semantics as ndt2d_batch_align_dev.
- * A context holds about 0.6 GB of device memory (per-workgroup slabs of the build and of the global-memory variant). */
+ * A context holds about 2.1 GB of device memory (per-workgroup slabs of the build and of the global-memory variant;
+ * NDT_TUNE_BATCH_GLOBAL_WORKGROUPS trades most of it against that variant's rate). */
 typedef struct ndt3d_batch ndt3d_batch;
 int32_t ndt3d_batch_create(const ndt3d_params* p, int32_t device_id, ndt3d_batch** out);
 /* coarse-to-fine over the batch, as ndt2d_batch_create_pyramid (levels coarse to fine, at most 8) */
@@ -498,6 +504,7 @@ int32_t ndt3d_batch_align_dev(ndt3d_batch* b, const float* d_tx, const float* d_
                               const double* d_init, size_t n_pairs, ndt3d_result* d_results, void* stream);
 void* ndt3d_batch_stream(ndt3d_batch* b);
 int32_t ndt3d_batch_wait_stream(ndt3d_batch* b, void* producer_stream);
+int32_t ndt3d_batch_set_tuning(ndt3d_batch* b, int32_t knob, int64_t value);   /* NDT_TUNE_BATCH_GLOBAL_WORKGROUPS */
 
 /* The 3D batch over several devices from ONE host process: ndt2d_multi_* for ndt3d_batch contexts (one context and one
  * host thread per device, contiguous work-balanced shards by ndt2d_multi_plan's rule).  ndt3d_multi_align takes host

@@ -323,6 +323,16 @@ def test_device_entry_point_handles_pairs_over_the_on_chip_capacity(gpu_lib, pai
                 assert rows[k].status == s.status == 0 and abs(rows[k].iterations - s.iterations) <= 1, (k, rows[k], s)
                 assert np.abs(np.array(rows[k].pose) - np.array(s.pose)).max() < 2e-5, (k, rows[k].pose, s.pose)
                 assert abs(rows[k].n_hit - s.n_hit) <= 2
+    # the variant's workgroup count (one table slab each) is a memory / rate knob: results do not depend on it
+    with NdtBatch2D() as b:
+        ref = b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"]).cpu()
+        for wgs in (1, 64):
+            b.set_tuning("batch_global_workgroups", wgs)
+            assert torch.equal(b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"]).cpu(), ref), wgs
+        for bad in (0, 257):
+            with pytest.raises(L.NdtError) as e:
+                b.set_tuning("batch_global_workgroups", bad)
+            assert e.value.code == L.NDT_ERR_INVALID_ARG
     # coarse-to-fine over the same batch: every level hands the big pairs over again
     from gtsam_ndt_amd.matcher import pyramid_params
     with NdtBatch2D(levels=pyramid_params()) as b:

@@ -129,6 +129,7 @@ def test_batch3d_capacity_handover_on_the_device(gpu_lib, mode):
     with its tables in global memory inside the same call - through the device entry point too - while the
     pairs that fit stay on chip (a mixed batch: cell size is per context, so the small pairs here are cropped
     scans whose grid fits)."""
+    from gtsam_ndt_amd import _lib as L
     from gtsam_ndt_amd.matcher import NdtBatch3D
     ds, T, S = _pairs(POSES[:3], [(32, 512), (16, 256), (16, 256)])
     crop = lambda c, r: tuple(np.asarray(a)[(np.abs(c[0]) < r) & (np.abs(c[1]) < r)] for a in c)
@@ -142,11 +143,18 @@ def test_batch3d_capacity_handover_on_the_device(gpu_lib, mode):
     with NdtBatch3D(**kw) as b:
         rd = b.decode(b.align_dev(*_dev_args(T, S, inits)))
         rh = b.align(T, S, inits)
+        # the variant's workgroup count (one 7.9 MB table slab each) is a memory / rate knob: the same bits with 1
+        b.set_tuning("batch_global_workgroups", 1)
+        r1 = b.decode(b.align_dev(*_dev_args(T, S, inits)))
+        for bad in (0, 257):
+            with pytest.raises(L.NdtError):
+                b.set_tuning("batch_global_workgroups", bad)
     rs = _single(T, S, inits, **kw)
-    for x, h, y in zip(rd, rh, rs):
+    for x, h, y, z in zip(rd, rh, rs, r1):
         assert x.status == y.status and x.status in (0, 1)
         _same(x, y, pose_tol=5e-6)
         assert x.pose == h.pose and np.array_equal(x.H, h.H)       # host entry point: the same kernels
+        assert x.pose == z.pose and np.array_equal(x.H, z.H)
 
 
 def test_batch3d_beyond_the_global_tables(gpu_lib):
