@@ -298,6 +298,11 @@ class NdtBatchHip {
     return lv;
   }
   ~NdtBatchHip() { ndt2d_batch_destroy(b_); }
+  // NDT_TUNE_BATCH_SMALL_VARIANT / NDT_TUNE_BATCH_GLOBAL_WORKGROUPS (memory of the global-table variant against its rate)
+  void setTuning(int32_t knob, int64_t value) {
+    const int32_t st = ndt2d_batch_set_tuning(b_, knob, value);
+    if (st != NDT_OK) throw NdtError(st, "ndt2d_batch_set_tuning");
+  }
   NdtBatchHip(const NdtBatchHip&) = delete;
   NdtBatchHip& operator=(const NdtBatchHip&) = delete;
 
@@ -567,6 +572,11 @@ class NdtBatchHip3 {
     if (st != NDT_OK) throw NdtError(st, "ndt3d_batch_create_pyramid");
   }
   ~NdtBatchHip3() { ndt3d_batch_destroy(b_); }
+  // NDT_TUNE_BATCH_GLOBAL_WORKGROUPS: 1..256 table slabs of 7.9 MB for the pairs whose voxel grid does not fit on chip
+  void setTuning(int32_t knob, int64_t value) {
+    const int32_t st = ndt3d_batch_set_tuning(b_, knob, value);
+    if (st != NDT_OK) throw NdtError(st, "ndt3d_batch_set_tuning");
+  }
   NdtBatchHip3(const NdtBatchHip3&) = delete;
   NdtBatchHip3& operator=(const NdtBatchHip3&) = delete;
 
