@@ -87,6 +87,17 @@ class GridInfo2D(C.Structure):
     ]
 
 
+class MapHeader(C.Structure):
+    """ndt_map_header of include/ndt_hip.h (104 bytes): what ndt2d_save_map / ndt3d_save_map write first."""
+    _fields_ = [("magic", C.c_uint32), ("version", C.c_uint32), ("dims", C.c_int32), ("ngrid", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_int32), ("cell_bytes", C.c_uint32),
+                ("cell_size", C.c_double), ("n_cells", C.c_uint64), ("n_points", C.c_uint64),
+                ("origin", (C.c_float * 3) * 4)]
+
+
+MAP_MAGIC = 0x4d54444e
+
+
 class Result3D(C.Structure):
     _fields_ = [("pose", C.c_double * 6), ("H", C.c_double * 36), ("g", C.c_double * 6), ("score", C.c_double),
                 ("iterations", C.c_int32), ("n_hit", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32)]
@@ -123,6 +134,9 @@ SIGNATURES = {
     "ndt2d_add_target_points_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp, C.POINTER(C.c_size_t), _vp]),
     "ndt2d_get_grid_info": (C.c_int32, [_vp, C.POINTER(GridInfo2D)]),
     "ndt2d_get_grid": (C.c_int32, [_vp, _vp, _vp, _vp]),
+    "ndt2d_map_size": (C.c_size_t, [_vp]),
+    "ndt2d_save_map": (C.c_int32, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ndt2d_load_map": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "ndt2d_evaluate": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval2D)]),
     "ndt2d_evaluate_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval2D)]),
     "ndt2d_align": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result2D)]),
@@ -169,6 +183,9 @@ SIGNATURES = {
     "ndt3d_add_target_points_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(C.c_size_t), _vp]),
     "ndt3d_get_grid_info": (C.c_int32, [_vp, C.POINTER(GridInfo3D)]),
     "ndt3d_get_grid": (C.c_int32, [_vp, _vp, _vp, _vp]),
+    "ndt3d_map_size": (C.c_size_t, [_vp]),
+    "ndt3d_save_map": (C.c_int32, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ndt3d_load_map": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "ndt3d_evaluate": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval3D)]),
     "ndt3d_evaluate_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Eval3D)]),
     "ndt3d_align": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_size_t, _dp, C.POINTER(Result3D)]),

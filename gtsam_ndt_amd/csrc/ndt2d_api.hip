@@ -1278,3 +1278,4 @@ extern "C" int32_t ndt2d_align_multi_scan_dev(ndt2d_handle* h, const float* cons
 #include "ndt3d_api.hpp"
 #include "ndt3d_batch_api.hpp"
 #include "ndt3d_multi_api.hpp"
+#include "ndt_map_io.hpp"

@@ -17,7 +17,7 @@ template <int MODE> struct Acc3 {
   static constexpr int kRowsPerWave = kRows / 4;
 };
 
-struct CellAcc3 {   // 88 B
+struct CellAcc3 {   // 80 B
   long long s[3];
   long long ss[6];   // xx xy xz yy yz zz
   unsigned int n;

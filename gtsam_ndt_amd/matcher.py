@@ -177,6 +177,19 @@ class NdtMatcher2D:
                 "ndt2d_get_grid")
         return count, mean, icov
 
+    # ---- submap persistence
+    def save_map(self) -> np.ndarray:
+        """The cached grid as a flat uint8 buffer (ndt_map_header + the exact per-cell sums; ndt2d_save_map)."""
+        buf = np.empty(int(self._lib.ndt2d_map_size(self._h)) or 1, dtype=np.uint8)
+        L.check(self._lib.ndt2d_save_map(self._h, buf.ctypes.data, buf.size, None), "ndt2d_save_map")
+        return buf
+
+    def load_map(self, buf):
+        """Make a saved map this handle's target: the sums are re-finalised with THIS handle's min_points /
+        eig_ratio (ndt2d_load_map); cell_size and overlap_grids must match."""
+        buf = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf.view(np.uint8))
+        L.check(self._lib.ndt2d_load_map(self._h, buf.ctypes.data, buf.size), "ndt2d_load_map")
+
     # ---- (ii)+(iii) one evaluation
     def evaluate(self, sx, sy, pose):
         p = (C.c_double * 3)(*[float(v) for v in pose])
@@ -622,6 +635,16 @@ class NdtMatcher3D:
         L.check(self._lib.ndt3d_get_grid(self._h, count.ctypes.data, mean.ctypes.data, icov.ctypes.data),
                 "ndt3d_get_grid")
         return count, mean, icov
+
+    def save_map(self) -> np.ndarray:
+        """The cached voxel grid as a flat uint8 buffer (ndt3d_save_map)."""
+        buf = np.empty(int(self._lib.ndt3d_map_size(self._h)) or 1, dtype=np.uint8)
+        L.check(self._lib.ndt3d_save_map(self._h, buf.ctypes.data, buf.size, None), "ndt3d_save_map")
+        return buf
+
+    def load_map(self, buf):
+        buf = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf.view(np.uint8))
+        L.check(self._lib.ndt3d_load_map(self._h, buf.ctypes.data, buf.size), "ndt3d_load_map")
 
     def evaluate(self, sx, sy, sz, pose):
         p = (C.c_double * 6)(*[float(v) for v in pose])

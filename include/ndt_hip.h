@@ -155,6 +155,32 @@ int32_t ndt2d_add_target_points(ndt2d_handle* h, const float* x, const float* y,
  * d_x/d_y (NULL: already complete); the call returns when the grid is updated. */
 int32_t ndt2d_add_target_points_dev(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n,
                                     const double pose[3], size_t* n_outside, void* stream);
+/* ---- submap persistence -------------------------------------------------------------------
+ * The cached grid as a flat buffer: this header, then n_cells per-cell blocks of the EXACT fixed-point sums the
+ * build keeps (2D, 48 B: int64 sx, sy, sxx, sxy, syy; uint32 n, pad.  3D, 80 B: int64 s[3], ss[6] (xx xy xz yy yz
+ * zz); uint32 n, pad.  Coordinates are relative to the cell centre, in units of cell_size / 2^22).  Loading
+ * re-finalises the sums with the LOADING handle's min_points / eig_ratio: with the saving handle's parameters the
+ * grid is bit for bit the one that was saved, it goes on taking points (ndt2d_add_target_points*), and a map can be
+ * re-finalised under other validity rules without the raw points.  cell_size (and overlap_grids) must match the
+ * handle's (NDT_ERR_INVALID_ARG otherwise, as for a buffer that is not a map or is cut short).  The format is
+ * little-endian, as the machines this library runs on. */
+#define NDT_MAP_MAGIC 0x4d54444eu   /* "NDTM" */
+typedef struct ndt_map_header {
+  uint32_t magic, version;         /* NDT_MAP_MAGIC, 1 */
+  int32_t dims, ngrid;             /* 2 or 3; 1, or 4 for the 2D overlapping grids (stored back to back) */
+  int32_t width, height, depth;    /* cells per axis (depth 1 in 2D); x fastest, then y, then z */
+  uint32_t cell_bytes;             /* 48 or 80 */
+  double cell_size;
+  uint64_t n_cells;                /* width * height * depth * ngrid */
+  uint64_t n_points;               /* points binned so far (2D; 0 in 3D) */
+  float origin[4][3];              /* lower corner of grid g */
+} ndt_map_header;
+/* bytes ndt2d_save_map writes for the cached grid (0 without one) */
+size_t ndt2d_map_size(const ndt2d_handle* h);
+/* *written (may be NULL) = the bytes needed, also when capacity is too small (NDT_ERR_CAPACITY) */
+int32_t ndt2d_save_map(ndt2d_handle* h, void* buf, size_t capacity, size_t* written);
+int32_t ndt2d_load_map(ndt2d_handle* h, const void* buf, size_t bytes);
+
 int32_t ndt2d_get_grid_info(ndt2d_handle* h, ndt2d_grid_info* info);
 /* Copies the finalised cell records to host arrays of width*height entries each
  * (any pointer may be NULL): count, mean (x,y interleaved), icov (a,b,c interleaved). */
@@ -435,6 +461,10 @@ int32_t ndt3d_add_target_points_dev(ndt3d_handle* h, const float* d_x, const flo
 /* device arrays; `stream` = the stream that produced them (NULL: already complete) */
 int32_t ndt3d_set_target_dev(ndt3d_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n,
                              void* stream);
+/* submap persistence, as ndt2d_save_map / ndt2d_load_map (dims = 3, 80-byte cell blocks) */
+size_t ndt3d_map_size(const ndt3d_handle* h);
+int32_t ndt3d_save_map(ndt3d_handle* h, void* buf, size_t capacity, size_t* written);
+int32_t ndt3d_load_map(ndt3d_handle* h, const void* buf, size_t bytes);
 int32_t ndt3d_get_grid_info(ndt3d_handle* h, ndt3d_grid_info* info);
 /* count [cells], mean [cells][3], icov [cells][6] (xx xy xz yy yz zz); any pointer may be NULL */
 int32_t ndt3d_get_grid(ndt3d_handle* h, int32_t* count, float* mean_xyz, float* icov6);

@@ -129,6 +129,14 @@ class NdtMatcherHip {
     return outside;
   }
   ndt2d_grid_info gridInfo() const { ndt2d_grid_info g; check(ndt2d_get_grid_info(h_, &g), "ndt2d_get_grid_info"); return g; }
+  // submap persistence: the cached grid as a flat buffer (ndt_map_header + exact per-cell sums), and back - bit for
+  // bit the same grid when the loading matcher has the saving one's parameters; it goes on taking points
+  std::vector<unsigned char> saveMap() const {
+    std::vector<unsigned char> buf(ndt2d_map_size(h_));
+    check(ndt2d_save_map(h_, buf.data(), buf.size(), nullptr), "ndt2d_save_map");
+    return buf;
+  }
+  void loadMap(const std::vector<unsigned char>& buf) { check(ndt2d_load_map(h_, buf.data(), buf.size()), "ndt2d_load_map"); }
 
   // (ii)+(iii)+solve: full alignment from an initial guess
   MatchResult align(const float* sx, const float* sy, size_t n, const Pose2& guess = Pose2()) {
@@ -489,6 +497,13 @@ class NdtMatcherHip3 {
   void reserveTarget(const std::array<double, 3>& lo, const std::array<double, 3>& hi) {
     check(ndt3d_reserve_target(h_, lo.data(), hi.data()), "ndt3d_reserve_target");
   }
+  // submap persistence, as NdtMatcherHip::saveMap / loadMap
+  std::vector<unsigned char> saveMap() const {
+    std::vector<unsigned char> buf(ndt3d_map_size(h_));
+    check(ndt3d_save_map(h_, buf.data(), buf.size(), nullptr), "ndt3d_save_map");
+    return buf;
+  }
+  void loadMap(const std::vector<unsigned char>& buf) { check(ndt3d_load_map(h_, buf.data(), buf.size()), "ndt3d_load_map"); }
   // device points, optionally moved into the map frame by `pose` first (the pose an alignment returned);
   // producer_stream = the stream that wrote them (nullptr: complete)
   size_t addTargetPointsDev(const float* d_x, const float* d_y, const float* d_z, size_t n, const Pose3* pose = nullptr,

@@ -73,6 +73,13 @@ int main(int argc, char** argv) {
     std::printf("infocov %.6f\n", prod);
     const auto loc = ndt::covarianceInLocalFrame(r);   // a rotation of the translation block: trace and rotation variance unchanged
     std::printf("localcov %.6g %.6g\n", (loc[0] + loc[4]) / (r.covariance[0] + r.covariance[4]), loc[8] / r.covariance[8]);
+    {   // the submap through a buffer into a second matcher: the same alignment, bit for bit
+      ndt::NdtMatcherHip m2;
+      m2.loadMap(m.saveMap());
+      const ndt::MatchResult r2 = m2.align(sx, sy, guess);
+      std::printf("maprt %d\n", (r2.pose.x == r.pose.x && r2.pose.y == r.pose.y && r2.pose.theta == r.pose.theta &&
+                                 r2.iterations == r.iterations && r2.information == r.information) ? 1 : 0);
+    }
     ndt::NdtBatchHip b;
     const ndt::NdtBatchHip::Cloud t{tx.data(), ty.data(), tx.size()}, s{sx.data(), sy.data(), sx.size()};
     const auto rs = b.align({t, t}, {s, s}, {guess, guess});

@@ -35,15 +35,18 @@ def test_struct_layout_matches_the_header(tmp_path):
     from gtsam_ndt_amd import _lib
     prog = tmp_path / "sz.c"
     prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ndt_hip.h"\n'
-                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ndt2d_params), sizeof(ndt2d_result),'
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ndt2d_params), sizeof(ndt2d_result),'
                     'sizeof(ndt2d_eval), sizeof(ndt2d_grid_info), offsetof(ndt2d_params, eig_ratio),'
-                    'offsetof(ndt2d_result, score), offsetof(ndt2d_params, min_hits));return 0;}\n')
+                    'offsetof(ndt2d_result, score), offsetof(ndt2d_params, min_hits), sizeof(ndt_map_header),'
+                    'offsetof(ndt_map_header, cell_size), offsetof(ndt_map_header, origin));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
     out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert out == [C.sizeof(_lib.Params2D), C.sizeof(_lib.Result2D), C.sizeof(_lib.Eval2D),
                    C.sizeof(_lib.GridInfo2D), _lib.Params2D.eig_ratio.offset, _lib.Result2D.score.offset,
-                   _lib.Params2D.min_hits.offset]
+                   _lib.Params2D.min_hits.offset, C.sizeof(_lib.MapHeader), _lib.MapHeader.cell_size.offset,
+                   _lib.MapHeader.origin.offset]
+    assert C.sizeof(_lib.MapHeader) == 104
 
 
 def test_header_is_plain_c(tmp_path):

@@ -62,6 +62,7 @@ def test_adapter_matches_oracle(exe, tmp_path, gpu_lib):
         assert np.abs(pose - np.array(ref["pose"])).max() < 1e-4
         assert int(lines[key][-1]) == 0
     assert lines["multi"] == lines["batch"]          # same kernel, same pair: bit-identical
+    assert lines["maprt"] == ["1"]                  # saveMap -> loadMap into a second matcher: the same alignment
     # device-pointer forms through the C++ adapter: the resident scan, several starts / scans per chain (start 0
     # and scan 0 are the plain alignment: bit-identical to it), the RCCL gather of the multi-device context
     assert lines["dev"][:5] == lines["single"][:3] + [lines["single"][3], lines["single"][5]]

@@ -1,0 +1,116 @@
+"""Submap persistence (ndt2d_save_map / ndt2d_load_map and the 3D twins): the cached grid leaves a handle as its exact
+per-cell sums and comes back bit for bit - records, alignments and later submap updates included."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gtsam_ndt_amd import synth, synth3d
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_grid(a, b):
+    for x, y in zip(a.grid(), b.grid()):
+        assert np.array_equal(x, y)
+    ia, ib = a.grid_info(), b.grid_info()
+    for f, _ in ia._fields_:
+        assert getattr(ia, f) == getattr(ib, f), f
+
+
+@pytest.mark.parametrize("overlap", [0, 4])
+def test_2d_map_round_trip_is_bit_exact(gpu_lib, overlap):
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(2, n_tgt=60_000, n_src=20_000)
+    other = synth.make_pair(3, n_tgt=200_000, n_src=1000)               # a bigger grid the loading handle held before
+    kw = dict(overlap_grids=overlap)
+    with NdtMatcher2D(**kw) as a, NdtMatcher2D(**kw) as b, NdtMatcher2D(**kw) as small:
+        a.set_target(d["tx"], d["ty"])
+        blob = a.save_map()
+        hdr = L.MapHeader.from_buffer_copy(blob[:C.sizeof(L.MapHeader)].tobytes())
+        info = a.grid_info()
+        assert (hdr.magic, hdr.version, hdr.dims, hdr.ngrid) == (L.MAP_MAGIC, 1, 2, 4 if overlap == 4 else 1)
+        assert (hdr.width, hdr.height, hdr.depth, hdr.cell_bytes) == (info.width, info.height, 1, 48)
+        assert blob.size == 104 + 48 * hdr.n_cells and hdr.n_points == 60_000 and hdr.cell_size == 0.5
+        b.set_target(other["tx"], other["ty"])                          # stale records of another, larger map
+        b.load_map(blob)
+        small.load_map(blob.tobytes())                                  # a fresh handle, from bytes
+        for m in (b, small):
+            _same_grid(a, m)
+            ra, rm = a.align(d["sx"], d["sy"], d["init"]), m.align(d["sx"], d["sy"], d["init"])
+            assert ra.pose == rm.pose and np.array_equal(ra.H, rm.H) and ra.iterations == rm.iterations and ra.status == 0
+        # the reloaded submap goes on taking points exactly as the original does
+        x2, y2 = d["sx"], d["sy"]                                      # the scan, a few centimetres off: more points per cell
+        na, nb = a.add_target_points(x2, y2), b.add_target_points(x2, y2)
+        assert na == nb
+        _same_grid(a, b)
+        assert np.array_equal(a.save_map(), b.save_map())
+
+
+def test_2d_map_reloads_under_other_validity_rules(gpu_lib):
+    """The sums are parameter-free: loading with min_points = 12 gives the grid set_target builds with min_points = 12."""
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(2, n_tgt=40_000, n_src=1000)
+    with NdtMatcher2D() as a, NdtMatcher2D(min_points=12, eig_ratio=0.01) as b, NdtMatcher2D(min_points=12, eig_ratio=0.01) as ref:
+        a.set_target(d["tx"], d["ty"])
+        b.load_map(a.save_map())
+        ref.set_target(d["tx"], d["ty"])
+        _same_grid(b, ref)
+        assert b.grid_info().n_valid < a.grid_info().n_valid
+
+
+def test_map_errors(gpu_lib):
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtMatcher2D, NdtMatcher3D
+    lib = L.load()
+    d = synth.make_pair(1)
+    d3 = synth3d.make_pair3d(n_elev=16, n_azim=256)
+    with NdtMatcher2D() as a, NdtMatcher2D(cell_size=0.25) as fine, NdtMatcher2D(overlap_grids=4) as four, NdtMatcher3D() as m3:
+        with pytest.raises(L.NdtError) as e:
+            a.save_map()
+        assert e.value.code == L.NDT_ERR_NO_TARGET and lib.ndt2d_map_size(a._h) == 0
+        a.set_target(d["tx"], d["ty"])
+        blob = a.save_map()
+        need = C.c_size_t(0)
+        short = np.empty(200, np.uint8)
+        assert lib.ndt2d_save_map(a._h, short.ctypes.data, short.size, C.byref(need)) == L.NDT_ERR_CAPACITY and need.value == blob.size
+        bad = blob.copy(); bad[0] ^= 0xFF
+        for h, buf in ((a, bad), (a, blob[:-8]), (a, blob[:50]), (fine, blob), (four, blob)):
+            with pytest.raises(L.NdtError) as e:
+                h.load_map(buf)
+            assert e.value.code == L.NDT_ERR_INVALID_ARG
+        with pytest.raises(L.NdtError) as e:
+            m3.load_map(blob)                                            # a 2D map into a 3D handle
+        assert e.value.code == L.NDT_ERR_INVALID_ARG
+        m3.set_target(d3["tx"], d3["ty"], d3["tz"])
+        with pytest.raises(L.NdtError):
+            a.load_map(m3.save_map())
+        # a failed load leaves the handle without a target rather than with half of one
+        r = a.align(d["sx"], d["sy"], d["init"])
+        assert r.status == 0                                             # header errors are caught before anything is touched
+
+
+def test_3d_map_round_trip_is_bit_exact(gpu_lib):
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    d = synth3d.make_pair3d(n_elev=32, n_azim=1024)
+    big = synth3d.make_pair3d(n_elev=64, n_azim=512, pose=(0.3, 0.1, 0.0, 0.0, 0.0, 0.1))
+    for mode in (0, 1):
+        with NdtMatcher3D(hessian_mode=mode) as a, NdtMatcher3D(hessian_mode=mode, cell_size=1.0) as b:
+            a.set_target(d["tx"], d["ty"], d["tz"])
+            blob = a.save_map()
+            hdr = L.MapHeader.from_buffer_copy(blob[:104].tobytes())
+            info = a.grid_info()
+            assert (hdr.dims, hdr.ngrid, hdr.cell_bytes) == (3, 1, 80)
+            assert (hdr.width, hdr.height, hdr.depth) == (info.width, info.height, info.depth) and blob.size == 104 + 80 * hdr.n_cells
+            b.set_target(big["tx"], big["ty"], big["tz"])
+            b.load_map(blob)
+            _same_grid(a, b)
+            ra, rb = a.align(d["sx"], d["sy"], d["sz"], d["init"]), b.align(d["sx"], d["sy"], d["sz"], d["init"])
+            assert ra.pose == rb.pose and np.array_equal(ra.H, rb.H) and (ra.status, ra.iterations) == (rb.status, rb.iterations)
+            assert mode == 1 or ra.status == 0                           # (Newton steps on this sparse pair wander; the contract is equality)
+            na, nb = a.add_target_points(big["tx"], big["ty"], big["tz"]), b.add_target_points(big["tx"], big["ty"], big["tz"])
+            assert na == nb
+            _same_grid(a, b)
+            assert np.array_equal(a.save_map(), b.save_map())
