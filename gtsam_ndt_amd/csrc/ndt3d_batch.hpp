@@ -317,6 +317,9 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     __syncthreads();                               // every wave has read out[pair] before anyone rewrites it
   }
 
+#ifdef NDT_B3_PHASE_CLOCKS
+  long long pc_t[8]; pc_t[0] = wall_clock64();
+#endif
   // ---- a1: bounding box of the target and grid geometry (oracle/ndt3d.py grid_geometry3)
   {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -393,6 +396,9 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     return in;
   };
 
+#ifdef NDT_B3_PHASE_CLOCKS
+  pc_t[1] = wall_clock64();
+#endif
   // ---- a2 (1/2): per-voxel counts
   if constexpr (GLOBAL) {
     // global tables: a range of voxels at a time in LDS (the kernel has the CU's LDS to itself; one pass over the target
@@ -426,6 +432,9 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     __syncthreads();
   }
 
+#ifdef NDT_B3_PHASE_CLOCKS
+  pc_t[2] = wall_clock64();
+#endif
   // ---- compaction: voxels with n >= min_points get a slot, in voxel order (deterministic)
   const int chunk = (ncell + kB3Threads - 1) / kB3Threads;
   const int c0 = tid * chunk < ncell ? tid * chunk : ncell;
@@ -465,6 +474,9 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   }
   __syncthreads();                                 // cnt is dead; its bytes become the pass sums
 
+#ifdef NDT_B3_PHASE_CLOCKS
+  pc_t[3] = wall_clock64();
+#endif
   if constexpr (GLOBAL) {
     // ---- a2 (2/2), global variant: the nine exact sums of a range of slots at a time in LDS, one pass over the target
     // per range (LDS atomics; the first version added them with 64-bit atomics at L2, which bounded the variant)
@@ -540,6 +552,9 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   __threadfence();                                 // the slab was written with plain stores by other waves of this workgroup
   __syncthreads();
 
+#ifdef NDT_B3_PHASE_CLOCKS
+  pc_t[4] = wall_clock64();
+#endif
   // ---- a3: finalise, records into LDS (global variant: into the slab)
   {
     int nvalid = 0;
@@ -575,6 +590,9 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     return;
   }
 
+#ifdef NDT_B3_PHASE_CLOCKS
+  pc_t[5] = wall_clock64();
+#endif
   // ---- a4-a8: Gauss-Newton loop, all on this CU
   if (tid == 0) { misc[9] = 0; misc[10] = 0; ls_lds->valid = 0; ls_lds->trials = 0; }
   __syncthreads();
@@ -705,6 +723,12 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   }
   if (tid == 0)
     write_result3(out, pose, bc + 6, bc + 6 + 21, bc[6 + 27], misc[9] + iter_base, (int)(bc[6 + 28] + 0.5), misc[10]);
+#ifdef NDT_B3_PHASE_CLOCKS
+  if (tid == 0) {                  // tools: 100 MHz ticks per phase in the unused lower triangle of H
+    pc_t[6] = wall_clock64();
+    for (int j = 0; j < 6; ++j) out->H[30 + j] = (double)(pc_t[j + 1] - pc_t[j]);
+  }
+#endif
 }
 
 template <int MODE>

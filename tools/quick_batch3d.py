@@ -1,5 +1,5 @@
 """Timing of the 3D loop-closure batch (k_batch3) on replicated config-5 pairs.
-usage: python tools/quick_batch3d.py [n_pairs=256] [distinct=4] [n_azim=2048] [mode=0] [cell=1.0]"""
+usage: python tools/quick_batch3d.py [n_pairs=256] [distinct=4] [n_azim=2048] [mode=0] [cell=1.0] [iterations=30]"""
 import sys, time
 import numpy as np
 import torch
@@ -14,7 +14,7 @@ distinct = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 n_azim = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 cell = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
-K = 30
+K = int(sys.argv[6]) if len(sys.argv) > 6 else 30
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(5)
 poses = [tuple(np.array(synth3d.T_STAR_3D) * rng.uniform(-1.0, 1.0, 6)) for _ in range(distinct)]
