@@ -118,6 +118,39 @@ __device__ __forceinline__ void for_each_target_point3(const float* tx, const fl
   }
 }
 
+// The build's passes that add into LDS walk the target in ROWS of 64 points: lane l of a wave takes the points
+// i = 64 row + l of the wave's contiguous block of rows, one row per step (coalesced: a row is 256 B).  A 64-beam scan
+// in firing order (all beams of one azimuth, then the next azimuth) puts one beam in every lane, and consecutive rows of
+// a lane are neighbouring bearings of that beam - the same voxel for tens of steps - so a lane adds a run of equal keys
+// up in registers and issues its LDS atomics once per run instead of once per point (they are 23 % of a config-5 pair's
+// time otherwise).  Any other order of the cloud is as correct (the sums are exact integers: every
+// partition gives the same bits) and costs what the plain loop costs.  body(x, y, z) sees the lane's points in order.
+template <typename F>
+__device__ __forceinline__ void for_each_target_point_rows3(const float* tx, const float* ty, const float* tz, int nt, F&& body) {
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)tx, 0, nt * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)ty, 0, nt * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)tz, 0, nt * 4, 0x00020000);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = (nt + 63) >> 6;
+  const int per_wave = (rows + kB3Waves - 1) / kB3Waves;
+  const int r0 = wave * per_wave;
+  const int r1 = r0 + per_wave < rows ? r0 + per_wave : rows;
+  constexpr int U = 4;                                                // rows in flight
+  for (int r = r0; r < r1; r += U) {
+    float x[U], y[U], z[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int off = (((r + u) << 6) + lane) * 4;                    // beyond the cloud: the buffer returns 0, unused
+      x[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+      y[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
+      z[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, off, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (r + u < r1 && ((r + u) << 6) + lane < nt) body(x[u], y[u], z[u]);
+  }
+}
+
 struct Cfg1024 { static constexpr int kWaves = kB3Waves; };   // for block_excl_scan
 
 __device__ __forceinline__ void write_result3(Result3Dev* o, const double* pose, const double* s21, const double* g,
@@ -410,13 +443,22 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
       const int np = ncell - c0 < kPassCells ? ncell - c0 : kPassCells;
       for (int k = tid; k < np; k += kB3Threads) pc[k] = 0u;
       __syncthreads();
-      for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
-        int ix, iy, iz;
-        if (voxel_of(px, py, pz, ix, iy, iz)) {
-          const int r = __mul24(__mul24(iz, Hh) + iy, W) + ix - c0;
-          if ((unsigned)r < (unsigned)np) atomicAdd(&pc[r], 1u);
-        }
-      });
+      {
+        int cur = -1;                                  // the lane's current run: voxel (relative to c0; -1 = none of this range)
+        unsigned int run = 0u;
+        for_each_target_point_rows3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+          int ix, iy, iz;
+          int r = -1;
+          if (voxel_of(px, py, pz, ix, iy, iz)) r = __mul24(__mul24(iz, Hh) + iy, W) + ix - c0;
+          if ((unsigned)r >= (unsigned)np) r = -1;
+          if (r != cur) {
+            if (cur >= 0) atomicAdd(&pc[cur], run);
+            cur = r; run = 0u;
+          }
+          ++run;
+        });
+        if (cur >= 0) atomicAdd(&pc[cur], run);
+      }
       __syncthreads();
       for (int k = tid; k < np; k += kB3Threads) cnt[c0 + k] = pc[k];
       __syncthreads();
@@ -425,10 +467,20 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
   } else {
     for (int k = tid; k < ncell; k += kB3Threads) cnt[k] = 0u;
     __syncthreads();
-    for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
-      int ix, iy, iz;
-      if (voxel_of(px, py, pz, ix, iy, iz)) atomicAdd(&cnt[__mul24(__mul24(iz, Hh) + iy, W) + ix], 1u);
-    });
+    {
+      int cur = -1;                                    // the lane's current run of points of one voxel
+      unsigned int run = 0u;
+      for_each_target_point_rows3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+        int ix, iy, iz;
+        const int key = voxel_of(px, py, pz, ix, iy, iz) ? __mul24(__mul24(iz, Hh) + iy, W) + ix : -1;
+        if (key != cur) {
+          if (cur >= 0) atomicAdd(&cnt[cur], run);
+          cur = key; run = 0u;
+        }
+        ++run;
+      });
+      if (cur >= 0) atomicAdd(&cnt[cur], run);
+    }
     __syncthreads();
   }
 
@@ -477,6 +529,59 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
 #ifdef NDT_B3_PHASE_CLOCKS
   pc_t[3] = wall_clock64();
 #endif
+  // One pass over the target for rows [j0, j1) of the nine exact sums (s[0..2], ss[0..5] = xx xy xz yy yz zz) of the
+  // slots [s0, s0 + np): base[(row - j0) * stride + slot - 1 - s0] in LDS.  A lane adds a run of points of one voxel up
+  // in registers (for_each_target_point_rows3) and issues the 64-bit LDS atomics once per run; a run ends after 256
+  // points at the latest, so the three coordinate sums stay in 32 bits (|u| <= 2^21).
+  auto sum_pass = [&](unsigned long long* base, int stride, int j0, int j1, int s0, int np) {
+    int cur = -2, r = -1, run = 0;
+    double ccx = 0.0, ccy = 0.0, ccz = 0.0;
+    int a0 = 0, a1 = 0, a2 = 0;
+    long long pr[6] = {0, 0, 0, 0, 0, 0};
+    auto flush = [&]() {
+      if (r >= 0) {
+        unsigned long long* q = base + r;
+        const unsigned long long v[9] = {(unsigned long long)(long long)a0, (unsigned long long)(long long)a1,
+                                         (unsigned long long)(long long)a2, (unsigned long long)pr[0], (unsigned long long)pr[1],
+                                         (unsigned long long)pr[2], (unsigned long long)pr[3], (unsigned long long)pr[4],
+                                         (unsigned long long)pr[5]};
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+          if (c >= j0 && c < j1) atomicAdd(q + (c - j0) * stride, v[c]);      // uniform condition
+      }
+      a0 = a1 = a2 = 0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) pr[c] = 0;
+      run = 0;
+    };
+    for_each_target_point_rows3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+      int ix, iy, iz;
+      const int key = voxel_of(px, py, pz, ix, iy, iz) ? __mul24(__mul24(iz, Hh) + iy, W) + ix : -1;
+      if (key != cur || run == 256) {
+        flush();
+        cur = key;
+        r = -1;
+        if (key >= 0) {
+          r = (int)idx[key] - 1 - s0;                                        // no slot: r < 0
+          if ((unsigned)r >= (unsigned)np) r = -1;
+          ccx = cell_centre(ox, ix, a.cell); ccy = cell_centre(oy, iy, a.cell); ccz = cell_centre(oz, iz, a.cell);
+        }
+      }
+      if (r >= 0) {
+        const int ux = fix_coord(px, ccx, fix_scale), uy = fix_coord(py, ccy, fix_scale), uz = fix_coord(pz, ccz, fix_scale);
+        a0 += ux; a1 += uy; a2 += uz;
+        if (3 >= j0 && 3 < j1) pr[0] += (long long)ux * ux;                  // uniform conditions: only this pass's rows
+        if (4 >= j0 && 4 < j1) pr[1] += (long long)ux * uy;
+        if (5 >= j0 && 5 < j1) pr[2] += (long long)ux * uz;
+        if (6 >= j0 && 6 < j1) pr[3] += (long long)uy * uy;
+        if (7 >= j0 && 7 < j1) pr[4] += (long long)uy * uz;
+        if (8 >= j0 && 8 < j1) pr[5] += (long long)uz * uz;
+        ++run;
+      }
+    });
+    flush();
+  };
+
   if constexpr (GLOBAL) {
     // ---- a2 (2/2), global variant: the nine exact sums of a range of slots at a time in LDS, one pass over the target
     // per range (LDS atomics; the first version added them with 64-bit atomics at L2, which bounded the variant)
@@ -487,27 +592,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
       const int np = nslot - s0 < kPassSlots ? nslot - s0 : kPassSlots;
       for (int j = tid; j < 9 * np; j += kB3Threads) ps[j] = 0ull;
       __syncthreads();
-      for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
-        int ix, iy, iz;
-        if (voxel_of(px, py, pz, ix, iy, iz)) {
-          const int r = (int)idx[__mul24(__mul24(iz, Hh) + iy, W) + ix] - 1 - s0;      // no slot: r < 0
-          if ((unsigned)r < (unsigned)np) {
-            const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
-            const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
-            const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
-            unsigned long long* q = ps + r;
-            atomicAdd(q, (unsigned long long)(long long)ux);
-            atomicAdd(q + np, (unsigned long long)(long long)uy);
-            atomicAdd(q + 2 * np, (unsigned long long)(long long)uz);
-            atomicAdd(q + 3 * np, prod64(ux, ux));
-            atomicAdd(q + 4 * np, prod64(ux, uy));
-            atomicAdd(q + 5 * np, prod64(ux, uz));
-            atomicAdd(q + 6 * np, prod64(uy, uy));
-            atomicAdd(q + 7 * np, prod64(uy, uz));
-            atomicAdd(q + 8 * np, prod64(uz, uz));
-          }
-        }
-      });
+      sum_pass(ps, np, 0, 9, s0, np);
       __syncthreads();
       for (int j = tid; j < 9 * np; j += kB3Threads) gsums[(size_t)(j / np) * kS + s0 + (j % np)] = ps[j];
       __syncthreads();
@@ -523,25 +608,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
       const int j1 = j0 + per < 9 ? j0 + per : 9;
       for (int j = tid; j < (j1 - j0) * nslot; j += kB3Threads) psum[j] = 0ull;
       __syncthreads();
-      for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
-        int ix, iy, iz;
-        if (voxel_of(px, py, pz, ix, iy, iz)) {
-          const int slot = idx[__mul24(__mul24(iz, Hh) + iy, W) + ix];
-          if (slot) {
-            const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
-            const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
-            const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
-            // s[0..2], ss[0..5] = xx xy xz yy yz zz
-            const unsigned long long v[9] = {(unsigned long long)(long long)ux, (unsigned long long)(long long)uy,
-                                             (unsigned long long)(long long)uz, prod64(ux, ux), prod64(ux, uy), prod64(ux, uz),
-                                             prod64(uy, uy), prod64(uy, uz), prod64(uz, uz)};
-            unsigned long long* q = psum + (slot - 1);
-#pragma unroll
-            for (int c = 0; c < 9; ++c)
-              if (c >= j0 && c < j1) atomicAdd(q + (c - j0) * nslot, v[c]);      // uniform condition
-          }
-        }
-      });
+      sum_pass(psum, nslot, j0, j1, 0, nslot);
       __syncthreads();
       for (int j = tid; j < (j1 - j0) * nslot; j += kB3Threads)
         gsums[(size_t)(j0 + j / nslot) * kS + (j % nslot)] = psum[j];

@@ -211,6 +211,7 @@ struct Lidar3dArgs {
   double el0, el_step, az_step, amp;             // beam pattern; amp = sqrt(3) * sigma
   unsigned long long seed;
   int n_box, n_elev, n_azim;
+  int firing_order;   // 0: ring by ring (ring-major); 1: all beams of a bearing, then the next bearing (as a driver delivers them)
 };
 __global__ __launch_bounds__(256) void k_lidar3d(Lidar3dArgs a, float* __restrict__ x, float* __restrict__ y,
                                                  float* __restrict__ z) {
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(256) void k_lidar3d(Lidar3dArgs a, float* __restric
     const unsigned long long k = 4ull * (unsigned long long)i;
     const double noise = (uniform01(a.seed, k) + uniform01(a.seed, k + 1) + uniform01(a.seed, k + 2) + uniform01(a.seed, k + 3) - 2.0) * a.amp;
     const double r = t_hit + noise;
-    x[i] = (float)(ds[0] * r); y[i] = (float)(ds[1] * r); z[i] = (float)(ds[2] * r);
+    const int o = a.firing_order ? j * a.n_elev + e : i;          // the same points either way: only their order differs
+    x[o] = (float)(ds[0] * r); y[o] = (float)(ds[1] * r); z[o] = (float)(ds[2] * r);
   }
 }
 
@@ -335,7 +337,7 @@ int32_t ndt_synth_config4_dev(uint64_t first_pair, size_t n_pairs, size_t n_tgt,
 
 int32_t ndt_synth_lidar3d_dev(const double* boxes_lo, const double* boxes_hi, int32_t n_box, double L, double height,
                               double sensor_z, uint64_t seed, const double pose[6], int32_t n_elev, int32_t n_azim,
-                              double sigma, float* d_x, float* d_y, float* d_z, void* stream) {
+                              double sigma, int32_t firing_order, float* d_x, float* d_y, float* d_z, void* stream) {
   if (!boxes_lo || !boxes_hi || n_box < 0 || n_box > kMaxBoxes || !pose || n_elev < 1 || n_azim < 1 || !d_x || !d_y || !d_z ||
       !(L > 0.0) || !(height > 0.0))
     return -1;
@@ -357,6 +359,7 @@ int32_t ndt_synth_lidar3d_dev(const double* boxes_lo, const double* boxes_hi, in
   a.amp = kSqrt3 * sigma;
   a.seed = seed;
   a.n_box = n_box; a.n_elev = n_elev; a.n_azim = n_azim;
+  a.firing_order = firing_order ? 1 : 0;
   const size_t n = (size_t)n_elev * (size_t)n_azim;
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;

@@ -25,7 +25,7 @@ SIGNATURES = {
     "ndt_synth_config4_dev": (C.c_int32, [C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
     "ndt_synth_lidar3d_dev": (C.c_int32, [_vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, _vp, C.c_int32,
-                                          C.c_int32, C.c_double, _vp, _vp, _vp, _vp]),
+                                          C.c_int32, C.c_double, C.c_int32, _vp, _vp, _vp, _vp]),
     "ndt_synth_last_error": (C.c_char_p, []),
 }
 
@@ -108,10 +108,12 @@ def config4_batch(first_pair: int, n_pairs: int, n_tgt: int = 100_000, n_src: in
 
 
 def lidar_scan3d(seed: int, pose, n_elev: int = 64, n_azim: int = 2048, sigma: float = 0.02, L: float = 40.0,
-                 height: float = 6.0, scene_seed: int = 5, device="cuda:0", out=None):
+                 height: float = 6.0, scene_seed: int = 5, device="cuda:0", out=None, firing_order: bool = False):
     """synth3d.lidar_scan on the device (ndt_synth_lidar3d_dev): (x, y, z) float32 CUDA tensors of n_elev * n_azim
     sensor-frame points.  Same scene, beams and noise as the numpy generator; equal to it up to float32 rounding
-    (not bit for bit: the beam directions' cos / sin come from the device's libm)."""
+    (not bit for bit: the beam directions' cos / sin come from the device's libm).  firing_order=True: the same points
+    in the order a spinning lidar's driver delivers them (all beams of one bearing, then the next bearing) instead of
+    ring by ring."""
     import torch
     from . import synth3d
     lo, hi = synth3d.scene_boxes(scene_seed, L, height)
@@ -126,6 +128,6 @@ def lidar_scan3d(seed: int, pose, n_elev: int = 64, n_azim: int = 2048, sigma: f
     with torch.cuda.device(out[0].device):
         _check(load().ndt_synth_lidar3d_dev(lo.ctypes.data, hi.ctypes.data, lo.shape[0], float(L), float(height),
                                             float(synth3d.SENSOR_Z), int(seed), C.cast(p, _vp), int(n_elev), int(n_azim),
-                                            float(sigma), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                            float(sigma), int(bool(firing_order)), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
                                             torch.cuda.current_stream().cuda_stream), "ndt_synth_lidar3d_dev")
     return out

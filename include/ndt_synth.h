@@ -47,13 +47,15 @@ int32_t ndt_synth_config4_dev(uint64_t first_pair, size_t n_pairs, size_t n_tgt,
 /* synth3d.lidar_scan(seed, pose, n_elev, n_azim, sigma) on the device: the 64-beam lidar of BASELINE config 5 ray
  * cast against the box room [-L/2, L/2]^2 x [0, height] with the clutter boxes boxes_lo / boxes_hi (HOST arrays
  * [n_box][3], n_box <= 32: synth3d.scene_boxes), sensor at pose (tx, ty, tz + sensor_z; roll, pitch, yaw), points in
- * the SENSOR frame, ring-major.  Same beams, same noise counters, float64 ray casting; NOT bit-identical to numpy
+ * the SENSOR frame, ring by ring (firing_order = 0: index = ring * n_azim + bearing, as synth3d) or in firing order
+ * (firing_order = 1: index = bearing * n_elev + ring - all beams of one bearing, then the next bearing, as a
+ * spinning lidar's driver delivers them; the same points, permuted).  Same beams, same noise counters, float64 ray casting; NOT bit-identical to numpy
  * (the beams' cos / sin come from the device's libm): points agree to float32 rounding except for a ray that grazes
  * a box edge.  d_x / d_y / d_z: device arrays of n_elev * n_azim floats.  Asynchronous on `stream`. */
 #define NDT_SYNTH_MAX_BOXES 32
 int32_t ndt_synth_lidar3d_dev(const double* boxes_lo, const double* boxes_hi, int32_t n_box, double L, double height,
                               double sensor_z, uint64_t seed, const double pose[6], int32_t n_elev, int32_t n_azim,
-                              double sigma, float* d_x, float* d_y, float* d_z, void* stream);
+                              double sigma, int32_t firing_order, float* d_x, float* d_y, float* d_z, void* stream);
 
 /* text of the last error on this thread ("" if none) */
 const char* ndt_synth_last_error(void);

@@ -251,3 +251,29 @@ def test_multi_device_3d_context_host_shards_and_rccl_gather(gpu_lib):
         with pytest.raises(L.NdtError) as e:
             m.align_dev([shard, None])
         assert e.value.code == L.NDT_ERR_INVALID_ARG
+
+
+def test_batch3d_does_not_depend_on_the_order_of_the_points(gpu_lib):
+    """The build walks the target in rows of 64 points and adds runs of one voxel up in registers before it touches LDS
+    (fast on scans in firing order); its sums are exact integers, so any order of the same points gives the same grid,
+    and the alignment differs by float32 summation order only: ring by ring, firing order, shuffled."""
+    from gtsam_ndt_amd.matcher import NdtBatch3D
+    ds, T, S = _pairs(POSES[:2], [(64, 512), (16, 300)])
+    inits = [d["init"] for d in ds]
+    rng = np.random.default_rng(3)
+    def reorder(c, how, shape):
+        n = len(c[0])
+        if how == "firing":
+            perm = np.arange(n).reshape(shape).T.reshape(-1)
+        else:
+            perm = rng.permutation(n)
+        return tuple(np.ascontiguousarray(np.asarray(a)[perm]) for a in c)
+    shapes = [(64, 512), (16, 300)]
+    with NdtBatch3D() as b:
+        ref = b.align(T, S, inits)
+        for how in ("firing", "shuffled"):
+            T2 = [reorder(c, how, sh) for c, sh in zip(T, shapes)]
+            S2 = [reorder(c, how, sh) for c, sh in zip(S, shapes)]
+            for x, y in zip(b.align(T2, S2, inits), ref):
+                assert x.status == y.status == 0 and abs(x.iterations - y.iterations) <= 1 and abs(x.n_hit - y.n_hit) <= 2
+                assert np.abs(np.array(x.pose) - np.array(y.pose)).max() < 5e-6, (how, x.pose, y.pose)

@@ -86,3 +86,8 @@ def test_device_lidar3d_matches_numpy_generator(gpu_lib):
         err = np.abs(got - ref).max(axis=1)
         assert (err > 1e-5).sum() <= 4, ((err > 1e-5).sum(), err.max())
         assert np.median(err) < 2e-6
+        # firing order (all beams of one bearing, then the next bearing): the same points, permuted, bit for bit
+        fx, fy, fz = (t.cpu().numpy() for t in synth_dev.lidar_scan3d(seed, pose, shape[0], shape[1], 0.02, scene_seed=scene,
+                                                                       firing_order=True))
+        for ring_major, firing in ((x, fx), (y, fy), (z, fz)):
+            assert np.array_equal(ring_major.reshape(shape).T.reshape(-1), firing)
