@@ -443,22 +443,13 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
       const int np = ncell - c0 < kPassCells ? ncell - c0 : kPassCells;
       for (int k = tid; k < np; k += kB3Threads) pc[k] = 0u;
       __syncthreads();
-      {
-        int cur = -1;                                  // the lane's current run: voxel (relative to c0; -1 = none of this range)
-        unsigned int run = 0u;
-        for_each_target_point_rows3(tx, ty, tz, nt, [&](float px, float py, float pz) {
-          int ix, iy, iz;
-          int r = -1;
-          if (voxel_of(px, py, pz, ix, iy, iz)) r = __mul24(__mul24(iz, Hh) + iy, W) + ix - c0;
-          if ((unsigned)r >= (unsigned)np) r = -1;
-          if (r != cur) {
-            if (cur >= 0) atomicAdd(&pc[cur], run);
-            cur = r; run = 0u;
-          }
-          ++run;
-        });
-        if (cur >= 0) atomicAdd(&pc[cur], run);
-      }
+      for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {        // (the row-wise walk of the on-chip
+        int ix, iy, iz;                                                                  //  build measured slower here)
+        if (voxel_of(px, py, pz, ix, iy, iz)) {
+          const int r = __mul24(__mul24(iz, Hh) + iy, W) + ix - c0;
+          if ((unsigned)r < (unsigned)np) atomicAdd(&pc[r], 1u);
+        }
+      });
       __syncthreads();
       for (int k = tid; k < np; k += kB3Threads) cnt[c0 + k] = pc[k];
       __syncthreads();
@@ -592,7 +583,27 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
       const int np = nslot - s0 < kPassSlots ? nslot - s0 : kPassSlots;
       for (int j = tid; j < 9 * np; j += kB3Threads) ps[j] = 0ull;
       __syncthreads();
-      sum_pass(ps, np, 0, 9, s0, np);
+      for_each_target_point3(tx, ty, tz, nt, [&](float px, float py, float pz) {
+        int ix, iy, iz;
+        if (voxel_of(px, py, pz, ix, iy, iz)) {
+          const int r = (int)idx[__mul24(__mul24(iz, Hh) + iy, W) + ix] - 1 - s0;      // no slot: r < 0
+          if ((unsigned)r < (unsigned)np) {
+            const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
+            const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
+            const int uz = fix_coord(pz, cell_centre(oz, iz, a.cell), fix_scale);
+            unsigned long long* q = ps + r;
+            atomicAdd(q, (unsigned long long)(long long)ux);
+            atomicAdd(q + np, (unsigned long long)(long long)uy);
+            atomicAdd(q + 2 * np, (unsigned long long)(long long)uz);
+            atomicAdd(q + 3 * np, prod64(ux, ux));
+            atomicAdd(q + 4 * np, prod64(ux, uy));
+            atomicAdd(q + 5 * np, prod64(ux, uz));
+            atomicAdd(q + 6 * np, prod64(uy, uy));
+            atomicAdd(q + 7 * np, prod64(uy, uz));
+            atomicAdd(q + 8 * np, prod64(uz, uz));
+          }
+        }
+      });
       __syncthreads();
       for (int j = tid; j < 9 * np; j += kB3Threads) gsums[(size_t)(j / np) * kS + s0 + (j % np)] = ps[j];
       __syncthreads();

@@ -1,5 +1,5 @@
 """Timing of the 3D loop-closure batch (k_batch3) on replicated config-5 pairs.
-usage: python tools/quick_batch3d.py [n_pairs=256] [distinct=4] [n_azim=2048] [mode=0] [cell=1.0] [iterations=30]"""
+usage: python tools/quick_batch3d.py [n_pairs=256] [distinct=4] [n_azim=2048] [mode=0] [cell=1.0] [iterations=30] [order=ring|firing]"""
 import sys, time
 import numpy as np
 import torch
@@ -19,6 +19,10 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(5)
 poses = [tuple(np.array(synth3d.T_STAR_3D) * rng.uniform(-1.0, 1.0, 6)) for _ in range(distinct)]
 ds = [synth3d.make_pair3d(n_azim=n_azim, pose=p) for p in poses]
+if len(sys.argv) > 7 and sys.argv[7] == "firing":      # all 64 beams of one bearing, then the next bearing (a driver's order)
+    for d_ in ds:
+        for c in ("tx", "ty", "tz", "sx", "sy", "sz"):
+            d_[c] = np.ascontiguousarray(d_[c].reshape(64, n_azim).T).reshape(-1)
 npts = ds[0]["tx"].size
 rep = [k % distinct for k in range(n_pairs)]
 t = [torch.from_numpy(np.concatenate([ds[r][c] for r in rep])).to(dev) for c in ("tx", "ty", "tz")]
