@@ -520,7 +520,10 @@ int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
  * Beyond that a pair gets status NDT_ERR_CAPACITY from the _dev entry point, and the host-pointer entry
  * point re-runs it through the single-pair path transparently.  Stream semantics as ndt2d_batch_align_dev.
  * A context holds about 2.1 GB of device memory (per-workgroup slabs of the build and of the global-memory variant;
- * NDT_TUNE_BATCH_GLOBAL_WORKGROUPS trades most of it against that variant's rate). */
+ * NDT_TUNE_BATCH_GLOBAL_WORKGROUPS trades most of it against that variant's rate).
+ * Results do not depend on the order of a cloud's points beyond float32 summation order (the grid not at all);
+ * the grid build is fastest on scans left in the order a 64-beam driver delivers them (all beams of one bearing, then
+ * the next bearing): it walks a cloud in rows of 64 points and combines a lane's consecutive rows in registers. */
 typedef struct ndt3d_batch ndt3d_batch;
 int32_t ndt3d_batch_create(const ndt3d_params* p, int32_t device_id, ndt3d_batch** out);
 /* coarse-to-fine over the batch, as ndt2d_batch_create_pyramid (levels coarse to fine, at most 8) */
