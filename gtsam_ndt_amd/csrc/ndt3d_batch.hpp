@@ -410,15 +410,16 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     }
     return;
   }
-  // on chip: per-pair carve behind the voxel table; global variant: fixed regions of the slab, and the counts
-  // of the build live in the voxel table itself (converted to slot indices in place)
-  const int rec_base = (kB3Idx + 2 * ncell + 15) & ~15;
-  const int slot_cap = GLOBAL ? kG3MaxSlots : (kB3LdsBytes - rec_base) / kB3RecBytes;      // records incl. the dummy record 0
+  // on chip: per-pair carve behind the voxel table; global variant: table (and the build's counts, converted to slot
+  // indices in place) in fixed regions of the slab, and the whole carve for records - the first 4 461 of them live in
+  // LDS here too (a 0.8 m grid over the 40 m room has 3 900), the rest in the slab
+  const int rec_base = GLOBAL ? kB3Idx : (kB3Idx + 2 * ncell + 15) & ~15;
+  const int slot_cap = (kB3LdsBytes - rec_base) / kB3RecBytes;                            // records incl. the dummy record 0
   unsigned int* cnt = GLOBAL ? reinterpret_cast<unsigned int*>(slab + kG3Idx) : reinterpret_cast<unsigned int*>(smem + rec_base);
   unsigned long long* psum = reinterpret_cast<unsigned long long*>(smem + rec_base);      // on-chip build: u64 [per][nslot]
-  float4* recA = GLOBAL ? reinterpret_cast<float4*>(slab + kG3RecA) : reinterpret_cast<float4*>(smem + rec_base);
-  float4* recB = GLOBAL ? reinterpret_cast<float4*>(slab + kG3RecB) : reinterpret_cast<float4*>(smem + rec_base + 16 * slot_cap);
-  float* recC = GLOBAL ? reinterpret_cast<float*>(slab + kG3RecC) : reinterpret_cast<float*>(smem + rec_base + 32 * slot_cap);
+  float4* recA = reinterpret_cast<float4*>(smem + rec_base);
+  float4* recB = reinterpret_cast<float4*>(smem + rec_base + 16 * slot_cap);
+  float* recC = reinterpret_cast<float*>(smem + rec_base + 32 * slot_cap);
 
   // (voxel keys are formed with 24-bit multiplies - every index and the key itself stay below 2^21 - which issue at
   // full rate; the 32-bit form compiles to quarter-rate v_mad_u64_u32)
@@ -492,8 +493,8 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
 #ifndef NDT_B3_OVERFLOW
 #define NDT_B3_OVERFLOW 1          // 0 (tools only): over-capacity pairs always go to the global-table variant
 #endif
-  const bool overflow = NDT_B3_OVERFLOW && !GLOBAL && nslot + 1 > slot_cap;           // uniform
-  if (nslot > kS || nslot < 1 || ((GLOBAL || !NDT_B3_OVERFLOW) && nslot + 1 > slot_cap) ||
+  const bool overflow = (GLOBAL || NDT_B3_OVERFLOW) && nslot + 1 > slot_cap;          // uniform
+  if (nslot > (GLOBAL ? kS - 1 : kS) || nslot < 1 || (!GLOBAL && !NDT_B3_OVERFLOW && nslot + 1 > slot_cap) ||
       (!GLOBAL && 8 * nslot > kB3LdsBytes - rec_base)) {   // (record 0 is the dummy; one sum per slot must fit a build pass)
     if (tid == 0) {
       if (!GLOBAL && nslot >= 1 && a.fb_marks) a.fb_marks[pair] = 1;                  // too many occupied voxels for the carve
@@ -501,9 +502,9 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
     }
     return;
   }
-  float4* ovA = reinterpret_cast<float4*>(slab + kB3SlabRecA);       // record of slot s >= slot_cap at [s - slot_cap]
-  float4* ovB = reinterpret_cast<float4*>(slab + kB3SlabRecB);
-  float* ovC = reinterpret_cast<float*>(slab + kB3SlabRecC);
+  float4* ovA = reinterpret_cast<float4*>(slab + (GLOBAL ? kG3RecA : (size_t)kB3SlabRecA));       // record of slot s >= slot_cap at [s - slot_cap]
+  float4* ovB = reinterpret_cast<float4*>(slab + (GLOBAL ? kG3RecB : (size_t)kB3SlabRecB));
+  float* ovC = reinterpret_cast<float*>(slab + (GLOBAL ? kG3RecC : (size_t)kB3SlabRecC));
   for (int k = c0; k < c1; ++k) {
     const unsigned int n = cnt[k];                 // (global variant: read before idx[k], the same word, is written)
     if (n >= (unsigned)minpts) {
@@ -633,7 +634,7 @@ __device__ __forceinline__ void process_pair3(const Batch3Args& a, const int pai
 #ifdef NDT_B3_PHASE_CLOCKS
   pc_t[4] = wall_clock64();
 #endif
-  // ---- a3: finalise, records into LDS (global variant: into the slab)
+  // ---- a3: finalise, records into LDS (those beyond the carve: into the slab)
   {
     int nvalid = 0;
     for (int sl = tid; sl < nslot; sl += kB3Threads) {

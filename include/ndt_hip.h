@@ -515,8 +515,9 @@ int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
  * <= 157 KB during the build (BASELINE config 5: 17 424 voxels, 2 706 occupied = 132 KB; that grid holds up to
  * 3 494 occupied voxels).  A pair
  * beyond it is handed, on the device and within the same call, to a second variant of the kernel that
- * keeps the pair's tables in global memory (up to 2^20 voxels - e.g. 256 x 256 x 16 - and 32 767 occupied; a pair
- * that only has a few more occupied voxels than fit stays on chip with its last records in global memory).
+ * keeps the pair's voxel table in global memory and its first 4 461 records on chip (up to 2^20 voxels - e.g.
+ * 256 x 256 x 16 - and 32 767 occupied; a pair that only has a few more occupied voxels than fit stays on the first
+ * variant with its last records in global memory).
  * Beyond that a pair gets status NDT_ERR_CAPACITY from the _dev entry point, and the host-pointer entry
  * point re-runs it through the single-pair path transparently.  Stream semantics as ndt2d_batch_align_dev.
  * A context holds about 2.1 GB of device memory (per-workgroup slabs of the build and of the global-memory variant;
