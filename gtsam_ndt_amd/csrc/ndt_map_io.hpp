@@ -14,6 +14,21 @@ namespace {
 
 constexpr uint32_t kMapVersion = 1;
 
+// The outermost ring of a 2D grid stays empty by contract (alignments clamp out-of-range lookups onto it,
+// ndt2d_add_target_points never fills it): a map that did not come from ndt2d_save_map must not break that.
+__global__ void k_clear_ring(CellAcc* __restrict__ acc, int W, int H, int ngrid) {
+  const int per = 2 * W + 2 * H;                     // (corners twice: harmless)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per * ngrid) return;
+  const int q = i / per, j = i - q * per;
+  int ix, iy;
+  if (j < W) { ix = j; iy = 0; }
+  else if (j < 2 * W) { ix = j - W; iy = H - 1; }
+  else if (j < 2 * W + H) { ix = 0; iy = j - 2 * W; }
+  else { ix = W - 1; iy = j - 2 * W - H; }
+  acc[(size_t)q * W * H + (size_t)iy * W + ix] = CellAcc{};
+}
+
 int32_t check_map_header(const ndt_map_header& m, size_t bytes, int dims, uint32_t cell_bytes, double cell_size) {
   if (m.magic != NDT_MAP_MAGIC || m.version != kMapVersion) { set_error("not an NDT map of this format version"); return NDT_ERR_INVALID_ARG; }
   if (m.dims != dims || m.cell_bytes != cell_bytes) { set_error("map has another dimension"); return NDT_ERR_INVALID_ARG; }
@@ -85,6 +100,11 @@ int32_t ndt2d_load_map(ndt2d_handle* h, const void* buf, size_t bytes) {
     h->cell_capacity = want;
   }
   HIP_TRY(hipMemcpyAsync(g.acc, (const char*)buf + sizeof m, ncell * sizeof(CellAcc), hipMemcpyHostToDevice, h->stream));
+  {
+    const int n_ring = (2 * g.W + 2 * g.H) * g.ngrid;
+    hipLaunchKernelGGL(k_clear_ring, dim3((unsigned)((n_ring + 255) / 256)), dim3(256), 0, h->stream, g.acc, g.W, g.H, g.ngrid);
+    HIP_TRY(hipGetLastError());
+  }
   { const int32_t fs = finalise_grid(h); if (fs != NDT_OK) return fs; }      // synchronises: buf is free on return
   h->n_points = (size_t)m.n_points;
   h->last_ntile = 0;                 // the next ndt2d_set_target sizes its launches the two-round-trip way once

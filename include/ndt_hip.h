@@ -162,7 +162,8 @@ int32_t ndt2d_add_target_points_dev(ndt2d_handle* h, const float* d_x, const flo
  * re-finalises the sums with the LOADING handle's min_points / eig_ratio: with the saving handle's parameters the
  * grid is bit for bit the one that was saved, it goes on taking points (ndt2d_add_target_points*), and a map can be
  * re-finalised under other validity rules without the raw points.  cell_size (and overlap_grids) must match the
- * handle's (NDT_ERR_INVALID_ARG otherwise, as for a buffer that is not a map or is cut short).  The format is
+ * handle's (NDT_ERR_INVALID_ARG otherwise, as for a buffer that is not a map or is cut short); sums found in the
+ * outermost ring of a 2D map, which the builders keep empty, are dropped on load.  The format is
  * little-endian, as the machines this library runs on. */
 #define NDT_MAP_MAGIC 0x4d54444eu   /* "NDTM" */
 typedef struct ndt_map_header {

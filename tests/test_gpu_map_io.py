@@ -114,3 +114,23 @@ def test_3d_map_round_trip_is_bit_exact(gpu_lib):
             assert na == nb
             _same_grid(a, b)
             assert np.array_equal(a.save_map(), b.save_map())
+
+
+def test_2d_load_keeps_the_outer_ring_empty(gpu_lib):
+    """Alignments clamp out-of-range lookups onto the grid's outermost ring, which the builders never fill: a map
+    edited by hand (or corrupted) with points in ring cells loads with those cells cleared."""
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(1)
+    with NdtMatcher2D() as a, NdtMatcher2D() as b:
+        a.set_target(d["tx"], d["ty"])
+        blob = a.save_map().copy()
+        hdr = L.MapHeader.from_buffer_copy(blob[:104].tobytes())
+        cells = blob[104:].view(np.int64).reshape(-1, 6)              # sx sy sxx sxy syy (n | pad)
+        inner = int(np.argmax(cells[:, 5] & 0xFFFFFFFF))              # the fullest cell's sums ...
+        for ring_cell in (0, hdr.width - 1, hdr.width * (hdr.height - 1) + 3, 2 * hdr.width):    # ... copied onto the ring
+            cells[ring_cell] = cells[inner]
+        b.load_map(blob)
+        for x, y in zip(a.grid(), b.grid()):
+            assert np.array_equal(x, y)                                # the ring is empty again, nothing else changed
+        assert b.grid_info().n_valid == a.grid_info().n_valid
