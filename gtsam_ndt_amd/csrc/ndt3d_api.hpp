@@ -167,7 +167,7 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
   unsigned int* hb = (unsigned int*)h->h_small;
   for (int a = 0; a < 3; ++a) { hb[2 * a] = 0xFFFFFFFFu; hb[2 * a + 1] = 0u; }
   HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, 24, hipMemcpyHostToDevice, h->stream));
-  const int sb = stream_blocks(n) > 512 ? 512 : stream_blocks(n);
+  const int sb = stream_blocks(n) > kBoundsBlocks ? kBoundsBlocks : stream_blocks(n);   // few blocks: each ends in six atomics on the same six words
   hipLaunchKernelGGL(k_bounds3, dim3(sb), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_bounds);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, 24, hipMemcpyDeviceToHost, h->stream));
