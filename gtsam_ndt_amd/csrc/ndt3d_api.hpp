@@ -83,7 +83,7 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
     const int ntile = (int)ntile_ll;
     int32_t st = ensure3(h->d_b, &h->bcap, n);
     if (st != NDT_OK) return st;
-    const size_t tneed = 3 * (size_t)ntile + 4;
+    const size_t tneed = 4 * (size_t)ntile + 4;          // total | start (+1) | cursor | tickets of the shared tiles
     if (tneed > h->tile_cap) {
       if (h->d_tiles) (void)hipFree(h->d_tiles);
       h->d_tiles = nullptr; h->tile_cap = 0;
@@ -102,8 +102,11 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, (const GeomDev*)nullptr);
     hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
                        dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2]);
-    hipLaunchKernelGGL(k_tile_accumulate3, dim3(ntile), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1], h->d_b[2],
-                       d_start, g, ntx, nty, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+    unsigned int* d_ticket = h->d_tiles + 3 * ntile + 1;
+    HIP_TRY(hipMemsetAsync(d_ticket, 0, ntile * sizeof(unsigned int), h->stream));
+    if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));      // shared tiles add into the sums
+    hipLaunchKernelGGL(k_tile_accumulate3, dim3(ntile, kTile3Split), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1],
+                       h->d_b[2], d_start, g, ntx, nty, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, h->d_counters, d_ticket);
     HIP_TRY(hipGetLastError());
   } else {
     if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));

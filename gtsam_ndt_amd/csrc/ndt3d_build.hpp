@@ -14,6 +14,8 @@ namespace ndt {
 
 constexpr int kT3x = 2, kT3y = 2, kT3z = 2;                        // log2 tile edge: 4 x 4 x 4
 constexpr int kTile3Cells = 1 << (kT3x + kT3y + kT3z);             // 64
+constexpr int kTile3Split = 8;                                     // workgroups that may share a tile (k_tile_accumulate3)
+constexpr int kTile3SubMin = 1024;                                 // ... one per this many points of the tile
 
 struct BinGeom3 {
   float ox, oy, oz, inv_c;
@@ -97,16 +99,29 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
                                                                    const float* __restrict__ bz,
                                                                    const unsigned int* __restrict__ tile_start, Grid3Dev g,
                                                                    int ntx, int nty, int merge, int min_points,
-                                                                   double eig_ratio, int* __restrict__ counters) {
+                                                                   double eig_ratio, int* __restrict__ counters,
+                                                                   unsigned int* __restrict__ tile_ticket) {
   __shared__ unsigned int s_n[kTile3Cells];
   __shared__ unsigned long long s_sum[9][kTile3Cells];
-  const int tile = blockIdx.x;
+  __shared__ int s_last;
+  const int tile = blockIdx.x, sub = blockIdx.y;
   const int tx0 = (tile % ntx) << kT3x, ty0 = ((tile / ntx) % nty) << kT3y, tz0 = (tile / (ntx * nty)) << kT3z;
-  // init: zeros, or the cached sums of this tile's voxels (merge = incremental submap update)
+  // A lidar scan puts thousands of points into the few tiles around the sensor, and one workgroup per tile left the
+  // build waiting for the fullest one.  A tile of more than kTile3SubMin points is shared by up to kTile3Split workgroups
+  // (grid.y): each sums its share in LDS, adds it to the grid's sums with atomics (exact integers: any split gives
+  // the same bits; the host zeroes the sums first unless this is a submap update), and the last one to arrive
+  // finalises the tile.
+  const unsigned int p0 = tile_start[tile], p1 = tile_start[tile + 1];
+  int nsub = (int)((p1 - p0 + kTile3SubMin - 1) / kTile3SubMin);
+  nsub = nsub < 1 ? 1 : (nsub > kTile3Split ? kTile3Split : nsub);
+  if (sub >= nsub) return;                           // uniform
+  const bool split = nsub > 1;
+  // init: zeros, or the cached sums of this tile's voxels (merge = incremental submap update; a shared tile adds
+  // to them in place instead)
   for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
     const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
     CellAcc3 a = {};
-    if (merge && ix < g.W && iy < g.H && iz < g.D) a = g.acc[((size_t)iz * g.H + iy) * g.W + ix];
+    if (merge && !split && ix < g.W && iy < g.H && iz < g.D) a = g.acc[((size_t)iz * g.H + iy) * g.W + ix];
     s_n[c] = a.n;
 #pragma unroll
     for (int j = 0; j < 3; ++j) s_sum[j][c] = (unsigned long long)a.s[j];
@@ -114,22 +129,22 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
     for (int j = 0; j < 6; ++j) s_sum[3 + j][c] = (unsigned long long)a.ss[j];
   }
   __syncthreads();
-  const unsigned int p0 = tile_start[tile], p1 = tile_start[tile + 1];
-  // 8 points in flight per thread: a lidar scan puts tens of thousands of points into the few
-  // tiles around the sensor, and a one-point loop pays the memory latency on every trip
+  const unsigned int share = (p1 - p0 + nsub - 1) / nsub;
+  const unsigned int q0 = p0 + sub * share, q1 = q0 + share < p1 ? q0 + share : p1;
+  // 8 points in flight per thread: a one-point loop pays the memory latency on every trip
   constexpr int kU = 8;
-  for (unsigned int i = p0 + threadIdx.x; i < p1; i += kBinThreads * kU) {
+  for (unsigned int i = q0 + threadIdx.x; i < q1; i += kBinThreads * kU) {
     float qx[kU], qy[kU], qz[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const unsigned int ii = i + u * kBinThreads;
-      qx[u] = ii < p1 ? bx[ii] : 0.f;
-      qy[u] = ii < p1 ? by[ii] : 0.f;
-      qz[u] = ii < p1 ? bz[ii] : 0.f;
+      qx[u] = ii < q1 ? bx[ii] : 0.f;
+      qy[u] = ii < q1 ? by[ii] : 0.f;
+      qz[u] = ii < q1 ? bz[ii] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      if (i + u * kBinThreads < p1) {
+      if (i + u * kBinThreads < q1) {
         const float px = qx[u], py = qy[u], pz = qz[u];
         const int ix = (int)((px - g.ox) * g.inv_c), iy = (int)((py - g.oy) * g.inv_c), iz = (int)((pz - g.oz) * g.inv_c);
         const int ux = fix_coord(px, cell_centre(g.ox, ix, g.cell), g.fix_scale);
@@ -150,6 +165,40 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
     }
   }
   __syncthreads();
+  if (split) {
+    for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
+      const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
+      if (s_n[c] != 0u && ix < g.W && iy < g.H && iz < g.D) {
+        CellAcc3* a = &g.acc[((size_t)iz * g.H + iy) * g.W + ix];
+        atomicAdd(&a->n, s_n[c]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) atomicAdd(reinterpret_cast<unsigned long long*>(&a->s[j]), s_sum[j][c]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) atomicAdd(reinterpret_cast<unsigned long long*>(&a->ss[j]), s_sum[3 + j][c]);
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tile_ticket[tile], 1u) == (unsigned)(nsub - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;                             // uniform
+    __threadfence();
+    // the last of the tile's workgroups: every share is in the grid's sums - read them back for the finalise below
+    for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
+      const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
+      if (ix < g.W && iy < g.H && iz < g.D) {
+        const CellAcc3* a = &g.acc[((size_t)iz * g.H + iy) * g.W + ix];
+        s_n[c] = __hip_atomic_load(&a->n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          s_sum[j][c] = (unsigned long long)__hip_atomic_load(&a->s[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          s_sum[3 + j][c] = (unsigned long long)__hip_atomic_load(&a->ss[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+  }
   int nvalid = 0, nover = 0;
   for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
     const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
@@ -166,7 +215,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
       else if (finalise_sums3(a, cell_centre(g.ox, ix, g.cell), cell_centre(g.oy, iy, g.cell), cell_centre(g.oz, iz, g.cell),
                               g.fix_scale, min_points, eig_ratio, ra, rb, rc))
         nvalid++;
-      g.acc[k] = a;
+      if (!split) g.acc[k] = a;
       g.rec[4 * k] = ra; g.rec[4 * k + 1] = rb; g.rec[4 * k + 2] = rc;
     }
   }
