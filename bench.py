@@ -237,6 +237,45 @@ def multi_scan_rate_3d(dev, dev_index, target, base_scans, base_poses, m: int, s
             "scans_within_1cm_of_truth_after_30_iterations": int(sum(e < 1e-2 for e in errs))}    # starts far is still on its way)
 
 
+def scan_loop_3d(dev, dev_index, n_scans: int = 40):
+    """The 3D front end's loop on the device: 64-beam scans of a sensor moving through the box room,
+    each aligned against the submap from an odometry-grade guess (converged mode) and merged into it with the
+    estimated pose (ndt3d_reserve_target, ndt3d_align_dev, ndt3d_add_target_points_dev); nothing but the 6-double
+    estimate crosses to the host per scan."""
+    from gtsam_ndt_amd import synth_dev
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    rng = np.random.default_rng(11)
+    poses = [np.zeros(6)]
+    for k in range(1, n_scans):                        # 0.3 m and a degree of yaw per scan, small roll / pitch / heave
+        step = np.array([0.3 * np.cos(0.02 * k), 0.3 * np.sin(0.02 * k), 0.0, 0.0, 0.0, 0.017])
+        p = poses[-1] + step
+        p[2] = 0.03 * np.sin(0.3 * k); p[3] = 0.004 * np.sin(0.5 * k); p[4] = 0.004 * np.cos(0.4 * k)
+        poses.append(p)
+    scans = [synth_dev.lidar_scan3d(700 + k, tuple(p), device=dev, firing_order=True) for k, p in enumerate(poses)]
+    torch.cuda.synchronize()
+    with NdtMatcher3D(device=dev_index) as m:
+        m.reserve_target((-24.0, -24.0, -3.0), (24.0, 24.0, 7.0))
+        m.add_target_points(*scans[0], pose=tuple(poses[0]))
+        est = [poses[0]]
+        errs, iters = [], []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(1, n_scans):
+            guess = est[-1] + (poses[k] - poses[k - 1]) + rng.normal(0.0, 1.0, 6) * np.array([0.03, 0.03, 0.01, 0.002, 0.002, 0.005])
+            r = m.align(*scans[k], tuple(guess))
+            m.add_target_points(*scans[k], pose=r.pose)
+            est.append(np.array(r.pose)); iters.append(r.iterations)
+            errs.append(float(np.abs(np.array(r.pose) - poses[k])[:3].max()))
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        info = m.grid_info()
+    return {"workload": f"{n_scans} scans x {int(scans[0][0].numel())} points in firing order, 0.3 m / 1 deg per scan, align (converged) + merge into "
+                        "the submap per scan, all on the device",
+            "scans_per_s": round((n_scans - 1) / el, 1), "ms_per_scan": round(1e3 * el / (n_scans - 1), 3),
+            "iterations_mean": round(float(np.mean(iters)), 1), "position_err_max_m": max(errs), "position_err_last_m": errs[-1],
+            "submap_valid_voxels": int(info.n_valid)}
+
+
 def lidar_batch_rate(dev, dev_index, n_pairs: int = 4096, npts: int = 1000, unique: int = 64):
     """Loop-closure batch of lidar-sized pairs (the 256-thread variant of the batch kernel, two pairs
     per CU): `unique` different synthetic pairs repeated to n_pairs, fixed K iterations each."""
@@ -784,6 +823,8 @@ def main():
             out["batch_lidar_sized"] = lidar_batch_rate(dev, dev_index)
             # the same kernel with enough work per launch to leave the latency regime: a 1M-point source
             out["config3_with_1M_point_source"] = single_pair_rate(dev, dev_index, 3, max(5, a.steps // 5), 2, n_src=1_000_000)
+            if not a.no_3d:
+                out["scan_loop_3d"] = scan_loop_3d(dev, dev_index)
         copy_peak = stream_copy_GBps(dev)
         out["roofline"]["stream_copy_GBps"] = round(copy_peak, 1)
         out["roofline"]["frac_of_stream_copy"] = round(out["roofline"]["achieved"] / copy_peak, 4)
