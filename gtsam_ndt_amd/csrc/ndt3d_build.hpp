@@ -14,8 +14,12 @@ namespace ndt {
 
 constexpr int kT3x = 2, kT3y = 2, kT3z = 2;                        // log2 tile edge: 4 x 4 x 4
 constexpr int kTile3Cells = 1 << (kT3x + kT3y + kT3z);             // 64
-constexpr int kTile3Split = 8;                                     // workgroups that may share a tile (k_tile_accumulate3)
-constexpr int kTile3SubMin = 1024;                                 // ... one per this many points of the tile
+#ifndef NDT_TILE3_SPLIT
+#define NDT_TILE3_SPLIT 8
+#define NDT_TILE3_SUBMIN 1024
+#endif
+constexpr int kTile3Split = NDT_TILE3_SPLIT;                       // workgroups that may share a tile (k_tile_accumulate3)
+constexpr int kTile3SubMin = NDT_TILE3_SUBMIN;                     // ... one per this many points of the tile
 
 struct BinGeom3 {
   float ox, oy, oz, inv_c;
