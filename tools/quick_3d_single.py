@@ -5,6 +5,10 @@ import numpy as np, torch
 from gtsam_ndt_amd import synth3d
 from gtsam_ndt_amd.matcher import NdtMatcher3D
 d = synth3d.make_pair3d()
+order = sys.argv[1] if len(sys.argv) > 1 else "ring"
+if order == "firing":      # all 64 beams of one bearing, then the next bearing
+    for c in ("tx", "ty", "tz", "sx", "sy", "sz"):
+        d[c] = np.ascontiguousarray(d[c].reshape(64, 2048).T).reshape(-1)
 s = [torch.from_numpy(d[k]).cuda() for k in ("sx", "sy", "sz")]
 for mode in (0, 1):
     with NdtMatcher3D(fixed_iterations=30, hessian_mode=mode) as m:
@@ -19,4 +23,4 @@ for mode in (0, 1):
             m.align_async(*s, d["init"], producer_complete=True)
         e1.record(st); e1.synchronize()
         r = m.finish()
-        print(f"mode {mode}: {1e3 * e0.elapsed_time(e1) / (40 * 31):.3f} us per launch; {os.environ.get('NDT_HIP_LIB', 'product library')}")
+        print(f"mode {mode}: {1e3 * e0.elapsed_time(e1) / (40 * 31):.3f} us per launch; {os.environ.get('NDT_HIP_LIB', 'product library')}; {order} order")
