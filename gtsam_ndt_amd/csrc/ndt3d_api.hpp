@@ -25,6 +25,7 @@ struct ndt3d_handle {
   ndt::AlignCall3* d_call = nullptr;
   ndt::AlignDyn3* d_dyn = nullptr;
   ndt::AlignStatic3* h_static = nullptr;
+  hipEvent_t upload_ev = nullptr;     // recorded after the last upload from h_static
   ndt::IterState3* h_state = nullptr;
   unsigned long long* d_outside = nullptr;   // [1] points of the last build / update outside the extent
   int* h_flag = nullptr;              // pinned: raised by the launch that ends a converged-mode loop
@@ -53,6 +54,9 @@ int32_t ensure3(float** d, size_t* cap, size_t n) {
 }
 
 int32_t upload_static3(ndt3d_handle* h) {
+  // as upload_static in 2D: the copy is left in flight (whatever reads d_static is ordered behind it on the same
+  // stream); the pinned source is only rewritten once the previous copy has left it
+  HIP_TRY(hipEventSynchronize(h->upload_ev));
   ndt::AlignStatic3* c = h->h_static;
   c->grid = h->grid;
   ndt::SolveParams& p = c->prm;
@@ -62,7 +66,7 @@ int32_t upload_static3(ndt3d_handle* h) {
   p.step_max_trans = h->prm.step_max_trans; p.step_max_rot = h->prm.step_max_rot;
   p.step_scale = h->prm.step_scale > 0.0 ? h->prm.step_scale : 1.0;
   HIP_TRY(hipMemcpyAsync(h->d_static, c, sizeof(ndt::AlignStatic3), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipEventRecord(h->upload_ev, h->stream));
   return NDT_OK;
 }
 
@@ -377,6 +381,7 @@ int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** ou
   if (hipMalloc((void**)&h->d_call, sizeof(ndt::AlignCall3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_dyn, sizeof(ndt::AlignDyn3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_static, sizeof(ndt::AlignStatic3), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipEventCreateWithFlags(&h->upload_ev, hipEventDisableTiming) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipHostMalloc((void**)&h->h_state, sizeof(ndt::IterState3), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   *h->h_flag = 0;
@@ -397,6 +402,7 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag, h->h_state_multi};
   for (void* p : host) if (p) (void)hipHostFree(p);
+  if (h->upload_ev) (void)hipEventDestroy(h->upload_ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return NDT_OK;
