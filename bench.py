@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the MI355X NDT scan matcher (driver contract).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W           # any N: for N > 1 this process starts its own N ranks
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Metric (BASELINE.json): NDT Gauss-Newton iterations/sec @ 1M-point target, plus the
 converged-pose error against the CPU reference (here: this repo's oracle - the reference
 implementation is unavailable, /root/reference/README.md:1).
 
-N = 1  workload = BASELINE config 3: one pair, 1M-point submap target vs 100k-point scan.
+N = 1  value = BASELINE config 3: one pair, 1M-point submap target vs 100k-point scan.
        A step = one alignment of fixed K_GN = 30 Gauss-Newton iterations with the target grid
        cached and all inputs resident in HBM (the grid build is timed separately and
-       reported as grid_build_ms).  value = steps * 30 / elapsed.
-N > 1  workload = BASELINE config 4, the loop-closure batch: 512 candidate pairs x 100k
-       points per rank (4096 pairs at N = 8), sharded over ranks with no data-path
-       collective; one RCCL all_gather of the per-pair results at the end of each step.
-       A step = every rank aligns all its pairs (grid build + 30 GN iterations each).
-       value = total GN iterations of all ranks / elapsed (max over ranks).  The N = 1 line
-       also carries this workload's single-GPU figure in "batch" so that scaling can be read
-       against the same workload.
+       reported as grid_build).  value = steps * 30 / elapsed.  The line also carries, under
+       `batch`, the single-GPU figure of BASELINE config 4 (512 candidate pairs x 100k points).
+N > 1  one process per GPU (RCCL).  A single alignment does not shard, so
+       `value` is the N = 1 workload as one independent replica per GPU ("value_kind": "replicas":
+       linear by construction, it exercises no multi-GPU code).  The path that DOES shard is in
+       the same line under `batch`: config 4, 512 pairs per rank (4096 at N = 8), pairs split
+       over the ranks with no data-path collective and ONE RCCL all_gather of the result rows
+       inside every timed step.  batch.value = pair-iterations of all ranks / max-over-ranks
+       time: read the 1 -> 8 scaling of the multi-GPU path from batch.value against the N = 1
+       line's batch.value.
 
-One JSON line is printed by rank 0.  roofline / cpu_baseline are described in DESIGN.md §7.
+Started without WORLD_SIZE in the environment and with --gpus N > 1, this script launches
+`python -m torch.distributed.run --nproc-per-node N` on itself as a CHILD process before any
+GPU call, relays rank 0's JSON line and exits with the child's code (a process that has
+touched the GPU is never re-executed).
+
+One JSON line is printed by rank 0.  roofline / cpu_baseline are described in DESIGN.md section 7.
 """
 from __future__ import annotations
 
@@ -70,6 +77,10 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the N>1 flow on a 1-GPU box: every rank uses cuda:0 and the result "
                          "gather runs over gloo on host copies (RCCL refuses two ranks on one device)")
+    ap.add_argument("--converged-batch", action="store_true",
+                    help="also time the loop-closure batch in converged mode (each pair runs until its own convergence test "
+                         "passes) with STRIDED sharding at N > 1 (pair k -> rank k mod N: evens out iteration-count variance, "
+                         "SURVEY 8e); reported under batch_converged")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N>1 code path (process group + all_gather) even with one rank")
     a = ap.parse_args()
@@ -399,7 +410,7 @@ def cross_check_batch_rows(dev_index, t, rows, ppr, every: int = 64):
                     "max |pose difference| between the two kernels"}
 
 
-def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=None):
+def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=None, converged=False):
     """BASELINE config 4, this rank's shard: `ppr` candidate pairs x batch_points, generated in HBM
     by the device twin of synth.py (bit-identical to synth.make_pair(4, k)); a step aligns every
     pair (LDS grid build + 30 GN iterations each) and gathers the per-pair results of all ranks
@@ -410,13 +421,16 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=Non
     steps = steps or a.steps
     npts = a.batch_points
     total = ppr * world
-    mine = nd.shard_range(total, rank, world)
+    # fixed-K mode: every pair costs the same, contiguous shards.  Converged mode: pairs need different iteration
+    # counts, so the shards are strided (pair k -> rank k mod world) and the gather undoes the permutation.
+    strided = bool(converged and world > 1)
+    mine = nd.shard_range(total, rank, world, strided=strided)
     t0 = time.perf_counter()
-    t = synth_dev.config4_batch(mine.start, len(mine), npts, npts, device=dev)
+    t = synth_dev.config4_batch(mine.start, len(mine), npts, npts, device=dev, indices=list(mine) if strided else None)
     torch.cuda.synchronize()
     gen_ms = 1e3 * (time.perf_counter() - t0)
     truth = t["pose"].cpu().numpy()
-    b = NdtBatch2D(device=dev_index, fixed_iterations=K_GN)
+    b = NdtBatch2D(device=dev_index, fixed_iterations=0 if converged else K_GN)
     host_ms = None
     if dist is None and a.host_path and ppr <= 512:
         # the same batch through the host-pointer entry point (pageable host arrays -> upload ->
@@ -445,7 +459,7 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=Non
 
         def step():
             b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"], out=res, stream=cur)
-            return nd.gather_results(res, total) if dist is not None else res
+            return nd.gather_results(res, total, strided=strided) if dist is not None else res
 
         for _ in range(max(1, a.warmup)):
             allr = step()
@@ -456,16 +470,18 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=Non
             e0.record(side)
             b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"], out=res, stream=cur)
             e1.record(side)
-            allr = nd.gather_results(res, total) if dist is not None else res
+            allr = nd.gather_results(res, total, strided=strided) if dist is not None else res
         barrier()
         elapsed = time.perf_counter() - t0
         kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev)
     if dist is not None:
         elapsed = nd.max_over_ranks(elapsed, device=dev)
     rows = NdtBatch2D.decode(allr)
-    assert len(rows) == total and all(r.iterations == K_GN and r.status == 0 for r in rows)
-    local = rows[mine.start: mine.stop]
+    local = [rows[k] for k in mine]
     err = np.abs(np.array([r.pose for r in local]) - truth)      # vs the generating pose (sampling noise)
+    if converged:
+        return converged_batch_line(a, rows, local, err, elapsed, kern_ms, steps, world, ppr, total, npts, strided, dist, dev, nd)
+    assert len(rows) == total and all(r.iterations == K_GN and r.status == 0 for r in rows)
     cross = cross_check_batch_rows(dev_index, t, local, ppr) if not a.headline_only else None
     if dist is not None and cross is not None:
         for k in ("dx_m", "dy_m", "dtheta_rad"):
@@ -489,8 +505,10 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=Non
         "config": {"workload": f"config4: loop-closure batch, {ppr} candidate pairs x {npts} pts per GPU "
                                f"({total} pairs total), 0.5 m cells, grid build + fixed 30 GN iterations per pair",
                    "pairs_per_gpu": ppr, "pairs_total": total, "n_target": npts, "n_source": npts,
-                   "cell_size": 0.5, "gn_iterations_per_pair": K_GN, "collective": "all_gather of 144 B/pair"
-                   if world > 1 else "none (1 GPU)",
+                   "cell_size": 0.5, "gn_iterations_per_pair": K_GN,
+                   "collective": ("all_gather of 144 B/pair inside every timed step ("
+                                  + ("gloo on host copies: one-GPU rehearsal" if a.rehearse_on_one_gpu else "RCCL") + ")")
+                   if dist is not None else "none (1 GPU)",
                    "generator": f"device twin of synth.make_pair(4, k), k = {mine.start}..{mine.stop - 1} on this rank "
                                 f"({gen_ms:.0f} ms incl. first-use overheads; outside the timed region)"},
         "pairs_per_s": round(total * steps / elapsed, 1),
@@ -523,6 +541,27 @@ def run_batch(a, dev, dev_index, rank, world, dist, barrier, ppr=None, steps=Non
     del t, res
     torch.cuda.empty_cache()
     return out
+
+
+def converged_batch_line(a, rows, local, err, elapsed, kern_ms, steps, world, ppr, total, npts, strided, dist, dev, nd):
+    """The `batch_converged` leg: every pair runs until its own convergence test passes.  value counts the
+    Gauss-Newton iterations actually made.  With N > 1 the shards are strided and `shard_balance` shows the
+    per-rank iteration totals of the strided split next to what contiguous shards of the same rows would carry."""
+    its = np.array([r.iterations for r in rows], dtype=np.int64)
+    ok = int(sum(r.status == 0 for r in rows))
+    by_rank_strided = [int(its[list(nd.shard_range(total, r, world, strided=True))].sum()) for r in range(world)]
+    by_rank_contig = [int(its[list(nd.shard_range(total, r, world))].sum()) for r in range(world)]
+    return {"workload": f"config4 in converged mode: {ppr} candidate pairs x {npts} pts per GPU ({total} total), each pair until "
+                        "its own convergence test passes (max 100 iterations)",
+            "value": round(float(its.sum()) * steps / elapsed, 1), "unit": "iters/s (iterations actually made)",
+            "pairs_per_s": round(total * steps / elapsed, 1), "ms_per_step": round(1e3 * elapsed / steps, 4), "steps": steps,
+            "n_gpus": world, "sharding": "strided (pair k -> rank k mod N)" if strided else "single GPU",
+            "pairs_converged": ok, "iterations_min_mean_max": [int(its.min()), round(float(its.mean()), 1), int(its.max())],
+            "shard_balance": {"iterations_per_rank_strided": by_rank_strided, "iterations_per_rank_contiguous": by_rank_contig,
+                              "max_over_mean_strided": round(max(by_rank_strided) / max(1.0, float(np.mean(by_rank_strided))), 4),
+                              "max_over_mean_contiguous": round(max(by_rank_contig) / max(1.0, float(np.mean(by_rank_contig))), 4)},
+            "avg_launch_ms_rank0": round(kern_ms / steps, 3),
+            "pose_err_vs_truth_max": {"dx_m": float(err[:, 0].max()), "dy_m": float(err[:, 1].max()), "dtheta_rad": float(err[:, 2].max())}}
 
 
 def run_3d(a, dev, dev_index):
@@ -653,8 +692,51 @@ def run_batch_3d(a, dev, dev_index, n_pairs=256, check=True):
                                  "(DESIGN.md section 5.5)"}}
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def self_launch(a) -> int:
+    """--gpus N > 1 without a launcher: start N ranks of this script as a CHILD `python -m torch.distributed.run`
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port), relay rank 0's JSON line to stdout and everything
+    else to stderr, and return the child's exit code.  Called before anything in this process touches the GPU, and
+    the child is a fresh process - nothing that has initialised HIP is ever re-executed."""
+    import subprocess
+    if not a.rehearse_on_one_gpu:
+        have = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
+        if have < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but only {have} device(s) visible "
+                  "(a one-GPU rehearsal of the N > 1 flow needs --rehearse-on-one-gpu)", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this pool (RCCL needs it)
+    line = None
+    with subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, cwd=ROOT) as p:
+        for out_line in p.stdout:
+            if out_line.startswith("{") and '"metric"' in out_line:
+                line = out_line.strip()
+            else:
+                sys.stderr.write(out_line)
+        rc = p.wait()
+    if rc != 0:
+        print(f"bench.py: the {a.gpus}-rank child run failed with exit code {rc}", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: the child run printed no JSON line", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -669,7 +751,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         if a.rehearse_on_one_gpu:
             local_rank = 0
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            import datetime
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -723,6 +806,8 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_iterate<GN>", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": (traffic or {}).get("bytes_per_launch"),
+                    "traffic_source": "not measured in this run: read from the committed PMC passes of the same command, "
+                                      + (traffic or {}).get("source", "profiles/pmc_traffic.json"),
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "avg_launch_us": round(launch_us, 3),
                     "timing": "HIP events on the handle's stream over the timed region / launches "
@@ -808,6 +893,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(d, a.cpu_seconds)
         if not a.no_batch:
             out["batch"] = run_batch(a, dev, dev_index, 0, 1, None, barrier)
+            if a.converged_batch:
+                out["batch_converged"] = run_batch(a, dev, dev_index, 0, 1, None, barrier, steps=max(3, min(a.steps, 10)), converged=True)
             if not a.no_batch_4096:
                 # all 4096 candidates of BASELINE config 4 on this one GPU (6.55 GB resident): the
                 # anchor for reading the N > 1 lines (512 pairs per GPU) as strong scaling as well
@@ -838,6 +925,8 @@ def main():
         # timed beside it under `batch`, comparable with the N = 1 line's `batch`.
         from gtsam_ndt_amd import dist as nd
         batch = run_batch(a, dev, dev_index, rank, world, dist, barrier)
+        batch_conv = (run_batch(a, dev, dev_index, rank, world, dist, barrier, steps=max(3, min(a.steps, 10)), converged=True)
+                      if a.converged_batch else None)
         d = synth.make_pair(3)
         tx, ty, sx, sy = (torch.from_numpy(d[k]).to(dev) for k in ("tx", "ty", "sx", "sy"))
         torch.cuda.synchronize()
@@ -866,6 +955,8 @@ def main():
             "metric": METRIC, "value": round(world * a.steps * K_GN / elapsed, 1), "unit": "iters/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_kind": "replicas (one independent config-3 alignment chain per GPU: linear by construction, no multi-GPU "
+                          "code runs in its timed region; the sharded path with its RCCL gather is batch.value)",
             "config": {"workload": "config3: 2D NDT, 1M-pt submap target vs 100k-pt scan, single pair, 0.5 m cells, fixed 30 GN "
                                    "iterations per step - one independent replica per GPU (replicas only: a single alignment "
                                    "does not shard); the sharded loop-closure batch of config 4 is under `batch`",
@@ -873,14 +964,17 @@ def main():
                        "hessian": "gauss-newton", "replicas": world},
             "roofline": {"bound": "hbm", "kernel": "k_iterate<GN>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (load_traffic() or {}).get("bytes_per_launch"), "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": round(launch_us, 3),
+                         "traffic": (load_traffic() or {}).get("bytes_per_launch"),
+                         "traffic_source": "not measured in this run: committed PMC passes of the N = 1 command (profiles/pmc_traffic.json)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(launch_us, 3),
                          "timing": "HIP events on rank 0's handle stream over the timed region / launches (per GPU)"},
             "scaling_note": "value: the N = 1 line's workload replicated per GPU (compare with the N = 1 line's value); "
                             "batch.value: the config-4 loop-closure batch sharded across the GPUs with its RCCL gather "
                             "(compare with the N = 1 line's batch.value)",
             "batch": batch,
         }
+        if batch_conv is not None:
+            out["batch_converged"] = batch_conv
 
     if rank == 0:
         print(json.dumps(out))

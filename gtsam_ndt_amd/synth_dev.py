@@ -87,12 +87,18 @@ def sample_scene(sc: synth.Scene2D, n: int, seed: int, sigma: float = 0.01, firs
 
 
 def config4_batch(first_pair: int, n_pairs: int, n_tgt: int = 100_000, n_src: int = 100_000, sigma: float = synth.SIGMA,
-                  device="cuda:0"):
-    """Candidates first_pair .. first_pair + n_pairs - 1 of BASELINE config 4, generated in HBM in
-    the layout ndt2d_batch_align_dev takes (the dict dist.pack_pairs builds from host pairs, as
+                  device="cuda:0", indices=None):
+    """Candidates first_pair .. first_pair + n_pairs - 1 of BASELINE config 4 - or, with `indices`, the candidates
+    of that list of global pair indices in that order (a strided shard, dist.shard_range(..., strided=True)) -
+    generated in HBM in the layout ndt2d_batch_align_dev takes (the dict dist.pack_pairs builds from host pairs, as
     torch tensors) plus ``pose`` [n_pairs, 3], the generating poses."""
     import torch
     dev = torch.device(device)
+    if indices is not None:
+        indices = [int(k) for k in indices]
+        n_pairs = len(indices)
+        if not indices or indices == list(range(indices[0], indices[0] + n_pairs)):      # contiguous after all: one call
+            first_pair, indices = (indices[0] if indices else 0), None
     f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
     t = {"tx": f32(n_pairs * n_tgt), "ty": f32(n_pairs * n_tgt), "sx": f32(n_pairs * n_src), "sy": f32(n_pairs * n_src),
          "toff": torch.empty(n_pairs + 1, dtype=torch.int64, device=dev),
@@ -100,10 +106,24 @@ def config4_batch(first_pair: int, n_pairs: int, n_tgt: int = 100_000, n_src: in
          "init": torch.empty((n_pairs, 3), dtype=torch.float64, device=dev),
          "pose": torch.empty((n_pairs, 3), dtype=torch.float64, device=dev)}
     with torch.cuda.device(dev):
-        _check(load().ndt_synth_config4_dev(int(first_pair), n_pairs, n_tgt, n_src, float(sigma), t["tx"].data_ptr(),
-                                            t["ty"].data_ptr(), t["sx"].data_ptr(), t["sy"].data_ptr(), t["toff"].data_ptr(),
-                                            t["soff"].data_ptr(), t["init"].data_ptr(), t["pose"].data_ptr(),
-                                            torch.cuda.current_stream().cuda_stream), "ndt_synth_config4_dev")
+        stream = torch.cuda.current_stream().cuda_stream
+        if indices is None:
+            _check(load().ndt_synth_config4_dev(int(first_pair), n_pairs, n_tgt, n_src, float(sigma), t["tx"].data_ptr(),
+                                                t["ty"].data_ptr(), t["sx"].data_ptr(), t["sy"].data_ptr(), t["toff"].data_ptr(),
+                                                t["soff"].data_ptr(), t["init"].data_ptr(), t["pose"].data_ptr(),
+                                                stream), "ndt_synth_config4_dev")
+        else:
+            # one generator call per candidate, each into its slot of the batch arrays; the per-call offset pairs
+            # (0, n) land in scratch words and the batch's offset tables are written once at the end
+            scratch = torch.empty(4, dtype=torch.int64, device=dev)
+            for j, k in enumerate(indices):
+                _check(load().ndt_synth_config4_dev(k, 1, n_tgt, n_src, float(sigma), t["tx"].data_ptr() + 4 * j * n_tgt,
+                                                    t["ty"].data_ptr() + 4 * j * n_tgt, t["sx"].data_ptr() + 4 * j * n_src,
+                                                    t["sy"].data_ptr() + 4 * j * n_src, scratch.data_ptr(), scratch.data_ptr() + 16,
+                                                    t["init"].data_ptr() + 24 * j, t["pose"].data_ptr() + 24 * j,
+                                                    stream), "ndt_synth_config4_dev")
+            t["toff"].copy_(torch.arange(n_pairs + 1, dtype=torch.int64, device=dev) * n_tgt)
+            t["soff"].copy_(torch.arange(n_pairs + 1, dtype=torch.int64, device=dev) * n_src)
     return t
 
 

@@ -9,6 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from gtsam_ndt_amd import dist as nd
+from conftest import free_port
 
 
 def test_shards_partition_the_batch():
@@ -17,6 +18,11 @@ def test_shards_partition_the_batch():
         assert got == list(range(total))
         sizes = nd.shard_sizes(total, world)
         assert max(sizes) - min(sizes) <= 1
+        # strided shards (pair k -> rank k mod world) partition the batch too, with the same sizes
+        st = [list(nd.shard_range(total, r, world, strided=True)) for r in range(world)]
+        assert sorted(i for s in st for i in s) == list(range(total))
+        assert [len(s) for s in st] == sizes
+        assert all(i % world == r for r, s in enumerate(st) for i in s)
     with pytest.raises(ValueError):
         nd.shard_range(10, 2, 2)
 
@@ -28,14 +34,20 @@ def _fake_rows(idx, width=18):
 
 
 def _worker(rank, world, port, total, q):
+    import datetime
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         mine = nd.shard_range(total, rank, world)
         allr = nd.gather_results(_fake_rows(mine), total)
         ok = bool(torch.equal(allr, _fake_rows(range(total))))
         all3 = nd.gather_results(_fake_rows(mine, 51), total)              # the 3D batch's rows through the same gather
         ok = ok and bool(torch.equal(all3, _fake_rows(range(total), 51)))
+        # strided shards (converged-mode load balance): the gather restores global pair order
+        mine_s = nd.shard_range(total, rank, world, strided=True)
+        for width in (18, 51):
+            alls = nd.gather_results(_fake_rows(mine_s, width), total, strided=True)
+            ok = ok and bool(torch.equal(alls, _fake_rows(range(total), width)))
         t = nd.max_over_ranks(1.0 + rank)
         q.put((rank, ok, t))
     finally:
@@ -47,14 +59,20 @@ def test_gather_restores_global_pair_order_world2(total):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + total % 7
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = [q.get(timeout=180) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:                      # a rank that died must not leave its peer blocked in a collective
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
+    assert all(p.exitcode == 0 for p in procs)
     assert sorted(r for r, _, _ in res) == [0, 1]
     assert all(ok for _, ok, _ in res)
     assert all(t == 2.0 for _, _, t in res)          # max over ranks of (1 + rank)

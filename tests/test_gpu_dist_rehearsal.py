@@ -26,7 +26,8 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     from gtsam_ndt_amd import dist as nd
     from gtsam_ndt_amd.matcher import NdtBatch2D, NdtBatch3D
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         dev = torch.device("cuda:0")
         p2, p3 = _pairs()
@@ -52,14 +53,23 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_batch(gpu_lib):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1500)
+    from conftest import free_port
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    rows2, rows3 = q.get(timeout=300)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        rows2, rows3 = q.get(timeout=300)
+        for p in procs:
+            p.join(timeout=120)
+    finally:
+        # a rank that died before q.put must not leave its peer blocked in a gloo collective, holding the GPU (and
+        # ~2 GB of batch slabs) for the rest of the run
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
+    assert all(p.exitcode == 0 for p in procs)
     p2, p3 = _pairs()
     with NdtBatch2D() as b:
         want2 = b.align([(p["tx"], p["ty"]) for p in p2], [(p["sx"], p["sy"]) for p in p2], [p["init"] for p in p2])

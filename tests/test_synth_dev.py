@@ -52,6 +52,21 @@ def test_config4_candidates_are_bit_identical_to_numpy(synth_dev, gpu_lib):
 
 
 @pytest.mark.gpu
+def test_config4_strided_shard_equals_the_contiguous_candidates(synth_dev, gpu_lib):
+    """A strided shard (pair k -> rank k mod world: bench.py --converged-batch) holds the same candidates, bit for bit,
+    as the contiguous generator call produces for those indices."""
+    nt, ns = 3000, 2500
+    full = {k: v.cpu().numpy() for k, v in synth_dev.config4_batch(0, 12, nt, ns).items()}
+    idx = list(range(1, 12, 4))
+    t = {k: v.cpu().numpy() for k, v in synth_dev.config4_batch(0, 0, nt, ns, indices=idx).items()}
+    assert t["toff"].tolist() == [j * nt for j in range(len(idx) + 1)] and t["soff"].tolist() == [j * ns for j in range(len(idx) + 1)]
+    for j, k in enumerate(idx):
+        for a, n in (("tx", nt), ("ty", nt), ("sx", ns), ("sy", ns)):
+            assert np.array_equal(t[a][j * n:(j + 1) * n], full[a][k * n:(k + 1) * n])
+        assert np.array_equal(t["pose"][j], full["pose"][k]) and np.array_equal(t["init"][j], full["init"][k])
+
+
+@pytest.mark.gpu
 def test_sample_scene_on_the_config3_submap_is_bit_identical(synth_dev, gpu_lib):
     """The 16-room submap scene (1216 segments) and the scan taken inside it, as make_pair(3) builds them."""
     d = synth.make_pair(3, n_tgt=300_000, n_src=50_000)
