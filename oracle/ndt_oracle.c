@@ -1,13 +1,15 @@
 /*
- * ndt_oracle.c - plain-C float64 restatement of oracle/ndt2d.py.  TEST INFRASTRUCTURE ONLY:
+ * ndt_oracle.c - plain-C float64 restatement of oracle/ndt2d.py (orc2d_*) and oracle/ndt3d.py
+ * (orc3d_*, at the end of the file).  TEST INFRASTRUCTURE ONLY:
  * it is the checker and the timed "cpu_baseline" (kind "port") of bench.py, never a product
  * path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
  * PARITY UNPINNED: the reference checkout holds no NDT source, test or golden vector
  * (/root/reference/README.md:1, "# GTSAM-NDT", is its only line), so this follows the
  * published algorithm (Biber & Strasser IROS 2003; Magnusson 2009; Welford 1962) with the
- * choices frozen in DESIGN.md section 2, exactly as oracle/ndt2d.py does.  tests/
- * test_oracle_c.py pins this file against the numpy oracle.
+ * choices frozen in docs/ALGORITHM.md, exactly as oracle/ndt2d.py / ndt3d.py do.  tests/
+ * test_oracle_c.py pins this file against the numpy oracles; tests/test_oracle_sanitize.py runs
+ * it under -fsanitize=address,undefined.
  *
  * Built by gtsam_ndt_amd/build.py: gcc -O2 -std=c11 -fopenmp -ffp-contract=off.
  */
@@ -317,4 +319,390 @@ int32_t orc_max_threads(void) {
 #else
   return 1;
 #endif
+}
+
+
+/* ========================================================================================== */
+/* 3D SE(3) variant: restatement of oracle/ndt3d.py.          */
+/* Same parameter struct (ndt3d_params is ndt2d_params), result = ndt3d_result.              */
+/* ========================================================================================== */
+
+typedef struct orc_result3 {   /* same layout as ndt3d_result */
+  double pose[6];
+  double H[36];
+  double g[6];
+  double score;
+  int32_t iterations, n_hit, status, reserved;
+} orc_result3;
+
+typedef struct orc_grid3d {
+  float o[3], inv_c;
+  int32_t dims[3], n_valid;
+  int64_t* count;
+  double* mean;  /* [ncell][3] */
+  double* icov;  /* [ncell][6]  xx xy xz yy yz zz */
+  uint8_t* valid;
+} orc_grid3d;
+
+#define ORC_JACOBI_SWEEPS 6
+
+/* oracle/ndt3d.py jacobi_eig3(): cyclic Jacobi, fixed sweeps over (0,1), (0,2), (1,2) */
+static void jacobi_eig3(double A[3][3], double V[3][3]) {
+  static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < ORC_JACOBI_SWEEPS; ++sweep) {
+    for (int e = 0; e < 3; ++e) {
+      const int p = PQ[e][0], q = PQ[e][1], r = 3 - p - q;
+      const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
+      double t = 0.0;
+      if (fabs(apq) > 1e-300) {
+        const double tau = (aqq - app) / (2.0 * apq);
+        t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));   /* tau^2 = inf -> t = 0 */
+      }
+      const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+      const double arp = A[r][p], arq = A[r][q];
+      A[p][p] = app - t * apq;
+      A[q][q] = aqq + t * apq;
+      A[p][q] = A[q][p] = 0.0;
+      A[r][p] = A[p][r] = c * arp - sn * arq;
+      A[r][q] = A[q][r] = sn * arp + c * arq;
+      for (int i = 0; i < 3; ++i) {
+        const double vp = V[i][p], vq = V[i][q];
+        V[i][p] = c * vp - sn * vq;
+        V[i][q] = sn * vp + c * vq;
+      }
+    }
+  }
+}
+
+/* oracle/ndt3d.py finalise_cells3() for one voxel: M2 = xx xy xz yy yz zz */
+static int finalise_cell3(int64_t n, const double M2[6], const orc_params* p, double icov[6]) {
+  const int64_t nmin = p->min_points > 2 ? p->min_points : 2;
+  if (n < nmin) return 0;
+  const double den = (double)(n - 1 > 1 ? n - 1 : 1);
+  double A[3][3], V[3][3];
+  A[0][0] = M2[0] / den; A[0][1] = A[1][0] = M2[1] / den; A[0][2] = A[2][0] = M2[2] / den;
+  A[1][1] = M2[3] / den; A[1][2] = A[2][1] = M2[4] / den; A[2][2] = M2[5] / den;
+  jacobi_eig3(A, V);
+  const double lam[3] = {A[0][0], A[1][1], A[2][2]};
+  const double lmax = fmax(lam[0], fmax(lam[1], lam[2]));
+  if (!(lmax > 0.0)) return 0;
+  double inv[3];
+  for (int k = 0; k < 3; ++k) inv[k] = 1.0 / fmax(lam[k], p->eig_ratio * lmax);
+  double C[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0.0;
+      for (int k = 0; k < 3; ++k) a += V[i][k] * inv[k] * V[j][k];
+      C[i][j] = a;
+    }
+  icov[0] = C[0][0]; icov[1] = C[0][1]; icov[2] = C[0][2]; icov[3] = C[1][1]; icov[4] = C[1][2]; icov[5] = C[2][2];
+  return 1;
+}
+
+void orc3d_free_grid(orc_grid3d* g) {
+  if (!g) return;
+  free(g->count); free(g->mean); free(g->icov); free(g->valid); free(g);
+}
+
+/* oracle/ndt3d.py grid_geometry3(), cell_keys3(), build_grid3(): two-pass mean (sum, then re-centred), centred M2 */
+orc_grid3d* orc3d_build_grid(const float* x, const float* y, const float* z, size_t n, const orc_params* p) {
+  if (n == 0) return NULL;
+  const float* P[3] = {x, y, z};
+  const double c = p->cell_size;
+  orc_grid3d* g = (orc_grid3d*)calloc(1, sizeof(*g));
+  g->inv_c = (float)(1.0 / c);
+  for (int a = 0; a < 3; ++a) {
+    float mn = P[a][0], mx = P[a][0];
+    for (size_t i = 1; i < n; ++i) { if (P[a][i] < mn) mn = P[a][i]; if (P[a][i] > mx) mx = P[a][i]; }
+    g->o[a] = (float)((floor((double)mn / c) - 1.0) * c);
+    volatile float f = (mx - g->o[a]) * g->inv_c;
+    g->dims[a] = (int32_t)floorf(f) + 2;
+  }
+  const size_t nc = (size_t)g->dims[0] * g->dims[1] * g->dims[2];
+  g->count = (int64_t*)calloc(nc, sizeof(int64_t));
+  g->mean = (double*)calloc(nc * 3, sizeof(double));
+  g->icov = (double*)calloc(nc * 6, sizeof(double));
+  g->valid = (uint8_t*)calloc(nc, 1);
+  int64_t* key = (int64_t*)malloc(n * sizeof(int64_t));
+  double* mean = (double*)calloc(nc * 3, sizeof(double));
+  double* corr = (double*)calloc(nc * 3, sizeof(double));
+  double* m2 = (double*)calloc(nc * 6, sizeof(double));
+  for (size_t i = 0; i < n; ++i) {
+    int64_t idx[3];
+    int inside = 1;
+    for (int a = 0; a < 3; ++a) {
+      volatile float f = (P[a][i] - g->o[a]) * g->inv_c;
+      idx[a] = (int64_t)floorf(f);
+      if (idx[a] < 0 || idx[a] >= g->dims[a]) inside = 0;
+    }
+    key[i] = inside ? (idx[2] * g->dims[1] + idx[1]) * g->dims[0] + idx[0] : -1;
+    if (!inside) continue;                /* cannot happen with this geometry (ndt3d.py asserts it) */
+    g->count[key[i]] += 1;
+    for (int a = 0; a < 3; ++a) mean[3 * key[i] + a] += (double)P[a][i];
+  }
+  for (size_t k = 0; k < nc; ++k) {
+    const double nz = g->count[k] > 0 ? (double)g->count[k] : 1.0;
+    for (int a = 0; a < 3; ++a) mean[3 * k + a] /= nz;
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (key[i] >= 0) for (int a = 0; a < 3; ++a) corr[3 * key[i] + a] += (double)P[a][i] - mean[3 * key[i] + a];
+  for (size_t k = 0; k < nc; ++k) {
+    const double nz = g->count[k] > 0 ? (double)g->count[k] : 1.0;
+    for (int a = 0; a < 3; ++a) mean[3 * k + a] = mean[3 * k + a] + corr[3 * k + a] / nz;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    if (key[i] < 0) continue;
+    const size_t k = (size_t)key[i];
+    const double dx = (double)x[i] - mean[3 * k], dy = (double)y[i] - mean[3 * k + 1], dz = (double)z[i] - mean[3 * k + 2];
+    m2[6 * k] += dx * dx; m2[6 * k + 1] += dx * dy; m2[6 * k + 2] += dx * dz;
+    m2[6 * k + 3] += dy * dy; m2[6 * k + 4] += dy * dz; m2[6 * k + 5] += dz * dz;
+  }
+  for (size_t k = 0; k < nc; ++k) {
+    double ic[6];
+    if (finalise_cell3(g->count[k], m2 + 6 * k, p, ic)) {
+      g->valid[k] = 1;
+      g->n_valid += 1;
+      for (int a = 0; a < 3; ++a) g->mean[3 * k + a] = mean[3 * k + a];
+      for (int a = 0; a < 6; ++a) g->icov[6 * k + a] = ic[a];
+    }
+  }
+  free(key); free(mean); free(corr); free(m2);
+  return g;
+}
+
+void orc3d_grid_info(const orc_grid3d* g, float o[3], float* inv_c, int32_t dims[3], int32_t* n_valid) {
+  for (int a = 0; a < 3; ++a) { o[a] = g->o[a]; dims[a] = g->dims[a]; }
+  *inv_c = g->inv_c; *n_valid = g->n_valid;
+}
+
+void orc3d_grid_copy(const orc_grid3d* g, int64_t* count, double* mean, double* icov, uint8_t* valid) {
+  const size_t nc = (size_t)g->dims[0] * g->dims[1] * g->dims[2];
+  if (count) memcpy(count, g->count, nc * sizeof(int64_t));
+  if (mean) memcpy(mean, g->mean, nc * 3 * sizeof(double));
+  if (icov) memcpy(icov, g->icov, nc * 6 * sizeof(double));
+  if (valid) memcpy(valid, g->valid, nc);
+}
+
+static void mat3_mul(const double A[3][3], const double B[3][3], double C[3][3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
+}
+
+/* oracle/ndt3d.py rot_and_derivs() + rot_second_derivs(): R = Rz Ry Rx; D[0..2] first derivatives (roll, pitch, yaw);
+ * DD[0..5] second derivatives in the order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2) */
+static void rot_derivs(double roll, double pitch, double yaw, double R[3][3], double D[3][3][3], double DD[6][3][3]) {
+  const double ca = cos(roll), sa = sin(roll), cb = cos(pitch), sb = sin(pitch), cg = cos(yaw), sg = sin(yaw);
+  const double Rx[3][3] = {{1, 0, 0}, {0, ca, -sa}, {0, sa, ca}};
+  const double Ry[3][3] = {{cb, 0, sb}, {0, 1, 0}, {-sb, 0, cb}};
+  const double Rz[3][3] = {{cg, -sg, 0}, {sg, cg, 0}, {0, 0, 1}};
+  const double dRx[3][3] = {{0, 0, 0}, {0, -sa, -ca}, {0, ca, -sa}};
+  const double dRy[3][3] = {{-sb, 0, cb}, {0, 0, 0}, {-cb, 0, -sb}};
+  const double dRz[3][3] = {{-sg, -cg, 0}, {cg, -sg, 0}, {0, 0, 0}};
+  const double ddRx[3][3] = {{0, 0, 0}, {0, -ca, sa}, {0, -sa, -ca}};
+  const double ddRy[3][3] = {{-cb, 0, -sb}, {0, 0, 0}, {sb, 0, -cb}};
+  const double ddRz[3][3] = {{-cg, sg, 0}, {-sg, -cg, 0}, {0, 0, 0}};
+  double T[3][3];
+#define ORC_PROD(Z, Y, X, OUT) do { mat3_mul(Z, Y, T); mat3_mul(T, X, OUT); } while (0)
+  ORC_PROD(Rz, Ry, Rx, R);
+  ORC_PROD(Rz, Ry, dRx, D[0]); ORC_PROD(Rz, dRy, Rx, D[1]); ORC_PROD(dRz, Ry, Rx, D[2]);
+  ORC_PROD(Rz, Ry, ddRx, DD[0]); ORC_PROD(Rz, dRy, dRx, DD[1]); ORC_PROD(dRz, Ry, dRx, DD[2]);
+  ORC_PROD(Rz, ddRy, Rx, DD[3]); ORC_PROD(dRz, dRy, Rx, DD[4]); ORC_PROD(ddRz, Ry, Rx, DD[5]);
+#undef ORC_PROD
+}
+
+#define ORC3_NACC (36 + 6 + 9 + 1)   /* H (full 6x6), g, M = sum w v p' (Newton), score */
+
+/* oracle/ndt3d.py evaluate3() in float64 truth mode.  Per-thread partial sums are added in thread order. */
+void orc3d_evaluate(const orc_grid3d* g, const float* sx, const float* sy, const float* sz, size_t n, const double pose[6],
+                    const orc_params* p, int threads, double H[36], double grad[6], double* score, int32_t* n_hit) {
+  double R[3][3], D[3][3][3], DD[6][3][3];
+  rot_derivs(pose[3], pose[4], pose[5], R, D, DD);
+  const double t[3] = {pose[0], pose[1], pose[2]};
+  const double o[3] = {(double)g->o[0], (double)g->o[1], (double)g->o[2]}, inv_c = (double)g->inv_c;
+  const double d1 = p->d1, d2 = p->d2;
+  const int newton = p->hessian_mode == 1;
+  int nthr = threads > 0 ? threads : 1;
+#ifndef _OPENMP
+  nthr = 1;
+#endif
+  double* part = (double*)calloc((size_t)nthr * ORC3_NACC, sizeof(double));
+  long* hits = (long*)calloc((size_t)nthr, sizeof(long));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthr)
+#endif
+  {
+#ifdef _OPENMP
+    const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+    const int tid = 0, nt = 1;
+#endif
+    double acc[ORC3_NACC];
+    for (int k = 0; k < ORC3_NACC; ++k) acc[k] = 0.0;
+    long nh = 0;
+    const size_t lo = n * (size_t)tid / (size_t)nt, hi = n * (size_t)(tid + 1) / (size_t)nt;
+    for (size_t i = lo; i < hi; ++i) {
+      const double pt[3] = {(double)sx[i], (double)sy[i], (double)sz[i]};
+      double pw[3];
+      int64_t idx[3];
+      int inside = 1;
+      for (int a = 0; a < 3; ++a) {
+        pw[a] = R[a][0] * pt[0] + R[a][1] * pt[1] + R[a][2] * pt[2] + t[a];
+        const double f = floor((pw[a] - o[a]) * inv_c);
+        if (!(f >= 0.0 && f < (double)g->dims[a])) inside = 0;
+        idx[a] = (int64_t)f;
+      }
+      if (!inside) continue;
+      const size_t k = (size_t)((idx[2] * g->dims[1] + idx[1]) * g->dims[0] + idx[0]);
+      if (!g->valid[k]) continue;
+      const double* ic = g->icov + 6 * k;
+      const double C[3][3] = {{ic[0], ic[1], ic[2]}, {ic[1], ic[3], ic[4]}, {ic[2], ic[4], ic[5]}};
+      const double q[3] = {pw[0] - g->mean[3 * k], pw[1] - g->mean[3 * k + 1], pw[2] - g->mean[3 * k + 2]};
+      double v[3];
+      for (int a = 0; a < 3; ++a) v[a] = C[a][0] * q[0] + C[a][1] * q[1] + C[a][2] * q[2];
+      const double m = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+      const double s = d1 * exp(-0.5 * d2 * m), w = s * d2;
+      double J[3][6];
+      for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) J[a][b] = a == b ? 1.0 : 0.0;
+        for (int r = 0; r < 3; ++r) J[a][3 + r] = D[r][a][0] * pt[0] + D[r][a][1] * pt[1] + D[r][a][2] * pt[2];
+      }
+      double CJ[3][6], Jv[6];
+      for (int c6 = 0; c6 < 6; ++c6) {
+        for (int a = 0; a < 3; ++a) CJ[a][c6] = C[a][0] * J[0][c6] + C[a][1] * J[1][c6] + C[a][2] * J[2][c6];
+        Jv[c6] = J[0][c6] * v[0] + J[1][c6] * v[1] + J[2][c6] * v[2];
+        acc[36 + c6] += w * Jv[c6];
+      }
+      for (int r = 0; r < 6; ++r)
+        for (int c6 = 0; c6 < 6; ++c6) {
+          double h = w * (J[0][r] * CJ[0][c6] + J[1][r] * CJ[1][c6] + J[2][r] * CJ[2][c6]);
+          if (newton) h -= d2 * w * Jv[r] * Jv[c6];
+          acc[6 * r + c6] += h;
+        }
+      if (newton)
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) acc[42 + 3 * a + b] += w * v[a] * pt[b];
+      acc[51] += s;
+      nh += 1;
+    }
+    memcpy(part + (size_t)tid * ORC3_NACC, acc, sizeof(acc));
+    hits[tid] = nh;
+  }
+  double tot[ORC3_NACC];
+  for (int k = 0; k < ORC3_NACC; ++k) tot[k] = 0.0;
+  long nh = 0;
+  for (int th = 0; th < nthr; ++th) {
+    for (int k = 0; k < ORC3_NACC; ++k) tot[k] += part[(size_t)th * ORC3_NACC + k];
+    nh += hits[th];
+  }
+  free(part); free(hits);
+  memcpy(H, tot, 36 * sizeof(double));
+  memcpy(grad, tot + 36, 6 * sizeof(double));
+  if (newton) {   /* v' d2p'/dpk dpl on the rotation block: sum_ab Rkl[a][b] M[a][b] */
+    static const int AB[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+    for (int e = 0; e < 6; ++e) {
+      double t2 = 0.0;
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) t2 += DD[e][a][b] * tot[42 + 3 * a + b];
+      const int a = AB[e][0], b = AB[e][1];
+      H[6 * (3 + a) + 3 + b] += t2;
+      if (a != b) H[6 * (3 + b) + 3 + a] += t2;
+    }
+  }
+  *score = tot[51];
+  *n_hit = (int32_t)nh;
+}
+
+/* oracle/ndt3d.py solve_ldl(), n = 6 */
+static int solve_ldl6(const double H[36], const double g[6], double x[6]) {
+  enum { N = 6 };
+  double dg[N];
+  for (int i = 0; i < N; ++i) dg[i] = fmax(fabs(H[N * i + i]), 1e-12);
+  double lam = 0.0;
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    double L[N][N], Dd[N];
+    memset(L, 0, sizeof(L));
+    int ok = 1;
+    for (int j = 0; j < N && ok; ++j) {
+      double pv = H[N * j + j] + lam * dg[j];
+      for (int k = 0; k < j; ++k) pv -= L[j][k] * L[j][k] * Dd[k];
+      if (!(pv > 1e-12 * dg[j])) { ok = 0; break; }
+      Dd[j] = pv;
+      for (int i = j + 1; i < N; ++i) {
+        double a = H[N * i + j];
+        for (int k = 0; k < j; ++k) a -= L[i][k] * L[j][k] * Dd[k];
+        L[i][j] = a / pv;
+      }
+    }
+    if (ok) {
+      double zz[N];
+      for (int i = 0; i < N; ++i) {
+        double a = -g[i];
+        for (int k = 0; k < i; ++k) a -= L[i][k] * zz[k];
+        zz[i] = a;
+      }
+      int fin = 1;
+      for (int i = N - 1; i >= 0; --i) {
+        double a = zz[i] / Dd[i];
+        for (int k = i + 1; k < N; ++k) a -= L[k][i] * x[k];
+        x[i] = a;
+      }
+      for (int i = 0; i < N; ++i) if (!isfinite(x[i])) fin = 0;
+      if (fin) return 1;
+    }
+    lam = lam == 0.0 ? 1e-6 : lam * 10.0;
+  }
+  for (int i = 0; i < N; ++i) x[i] = 0.0;
+  return 0;
+}
+
+/* oracle/ndt3d.py align3() with gn_update3() inlined */
+int32_t orc3d_align(const orc_grid3d* g, const float* sx, const float* sy, const float* sz, size_t n, const double init[6],
+                    const orc_params* p, int threads, orc_result3* out) {
+  memset(out, 0, sizeof(*out));
+  double pose[6];
+  memcpy(pose, init, sizeof(pose));
+  int it = 0, status = 0;
+  if (g->n_valid < 1) {
+    memcpy(out->pose, pose, sizeof(pose));
+    out->status = 4;
+    return 4;
+  }
+  double ls_base[6] = {0}, ls_step[6] = {0}, ls_score = 0.0, ls_alpha = 1.0;
+  int ls_valid = 0, ls_trials = 0;
+  for (;;) {
+    double d[6];
+    orc3d_evaluate(g, sx, sy, sz, n, pose, p, threads, out->H, out->g, &out->score, &out->n_hit);
+    if (p->line_search > 0 && ls_valid && ls_trials < p->line_search &&
+        (out->n_hit < p->min_hits || out->score < ls_score - 1e-3 * fabs(ls_score))) {
+      ls_alpha *= 0.5;
+      ls_trials += 1;
+      for (int j = 0; j < 3; ++j) pose[j] = ls_base[j] + ls_alpha * ls_step[j];
+      for (int j = 3; j < 6; ++j) pose[j] = wrap_angle(ls_base[j] + ls_alpha * ls_step[j]);
+      it += 1;
+      if (p->fixed_iterations > 0) { if (it >= p->fixed_iterations) break; continue; }
+      if (it >= p->max_iterations) { status = 1; break; }
+      continue;
+    }
+    if (out->n_hit < p->min_hits) { status = 3; break; }
+    if (!solve_ldl6(out->H, out->g, d)) { status = 2; break; }
+    { const double w = p->step_scale > 0.0 ? p->step_scale : 1.0; for (int j = 0; j < 6; ++j) d[j] *= w; }
+    const double nt = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), nr = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    double alpha = 1.0;
+    if (nt > p->step_max_trans) alpha = p->step_max_trans / nt;
+    if (nr * alpha > p->step_max_rot) alpha = p->step_max_rot / nr;
+    for (int j = 0; j < 6; ++j) d[j] *= alpha;
+    if (p->line_search > 0) {
+      for (int j = 0; j < 6; ++j) { ls_base[j] = pose[j]; ls_step[j] = d[j]; }
+      ls_score = out->score; ls_alpha = 1.0; ls_trials = 0; ls_valid = 1;
+    }
+    for (int j = 0; j < 3; ++j) pose[j] += d[j];
+    for (int j = 3; j < 6; ++j) pose[j] = wrap_angle(pose[j] + d[j]);
+    it += 1;
+    if (p->fixed_iterations > 0) { if (it >= p->fixed_iterations) break; continue; }
+    if (nt * alpha < p->eps_trans && nr * alpha < p->eps_rot) break;
+    if (it >= p->max_iterations) { status = 1; break; }
+  }
+  memcpy(out->pose, pose, sizeof(pose));
+  out->iterations = it;
+  out->status = status;
+  return status;
 }

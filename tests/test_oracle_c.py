@@ -40,3 +40,57 @@ def test_c_port_matches_numpy_oracle(cport, config, mode):
     rt = cg.align(d["sx"], d["sy"], d["init"], threads=2)          # OpenMP reduction order differs
     assert np.abs(np.array(rt["pose"]) - np.array(r2["pose"])).max() < 1e-7
     cg.close()
+
+
+# ---- 3D twin (orc3d_*) against oracle/ndt3d.py: SURVEY section 4 "cross-implementation" (pose <= 1e-9, H <= 1e-10 rel)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_c_port_3d_matches_numpy_oracle(cport, mode):
+    from gtsam_ndt_amd import synth3d
+    from oracle import ndt3d as o3
+    d = synth3d.make_pair3d(n_elev=32, n_azim=512)
+    prm = o3.Ndt3Params(hessian_mode=mode)
+    g = o3.build_grid3(d["tx"], d["ty"], d["tz"], prm)
+    cg = cport.CGrid3(d["tx"], d["ty"], d["tz"], prm)
+    assert cg.dims == tuple(g.dims) and cg.n_valid == g.n_valid and np.array_equal(cg.o, g.o) and cg.inv_c == g.inv_c
+    count, mean, icov, valid = cg.arrays()
+    np.testing.assert_array_equal(count, g.count)
+    np.testing.assert_array_equal(valid, g.valid)
+    np.testing.assert_allclose(mean, g.mean, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(icov, g.icov, rtol=1e-10, atol=1e-9 * np.abs(g.icov).max())
+    for pose in (d["init"], d["pose"]):
+        H, gr, s, nh = cg.evaluate(d["sx"], d["sy"], d["sz"], pose)
+        H2, g2, s2, nh2 = o3.evaluate3(g, d["sx"], d["sy"], d["sz"], pose, prm)
+        assert nh == nh2 and abs(s - s2) < 1e-9 * s2
+        assert np.abs(H - H2).max() < 1e-10 * np.abs(H2).max()
+        assert np.abs(gr - g2).max() < 1e-9 * np.sqrt(np.abs(np.diag(H2)).max() * s2)
+        Ht, gt, st, nht = cg.evaluate(d["sx"], d["sy"], d["sz"], pose, threads=3)      # partial sums per thread
+        assert nht == nh and np.abs(Ht - H).max() < 1e-12 * np.abs(H).max()
+    if mode == 0:
+        r = cg.align(d["sx"], d["sy"], d["sz"], d["init"])
+        r2 = o3.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm)
+        assert r["status"] == r2["status"] == 0 and r["iterations"] == r2["iterations"]
+        assert np.abs(np.array(r["pose"]) - np.array(r2["pose"])).max() < 1e-9
+        assert np.abs(r["H"] - r2["H"]).max() < 1e-9 * np.abs(r2["H"]).max()
+    # fixed-K with line search and over-relaxation: the same trajectory step for step
+    prm2 = o3.Ndt3Params(hessian_mode=mode, fixed_iterations=8, line_search=3, step_scale=1.5)
+    r = cg.align(d["sx"], d["sy"], d["sz"], d["init"], fixed_iterations=8, line_search=3, step_scale=1.5)
+    r2 = o3.align3(g, d["sx"], d["sy"], d["sz"], d["init"], prm2)
+    assert r["iterations"] == r2["iterations"] == 8
+    # Newton far from the optimum: Levenberg-damped steps through indefinite Hessians amplify the 1e-16 differences of
+    # the two summation orders (as in 2D, see above); Gauss-Newton keeps the survey's 1e-9
+    assert np.abs(np.array(r["pose"]) - np.array(r2["pose"])).max() < (1e-9 if mode == 0 else 1e-6)
+    cg.close()
+
+
+def test_c_port_3d_degenerate_inputs(cport):
+    from oracle import ndt3d as o3
+    rng = np.random.default_rng(0)
+    t = rng.uniform(-3, 3, (3, 40)).astype(np.float32)        # too sparse for any voxel (min_points 5 in 1 m cells)
+    prm = o3.Ndt3Params()
+    cg = cport.CGrid3(*t, prm)
+    g = o3.build_grid3(*t, prm)
+    assert cg.n_valid == g.n_valid
+    r = cg.align(*t, (0.0,) * 6)
+    r2 = o3.align3(g, *t, (0.0,) * 6, prm)
+    assert r["status"] == r2["status"] and r["iterations"] == r2["iterations"]
+    cg.close()
