@@ -28,7 +28,7 @@ NDT_ERR_RCCL = -7
 
 # ndt2d_set_tuning / ndt2d_batch_set_tuning knobs
 TUNING = {"launch_graphs": 1, "wide_threshold": 2, "short_scan_kernel": 3, "chunk_launches": 4, "binned_build": 5,
-          "batch_small_variant": 6, "team_kernel": 7, "split_from": 8, "single_sync_build": 9,
+          "batch_small_variant": 6, "split_from": 8, "single_sync_build": 9,
           "batch_global_workgroups": 10}
 
 HESSIAN_GAUSS_NEWTON = 0
@@ -148,7 +148,6 @@ SIGNATURES = {
     "ndt2d_align_multi_start_dev": (C.c_int32, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int32, _vp]),
     "ndt2d_stream": (_vp, [_vp]),
     "ndt2d_set_tuning": (C.c_int32, [_vp, C.c_int32, C.c_int64]),
-    "ndt2d_team_fallback_count": (C.c_int64, [_vp]),
     "ndt2d_batch_set_tuning": (C.c_int32, [_vp, C.c_int32, C.c_int64]),
     "ndt2d_wait_stream": (C.c_int32, [_vp, _vp]),
     "ndt2d_batch_wait_stream": (C.c_int32, [_vp, _vp]),

@@ -15,7 +15,6 @@
 #include "ndt2d_small.hpp"
 #include "ndt2d_build.hpp"
 #include "ndt2d_multi_start.hpp"
-#include "ndt2d_xcd.hpp"
 #include "ndt_host.hpp"
 
 #include <atomic>
@@ -64,20 +63,7 @@ struct ndt2d_handle {
   hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
   AlignDynMulti* d_dyn_multi = nullptr;    // multi-start chains (ndt2d_multi_start.hpp), allocated on first use
   IterState* h_state_multi = nullptr;      // pinned [kMaxStarts]
-  // team kernel (ndt2d_xcd.hpp): the whole loop in one launch, 32 workgroups per start
-  XcdShared* d_xcd = nullptr;              // barrier words and partial rows
-  IterState* d_xcd_state = nullptr;        // [kMaxStarts]
-  int* h_xcd_flag = nullptr;               // pinned [kMaxStarts]: +seq done, -seq the team gave up
   int split_from = 12;                     // multi-start / multi-scan calls of this many starts use the split chain (NDT_TUNE_SPLIT_FROM)
-  bool use_xcd = false;                    // NDT_TUNE_TEAM_KERNEL (off by default: measured slower than k_iterate for one start)
-  int home_xcd = 0;                        // team 0's workgroups are those with blockIdx % 8 == home_xcd
-  long long xcd_fallbacks = 0;             // calls whose team could not assemble and that ran on the other path
-  struct XcdRun {                          // a team-kernel call in flight, with what a fallback needs to run it again
-    bool active = false;
-    int m = 0, seq = 0, fixed = 0;
-    const float* sx = nullptr; const float* sy = nullptr; size_t n = 0;
-    double poses[kMaxStarts][3];
-  } xcd_run;
   ChunkRun chunk_run;                      // converged-mode loop begun by ndt2d_align_dev_async
   int call_seq = 0;                        // alignments enqueued so far (never 0 once one has run)
   bool wide = false;                       // this alignment's k_iterate launches use 1024-thread workgroups
@@ -459,90 +445,8 @@ int32_t ensure_graph(ndt2d_handle* h, int launches, int blocks) {
 // launches (synchronous early exit); 0: enqueue all launches, finished ones are no-ops.
 // Wait for a single-workgroup alignment: its last thread raises the flag in pinned host memory
 // after writing the state there, so the result is on the host the moment the spin ends.
-// ---- team kernel (ndt2d_xcd.hpp) -------------------------------------------------------------------
 int32_t ensure_multi_buffers(ndt2d_handle* h) {
   if (!h->h_state_multi) HIP_TRY(hipHostMalloc((void**)&h->h_state_multi, kMaxStarts * sizeof(IterState), hipHostMallocDefault));
-  return NDT_OK;
-}
-
-bool xcd_eligible(const ndt2d_handle* h, size_t n) {
-  return h->use_xcd && h->use_graph && h->prm.overlap_grids != 4 && !(h->use_wide && n >= h->wide_threshold) &&
-         h->prm.line_search >= 0;
-}
-
-// enqueue one launch that runs m starts to the end; results arrive in h_state_multi, flags in h_xcd_flag
-int32_t begin_xcd(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n, const double* poses, int m, int fixed) {
-  { const int32_t st = ensure_multi_buffers(h); if (st != NDT_OK) return st; }
-  if (!h->d_xcd) {
-    HIP_TRY(hipMalloc((void**)&h->d_xcd, sizeof(XcdShared)));
-    HIP_TRY(hipMalloc((void**)&h->d_xcd_state, kMaxStarts * sizeof(IterState)));
-    HIP_TRY(hipHostMalloc((void**)&h->h_xcd_flag, kMaxStarts * sizeof(int), hipHostMallocDefault));
-    for (int k = 0; k < kMaxStarts; ++k) h->h_xcd_flag[k] = 0;
-  }
-  h->call_seq = h->call_seq == 0x7fffffff ? 1 : h->call_seq + 1;
-  ndt2d_handle::XcdRun& r = h->xcd_run;
-  r.m = m; r.seq = h->call_seq; r.fixed = fixed; r.sx = d_sx; r.sy = d_sy; r.n = n;
-  StartPoses sp{};
-  for (int k = 0; k < m; ++k)
-    for (int j = 0; j < 3; ++j) { sp.p[k][j] = poses[3 * k + j]; r.poses[k][j] = poses[3 * k + j]; }
-  HIP_TRY(hipMemsetAsync(h->d_xcd, 0, sizeof(h->d_xcd->team), h->stream));       // barrier counters and abort flags
-  const bool newton = h->prm.hessian_mode == NDT_HESSIAN_NEWTON;
-  if (newton)
-    hipLaunchKernelGGL((k_align_xcd<1>), dim3(kXcdTeams * kXcdMembers), dim3(kXcdThreads), 0, h->stream, h->d_static, d_sx, d_sy,
-                       (int)n, sp, m, fixed, h->d_xcd, h->d_xcd_state, h->h_state_multi, h->h_xcd_flag, r.seq, h->home_xcd);
-  else
-    hipLaunchKernelGGL((k_align_xcd<0>), dim3(kXcdTeams * kXcdMembers), dim3(kXcdThreads), 0, h->stream, h->d_static, d_sx, d_sy,
-                       (int)n, sp, m, fixed, h->d_xcd, h->d_xcd_state, h->h_state_multi, h->h_xcd_flag, r.seq, h->home_xcd);
-  HIP_TRY(hipGetLastError());
-  r.active = true;
-  return NDT_OK;
-}
-
-// waits for the flags of the call in flight.  *gave_up = true: a team could not assemble (the GPU is
-// busy with other work); the launch has ended by then and the caller runs the other path.
-int32_t finish_xcd(ndt2d_handle* h, bool* gave_up) {
-  ndt2d_handle::XcdRun& r = h->xcd_run;
-  *gave_up = false;
-  if (!r.active) return NDT_OK;
-  r.active = false;
-  bool seen = false;
-  auto all_in = [&]() {
-    for (int k = 0; k < r.m; ++k) {
-      const int f = __atomic_load_n(&h->h_xcd_flag[k], __ATOMIC_ACQUIRE);
-      if (f != r.seq && f != -r.seq) return false;
-    }
-    return true;
-  };
-  HIP_TRY(spin_until(h->stream, all_in, &seen));
-  HIP_TRY(hipGetLastError());
-  if (!seen) { set_error("the team kernel did not report its end"); return NDT_ERR_HIP; }
-  for (int k = 0; k < r.m; ++k)
-    if (__atomic_load_n(&h->h_xcd_flag[k], __ATOMIC_ACQUIRE) == -r.seq) *gave_up = true;
-  if (*gave_up) {
-    h->xcd_fallbacks += 1;
-    HIP_TRY(hipStreamSynchronize(h->stream));                        // every team has left before the other path starts
-  }
-  return NDT_OK;
-}
-
-int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n, const double pose[3],
-                  int fixed_override, int check_every, bool wait, bool own_source, bool allow_xcd);
-
-// a single-start team-kernel call in flight -> its result in h->h_state (falls back if the team gave up)
-int32_t finish_xcd_single(ndt2d_handle* h) {
-  if (!h->xcd_run.active) return NDT_OK;
-  bool gave_up = false;
-  const int32_t st = finish_xcd(h, &gave_up);
-  if (st != NDT_OK) return st;
-  if (gave_up) {
-    const ndt2d_handle::XcdRun r = h->xcd_run;
-    const int32_t rs = run_align(h, r.sx, r.sy, r.n, r.poses[0], r.fixed, h->check_every, /*wait=*/true, /*own_source=*/false,
-                                 /*allow_xcd=*/false);
-    return rs;
-  }
-  std::memcpy(h->h_state, &h->h_state_multi[0], sizeof(IterState));
-  h->h_state->done = 2;               // marks "result already on the host"
-  h->pending = false;
   return NDT_OK;
 }
 
@@ -560,7 +464,6 @@ int32_t finish_small_run(ndt2d_handle* h) {
 }
 
 int32_t finish_chunk_run(ndt2d_handle* h) {
-  { const int32_t fs = finish_xcd_single(h); if (fs != NDT_OK) return fs; }
   { const int32_t fs = finish_small_run(h); if (fs != NDT_OK) return fs; }
   if (!h->chunk_run.active) return NDT_OK;
   bool seen = false;
@@ -572,18 +475,10 @@ int32_t finish_chunk_run(ndt2d_handle* h) {
 }
 
 int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n, const double pose[3],
-                  int fixed_override, int check_every, bool wait = true, bool own_source = false, bool allow_xcd = true) {
+                  int fixed_override, int check_every, bool wait = true, bool own_source = false) {
   TraceRange range("ndt2d_align: Gauss-Newton loop");
   if (!h->has_target) return NDT_ERR_NO_TARGET;
-  const bool team = allow_xcd && n > (size_t)kSmallMaxPoints && xcd_eligible(h, n);
-  if (h->xcd_run.active && team) {
-    // a team-kernel call in flight is simply followed on the stream by the next one (its result was
-    // not asked for; flags carry the call number, so the two cannot be confused)
-    h->xcd_run.active = false;
-  } else {
-    const int32_t fs = finish_chunk_run(h);                                  // an unfinished asynchronous call
-    if (fs != NDT_OK) return fs;
-  }
+  { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }     // an unfinished asynchronous call
   if (n == 0 || n > kMaxSourcePoints || !pose) return NDT_ERR_INVALID_ARG;
   if (h->n_valid < 1) {
     h->pending = false;
@@ -622,13 +517,6 @@ int32_t run_align(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t 
     h->small_run = true;
     h->pending = false;
     return wait ? finish_small_run(h) : NDT_OK;
-  }
-  if (team) {
-    // mid-size scan: the whole loop in one launch of a 32-workgroup team (ndt2d_xcd.hpp)
-    const int32_t bs = begin_xcd(h, d_sx, d_sy, n, pose, 1, fixed > 0 ? fixed : 0);
-    if (bs != NDT_OK) return bs;
-    h->pending = false;
-    return wait ? finish_xcd_single(h) : NDT_OK;
   }
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, h->stream, h->d_call, h->d_dyn, d_sx, d_sy, (int)n, pose[0], pose[1],
                      pose[2], fixed, chunked ? h->h_state : (IterState*)nullptr, chunked ? h->h_flag : (int*)nullptr,
@@ -818,7 +706,6 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipEventCreateWithFlags(&h->upload_ev, hipEventDisableTiming) != hipSuccess) return fail(NDT_ERR_HIP);
   *h->h_flag = 0;
-  { static std::atomic<int> next_home{0}; h->home_xcd = next_home.fetch_add(1) % kXcdTeams; }
   if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
   *out = h;
@@ -832,9 +719,6 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
   if (h->h_state_multi) (void)hipHostFree(h->h_state_multi);
-  if (h->h_xcd_flag) (void)hipHostFree(h->h_xcd_flag);
-  if (h->d_xcd) (void)hipFree(h->d_xcd);
-  if (h->d_xcd_state) (void)hipFree(h->d_xcd_state);
   void* dev[] = {h->d_geom, h->d_dyn_multi, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
                  h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
@@ -859,14 +743,11 @@ int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value) {
     case NDT_TUNE_SHORT_SCAN_KERNEL: h->use_small = value != 0; return NDT_OK;
     case NDT_TUNE_CHUNK_LAUNCHES: if (value < 2 || value > 128) return NDT_ERR_INVALID_ARG; h->check_every = (int)value; return NDT_OK;
     case NDT_TUNE_BINNED_BUILD: h->use_binned_build = value != 0; return NDT_OK;
-    case NDT_TUNE_TEAM_KERNEL: h->use_xcd = value != 0; return NDT_OK;
     case NDT_TUNE_SPLIT_FROM: if (value < 1 || value > 1000) return NDT_ERR_INVALID_ARG; h->split_from = (int)value; return NDT_OK;
     case NDT_TUNE_SINGLE_SYNC_BUILD: h->one_round_trip = value != 0; return NDT_OK;
     default: return NDT_ERR_INVALID_ARG;
   }
 }
-
-int64_t ndt2d_team_fallback_count(const ndt2d_handle* h) { return h ? (int64_t)h->xcd_fallbacks : -1; }
 
 int32_t ndt2d_wait_stream(ndt2d_handle* h, void* producer_stream) {
   if (!h) return NDT_ERR_INVALID_ARG;
@@ -1165,18 +1046,6 @@ int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const
   { const int32_t st = ensure_multi_buffers(h); if (st != NDT_OK) return st; }
   size_t n_max = 0;
   for (int32_t k = 0; k < (shared ? 1 : m); ++k) n_max = ns[k] > n_max ? ns[k] : n_max;
-  if (shared && xcd_eligible(h, n_max)) {
-    // one launch: team t (the 32 workgroups of one XCD) runs start t to the end (ndt2d_xcd.hpp)
-    const int32_t bs = begin_xcd(h, sxs[0], sys[0], ns[0], init_poses, m, h->prm.fixed_iterations);
-    if (bs != NDT_OK) return bs;
-    bool gave_up = false;
-    const int32_t fs = finish_xcd(h, &gave_up);
-    if (fs != NDT_OK) return fs;
-    if (!gave_up) {
-      for (int32_t k = 0; k < m; ++k) state_to_result(h->h_state_multi[k], &results[k]);
-      return NDT_OK;
-    }
-  }
   if (!h->d_dyn_multi) {
     HIP_TRY(hipMalloc((void**)&h->d_dyn_multi, sizeof(AlignDynMulti)));
     HIP_TRY(hipMemsetAsync(h->d_dyn_multi, 0, sizeof(AlignDynMulti), h->stream));

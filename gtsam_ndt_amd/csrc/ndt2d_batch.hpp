@@ -46,6 +46,8 @@ struct BatchArgs {
   int* fb_marks;             // [n_pairs], zeroed before the launches: the large variant sets 1 for a pair over
                              // the on-chip capacity, the third variant processes exactly those
                              // (null: such pairs get NDT_ERR_CAPACITY at once)
+  unsigned int* fb_seen;     // pinned host word: the third variant counts the pairs it processes here (the context grows
+                             // its set of table slabs from the starting few to one per CU once any have been seen)
   int n_pairs;
   int min_points;
   int fixed_iterations;
@@ -123,8 +125,9 @@ using BatchSmall = BatchCfg<256, 16384, 768, 8192, true, true>;
 // produce (a scan against a large submap); it runs on the context's global_blocks workgroups and only on the pairs
 // the large variant handed over.
 using BatchGlobal = BatchCfg<1024, 1 << 18, 32768, 0, false, false, true>;
-constexpr int kBatchGlobalBlocks = 256;      // default: one workgroup and one 3.7 MB table slab per CU (0.95 GB per context);
-constexpr int kBatchGlobalBlocksMax = 256;   // NDT_TUNE_BATCH_GLOBAL_WORKGROUPS trades the memory against the variant's rate
+constexpr int kBatchGlobalBlocksStart = 8;   // a context starts with 8 workgroups / 3.7 MB table slabs of the global-table variant (30 MB)
+constexpr int kBatchGlobalBlocks = 256;      // ... and grows to one per CU (0.95 GB) after the first call in which a pair needed it;
+constexpr int kBatchGlobalBlocksMax = 256;   // NDT_TUNE_BATCH_GLOBAL_WORKGROUPS pins the number instead
 constexpr int kBatchThreads = BatchLarge::kThreads;       // names the host code and tools/ use
 constexpr int kBatchMaxCells = BatchLarge::kMaxCells;
 constexpr int kBatchMaxSlots = BatchLarge::kMaxSlots;
@@ -663,6 +666,7 @@ __global__ __launch_bounds__(BatchGlobal::kThreads) void k_batch_fallback(BatchA
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   for (int pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
     if (__builtin_amdgcn_readfirstlane(a.fb_marks[pair]) != 0) {              // uniform
+      if (threadIdx.x == 0 && a.fb_seen) __hip_atomic_fetch_add(a.fb_seen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       process_pair<MODE, BatchGlobal>(a, pair, smem);
       __syncthreads();
       __threadfence();                                // the next pair rewrites this workgroup's slab

@@ -25,7 +25,9 @@ struct ndt2d_batch {
   int* d_fb_list = nullptr;              // [n_pairs]: marks of the pairs the large variant left to the global-table one
   size_t marks_cap = 0;
   unsigned char* d_slab = nullptr;       // [global_blocks][BatchGlobal::kTabBytes]
-  int global_blocks = ndt::kBatchGlobalBlocks;   // workgroups (and table slabs) of the global-table variant (NDT_TUNE_BATCH_GLOBAL_WORKGROUPS)
+  int global_blocks = ndt::kBatchGlobalBlocksStart;   // workgroups (and table slabs) of the global-table variant: a few to begin with,
+  bool global_pinned = false;            // one per CU once a call has used them - unless NDT_TUNE_BATCH_GLOBAL_WORKGROUPS fixed the number
+  unsigned int* h_fb_seen = nullptr;     // pinned host word the global-table variant counts its pairs in
   bool use_small = true;                 // lidar-sized pairs run on the 256-thread variant first (ndt2d_batch_set_tuning)
   int64_t last_large = -1;               // pairs the last host-pointer call's final level ran on the large variant
 };
@@ -35,6 +37,27 @@ static_assert(offsetof(ndt::ResultDev, score) == offsetof(ndt2d_result, score), 
 static_assert(offsetof(ndt::ResultDev, status) == offsetof(ndt2d_result, status), "ResultDev layout");
 
 namespace {
+
+// The global-table variant's slabs (3.7 MB / 7.9 MB per workgroup in 2D / 3D) are most of a context's memory and most
+// batches never touch them, so a context is created with a few and gets one per CU only when a previous call has
+// handed pairs to that variant (counted by the kernel in a pinned host word - no synchronisation to learn it).  The
+// call that first meets such pairs runs them on the starting set: slower for that call, the same results.
+template <typename Ctx>
+void grow_global_slabs(Ctx* b, unsigned char** slab, size_t slab_bytes, int full, hipStream_t st) {
+  if (b->global_pinned || b->global_blocks >= full || !b->h_fb_seen) return;
+  if (__atomic_load_n(b->h_fb_seen, __ATOMIC_RELAXED) == 0) return;
+  // earlier launches on either stream may still be using the present slabs
+  if (hipStreamSynchronize(st) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+  unsigned char* bigger = nullptr;
+  if (hipMalloc((void**)&bigger, (size_t)full * slab_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    b->global_pinned = true;            // not enough memory for the full set: stay with what there is
+    return;
+  }
+  (void)hipFree(*slab);
+  *slab = bigger;
+  b->global_blocks = full;
+}
 
 int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const unsigned long long* d_toff,
                      const float* d_sx, const float* d_sy, const unsigned long long* d_soff,
@@ -60,8 +83,10 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
     HIP_TRY(hipMalloc((void**)&b->d_fb_list, want * sizeof(int)));
     b->marks_cap = want;
   }
+  grow_global_slabs(b, &b->d_slab, ndt::BatchGlobal::kTabBytes, b->n_cu < ndt::kBatchGlobalBlocks ? b->n_cu : ndt::kBatchGlobalBlocks, st);
   a.slab = b->d_slab;
   a.fb_marks = b->d_fb_list;
+  a.fb_seen = b->h_fb_seen;
   // Per resolution level: the small variant takes every pair it can hold (lidar-sized scans) and
   // marks the rest, the large variant then takes exactly the marked ones.  A later level starts
   // every pair from the pose the previous one left in d_out; stream order is the only
@@ -171,6 +196,8 @@ int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels,
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipMalloc((void**)&b->d_queue, 16) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&b->d_slab, (size_t)b->global_blocks * ndt::BatchGlobal::kTabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc((void**)&b->h_fb_seen, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  *b->h_fb_seen = 0;
   // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch<0, ndt::BatchSmall>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::BatchSmall::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
@@ -199,6 +226,7 @@ int32_t ndt2d_batch_destroy(ndt2d_batch* b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void* dev[] = {b->d_slab, b->d_fb_list, b->d_queue, b->d_tx, b->d_ty, b->d_sx, b->d_sy, b->d_toff, b->d_soff, b->d_init, b->d_out, b->d_marks};
   for (void* p : dev) if (p) (void)hipFree(p);
+  if (b->h_fb_seen) (void)hipHostFree(b->h_fb_seen);
   for (ndt2d_handle* f : b->fallback) ndt2d_destroy(f);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -217,12 +245,15 @@ int32_t ndt2d_batch_set_tuning(ndt2d_batch* b, int32_t knob, int64_t value) {
   HIP_TRY(hipStreamSynchronize(b->stream));
   if (knob == NDT_TUNE_BATCH_SMALL_VARIANT) {
     b->use_small = value != 0;
-  } else if ((int)value != b->global_blocks) {       // one table slab per workgroup: re-allocate
-    unsigned char* slab = nullptr;
-    if (hipMalloc((void**)&slab, (size_t)value * ndt::BatchGlobal::kTabBytes) != hipSuccess) { (void)hipGetLastError(); return NDT_ERR_ALLOC; }
-    (void)hipFree(b->d_slab);
-    b->d_slab = slab;
-    b->global_blocks = (int)value;
+  } else {
+    if ((int)value != b->global_blocks) {            // one table slab per workgroup: re-allocate
+      unsigned char* slab = nullptr;
+      if (hipMalloc((void**)&slab, (size_t)value * ndt::BatchGlobal::kTabBytes) != hipSuccess) { (void)hipGetLastError(); return NDT_ERR_ALLOC; }
+      (void)hipFree(b->d_slab);
+      b->d_slab = slab;
+      b->global_blocks = (int)value;
+    }
+    b->global_pinned = true;                         // the caller's number stands: no growth on demand
   }
   return NDT_OK;
 }

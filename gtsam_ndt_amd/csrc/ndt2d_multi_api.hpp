@@ -1,11 +1,14 @@
 // C-ABI of the multi-device loop-closure context (included at the end of ndt2d_api.hip).
-// For a C++ host process that owns all GPUs of a node itself: one ndt2d_batch + one host thread
-// per device, pairs split into contiguous, work-balanced shards, results written straight into
-// the caller's array.  There is no exchange step between devices (pairs are independent), so
-// there is no collective here; the one-process-per-GPU deployment (torch.distributed / RCCL
-// gather) lives in gtsam_ndt_amd/dist.py and bench.py.
+// For a C++ host process that owns all GPUs of a node itself, in two forms:
+//   ndt2d_multi_align      host pointers: one ndt2d_batch + one host thread per device, pairs split into
+//                          contiguous, work-balanced shards (ndt2d_multi_plan), results written straight into
+//                          the caller's array - no collective, the host array is the meeting point;
+//   ndt2d_multi_align_dev  device-resident shards: every context aligns its shard on its own stream and the
+//                          result rows are exchanged with ONE grouped ncclAllGather (RCCL over xGMI) on those
+//                          streams - north_star's "final RCCL gather".  RCCL is loaded on first use (ndt_dyn.hpp).
+// Pairs are independent, so there is no exchange step during the alignments in either form.  The
+// one-process-per-GPU deployment (torch.distributed, backend "nccl" = RCCL) lives in gtsam_ndt_amd/dist.py / bench.py.
 #pragma once
-#include <rccl/rccl.h>
 
 #include <thread>
 #include <vector>
@@ -21,11 +24,63 @@ struct ndt2d_multi {
   size_t gather_cap = 0;              // rows per shard the buffers hold
 };
 
+namespace {
+
+// Result-row buffers of the gather: d_send[d] holds `rows` rows on device d, d_recv[d] holds rows * n_devices.
+// Grows to `want` rows by allocating EVERY new buffer first and swapping afterwards: a failed allocation leaves the
+// old buffers, and the capacity that describes them, exactly as they were (a later call that fits them still works).
+template <typename Ctx, typename Row>
+int32_t grow_gather_buffers(const std::vector<Ctx*>& ctx, std::vector<Row*>& d_send, std::vector<Row*>& d_recv,
+                            size_t* cap, size_t want) {
+  const int nd = static_cast<int>(ctx.size());
+  std::vector<Row*> ns(nd, nullptr), nr(nd, nullptr);
+  hipError_t err = hipSuccess;
+  for (int d = 0; d < nd && err == hipSuccess; ++d) {
+    err = hipSetDevice(ctx[d]->device);
+    if (err == hipSuccess) err = hipMalloc((void**)&ns[d], want * sizeof(Row));
+    if (err == hipSuccess) err = hipMalloc((void**)&nr[d], want * nd * sizeof(Row));
+  }
+  if (err == hipSuccess)
+    for (int d = 0; d < nd && err == hipSuccess; ++d) {      // the old buffers may still be in use by the last call
+      err = hipSetDevice(ctx[d]->device);
+      if (err == hipSuccess) err = hipStreamSynchronize(ctx[d]->stream);
+    }
+  if (err != hipSuccess) {
+    for (int d = 0; d < nd; ++d) {
+      (void)hipSetDevice(ctx[d]->device);
+      if (ns[d]) (void)hipFree(ns[d]);
+      if (nr[d]) (void)hipFree(nr[d]);
+    }
+    ::ndt::last_error() = std::string("gather buffers: ") + hipGetErrorString(err);
+    (void)hipGetLastError();
+    return err == hipErrorOutOfMemory ? NDT_ERR_ALLOC : NDT_ERR_HIP;
+  }
+  d_send.resize(nd, nullptr);
+  d_recv.resize(nd, nullptr);
+  for (int d = 0; d < nd; ++d) {
+    (void)hipSetDevice(ctx[d]->device);
+    if (d_send[d]) (void)hipFree(d_send[d]);
+    if (d_recv[d]) (void)hipFree(d_recv[d]);
+    d_send[d] = ns[d];
+    d_recv[d] = nr[d];
+  }
+  *cap = want;
+  return NDT_OK;
+}
+
+inline int32_t require_rccl() {
+  if (ndt::rccl().ok) return NDT_OK;
+  ndt::set_error("librccl.so.1 could not be loaded: the device-resident multi-GPU gather needs RCCL (everything else does not)");
+  return NDT_ERR_RCCL;
+}
+
+}  // namespace
+
 #define RCCL_TRY(expr)                                                                    \
   do {                                                                                    \
     const ncclResult_t _r = (expr);                                                       \
     if (_r != ncclSuccess) {                                                              \
-      ::ndt::last_error() = std::string(#expr) + ": " + ncclGetErrorString(_r);           \
+      ::ndt::last_error() = std::string(#expr) + ": " + ndt::rccl().GetErrorString(_r);           \
       return NDT_ERR_RCCL;                                                                \
     }                                                                                     \
   } while (0)
@@ -37,7 +92,7 @@ int32_t ndt2d_multi_destroy(ndt2d_multi* m) {
     if (d < m->d_send.size() && m->d_send[d]) (void)hipFree(m->d_send[d]);
     if (d < m->d_recv.size() && m->d_recv[d]) (void)hipFree(m->d_recv[d]);
   }
-  for (ncclComm_t c : m->comms) if (c) (void)ncclCommDestroy(c);
+  for (ncclComm_t c : m->comms) if (c && ndt::rccl().ok) (void)ndt::rccl().CommDestroy(c);
   for (ndt2d_batch* b : m->ctx) ndt2d_batch_destroy(b);
   delete m;
   return NDT_OK;
@@ -150,6 +205,7 @@ int32_t ndt2d_multi_align_dev(ndt2d_multi* m, const float* const* d_tx, const fl
     total += n_pairs[d];
   }
   if (total == 0) return NDT_ERR_INVALID_ARG;
+  { const int32_t rs = require_rccl(); if (rs != NDT_OK) return rs; }
   if (m->comms.empty()) {
     // one communicator per context, all in this process (ncclCommInitAll); a device listed twice
     // cannot take part in a collective with itself
@@ -160,27 +216,16 @@ int32_t ndt2d_multi_align_dev(ndt2d_multi* m, const float* const* d_tx, const fl
         if (devs[e] == devs[d]) { ndt::set_error("the RCCL gather needs distinct devices"); return NDT_ERR_INVALID_ARG; }
     }
     m->comms.assign(nd, nullptr);
-    const ncclResult_t r = ncclCommInitAll(m->comms.data(), nd, devs.data());
+    const ncclResult_t r = ndt::rccl().CommInitAll(m->comms.data(), nd, devs.data());
     if (r != ncclSuccess) {
       m->comms.clear();
-      ndt::last_error() = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
+      ndt::last_error() = std::string("ncclCommInitAll: ") + ndt::rccl().GetErrorString(r);
       return NDT_ERR_RCCL;
     }
   }
   if (longest > m->gather_cap) {
-    m->d_send.resize(nd, nullptr);
-    m->d_recv.resize(nd, nullptr);
-    const size_t want = longest + longest / 4 + 16;
-    for (int d = 0; d < nd; ++d) {
-      HIP_TRY(hipSetDevice(m->ctx[d]->device));
-      HIP_TRY(hipStreamSynchronize(m->ctx[d]->stream));
-      if (m->d_send[d]) (void)hipFree(m->d_send[d]);
-      if (m->d_recv[d]) (void)hipFree(m->d_recv[d]);
-      m->d_send[d] = m->d_recv[d] = nullptr;
-      HIP_TRY(hipMalloc((void**)&m->d_send[d], want * sizeof(ndt2d_result)));
-      HIP_TRY(hipMalloc((void**)&m->d_recv[d], want * nd * sizeof(ndt2d_result)));
-    }
-    m->gather_cap = want;
+    const int32_t gs = grow_gather_buffers(m->ctx, m->d_send, m->d_recv, &m->gather_cap, longest + longest / 4 + 16);
+    if (gs != NDT_OK) return gs;
   }
   // the gather moves `stride` rows per shard: the longest shard (padding rows are zero)
   const size_t stride = longest;
@@ -199,16 +244,16 @@ int32_t ndt2d_multi_align_dev(ndt2d_multi* m, const float* const* d_tx, const fl
   ndt::TraceRange range("ndt2d_multi: RCCL all-gather of the result rows");
   static_assert(sizeof(ndt2d_result) % sizeof(double) == 0, "rows travel as doubles");
   const size_t count = stride * (sizeof(ndt2d_result) / sizeof(double));
-  RCCL_TRY(ncclGroupStart());
+  RCCL_TRY(ndt::rccl().GroupStart());
   for (int d = 0; d < nd; ++d) {
-    const ncclResult_t r = ncclAllGather(m->d_send[d], m->d_recv[d], count, ncclDouble, m->comms[d], m->ctx[d]->stream);
+    const ncclResult_t r = ndt::rccl().AllGather(m->d_send[d], m->d_recv[d], count, ncclDouble, m->comms[d], m->ctx[d]->stream);
     if (r != ncclSuccess) {
-      (void)ncclGroupEnd();
-      ndt::last_error() = std::string("ncclAllGather: ") + ncclGetErrorString(r);
+      (void)ndt::rccl().GroupEnd();
+      ndt::last_error() = std::string("ncclAllGather: ") + ndt::rccl().GetErrorString(r);
       return NDT_ERR_RCCL;
     }
   }
-  RCCL_TRY(ncclGroupEnd());
+  RCCL_TRY(ndt::rccl().GroupEnd());
   if (results) {     // global pair order, padding dropped, from the first device's copy of the gather
     HIP_TRY(hipSetDevice(m->ctx[0]->device));
     size_t k = 0;

@@ -41,6 +41,7 @@ struct Batch3Args {
   unsigned char* gslab;      // tables of the global-memory variant: [global_blocks][kG3SlabBytes]
   int* fb_marks;             // [n_pairs], zeroed before the launches: k_batch3 sets 1 for a pair over the LDS carve,
                              // k_batch3_fallback processes exactly those (null: such pairs get NDT_ERR_CAPACITY at once)
+  unsigned int* fb_seen;     // pinned host word: k_batch3_fallback counts the pairs it processes here (BatchArgs::fb_seen)
   int n_pairs;
   int min_points;
   int fixed_iterations;
@@ -86,8 +87,9 @@ constexpr int kB3SlabBytes = kB3SlabRecC + kB3MaxSlots * 4;
 // 36-byte records gathered through L2.  It runs on the context's global_blocks workgroups and only on the pairs k_batch3 handed over.
 constexpr int kG3MaxCells = 1 << 20;                    // 1 048 576 voxels (e.g. 256 x 256 x 16)
 constexpr int kG3MaxSlots = 1 << 15;                    // occupied voxels (slot 0 is the dummy record)
-constexpr int kG3Blocks = 256;                          // default: one workgroup and one 7.9 MB slab per CU (2.0 GB per context);
-constexpr int kG3BlocksMax = 256;                       // NDT_TUNE_BATCH_GLOBAL_WORKGROUPS trades the memory against the variant's rate
+constexpr int kG3BlocksStart = 8;                       // a context starts with 8 workgroups / 7.9 MB slabs of the global-table variant (63 MB)
+constexpr int kG3Blocks = 256;                          // ... and grows to one per CU (2.0 GB) after the first call in which a pair needed it;
+constexpr int kG3BlocksMax = 256;                       // NDT_TUNE_BATCH_GLOBAL_WORKGROUPS pins the number instead
 constexpr size_t kG3Idx = 0;                                                  // u32 [MaxCells]
 constexpr size_t kG3SlotN = kG3Idx + (size_t)kG3MaxCells * 4;                 // u32 [MaxSlots]
 constexpr size_t kG3SlotKey = kG3SlotN + (size_t)kG3MaxSlots * 4;             // u32 [MaxSlots]
@@ -832,6 +834,7 @@ __global__ __launch_bounds__(kB3Threads) void k_batch3_fallback(Batch3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   for (int pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
     if (__builtin_amdgcn_readfirstlane(a.fb_marks[pair]) != 0) {              // uniform
+      if (threadIdx.x == 0 && a.fb_seen) __hip_atomic_fetch_add(a.fb_seen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       process_pair3<MODE, true>(a, pair, smem);
       __syncthreads();
       __threadfence();                                // the next pair rewrites this workgroup's slab

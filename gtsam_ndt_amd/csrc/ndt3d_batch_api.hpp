@@ -12,7 +12,9 @@ struct ndt3d_batch {
   unsigned int* d_queue = nullptr;
   unsigned char* d_slab = nullptr;    // [n_cu][kB3SlabBytes]
   unsigned char* d_gslab = nullptr;   // [global_blocks][kG3SlabBytes]: tables of the global-memory variant
-  int global_blocks = ndt::kG3Blocks; // its workgroups (NDT_TUNE_BATCH_GLOBAL_WORKGROUPS)
+  int global_blocks = ndt::kG3BlocksStart;   // its workgroups: a few to begin with, one per CU once a call has used them
+  bool global_pinned = false;         // ... unless NDT_TUNE_BATCH_GLOBAL_WORKGROUPS fixed the number (grow_global_slabs, ndt2d_batch_api.hpp)
+  unsigned int* h_fb_seen = nullptr;  // pinned host word the global-memory variant counts its pairs in
   int* d_fb = nullptr;                // [n_pairs]: marks of the pairs k_batch3 left to the global-memory variant
   size_t fb_cap = 0;
   // staging for the host-pointer entry point (one capacity per buffer)
@@ -42,8 +44,10 @@ int32_t batch3_launch(ndt3d_batch* b, const float* const d_t[3], const unsigned 
   a.init = d_init;
   a.out = reinterpret_cast<ndt::Result3Dev*>(d_out);
   a.queue = b->d_queue;
+  grow_global_slabs(b, &b->d_gslab, ndt::kG3SlabBytes, b->n_cu < ndt::kG3Blocks ? b->n_cu : ndt::kG3Blocks, st);
   a.slab = b->d_slab;
   a.gslab = b->d_gslab;
+  a.fb_seen = b->h_fb_seen;
   a.n_pairs = (int)n_pairs;
   const int blocks = (int)(n_pairs < (size_t)b->n_cu ? n_pairs : (size_t)b->n_cu);
   const int blocks_fb = (int)(n_pairs < (size_t)b->global_blocks ? n_pairs : (size_t)b->global_blocks);
@@ -99,6 +103,7 @@ int32_t ndt3d_batch_destroy(ndt3d_batch* b) {
   void* dev[] = {b->d_slab, b->d_gslab, b->d_fb, b->d_queue, b->d_t[0], b->d_t[1], b->d_t[2], b->d_s[0], b->d_s[1], b->d_s[2],
                  b->d_toff, b->d_soff, b->d_init, b->d_out};
   for (void* p : dev) if (p) (void)hipFree(p);
+  if (b->h_fb_seen) (void)hipHostFree(b->h_fb_seen);
   for (ndt3d_handle* f : b->fallback) ndt3d_destroy(f);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -130,6 +135,8 @@ int32_t ndt3d_batch_create_pyramid(const ndt3d_params* levels, int32_t n_levels,
   if (hipMalloc((void**)&b->d_queue, 16) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&b->d_slab, (size_t)b->n_cu * ndt::kB3SlabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&b->d_gslab, (size_t)b->global_blocks * ndt::kG3SlabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc((void**)&b->h_fb_seen, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  *b->h_fb_seen = 0;
   // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch3<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::kB3LdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
@@ -161,6 +168,7 @@ int32_t ndt3d_batch_set_tuning(ndt3d_batch* b, int32_t knob, int64_t value) {
     b->d_gslab = slab;
     b->global_blocks = (int)value;
   }
+  b->global_pinned = true;                             // the caller's number stands: no growth on demand
   return NDT_OK;
 }
 

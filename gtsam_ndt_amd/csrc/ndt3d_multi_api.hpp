@@ -2,7 +2,6 @@
 // one host thread per device; the device-resident form ends in ONE grouped ncclAllGather of the 408-byte result rows).
 // Included at the end of ndt2d_api.hip after ndt2d_multi_api.hpp (RCCL_TRY, ndt2d_multi_plan) and ndt3d_batch_api.hpp.
 #pragma once
-#include <rccl/rccl.h>
 
 #include <thread>
 #include <vector>
@@ -24,7 +23,7 @@ int32_t ndt3d_multi_destroy(ndt3d_multi* m) {
     if (d < m->d_send.size() && m->d_send[d]) (void)hipFree(m->d_send[d]);
     if (d < m->d_recv.size() && m->d_recv[d]) (void)hipFree(m->d_recv[d]);
   }
-  for (ncclComm_t c : m->comms) if (c) (void)ncclCommDestroy(c);
+  for (ncclComm_t c : m->comms) if (c && ndt::rccl().ok) (void)ndt::rccl().CommDestroy(c);
   for (ndt3d_batch* b : m->ctx) ndt3d_batch_destroy(b);
   delete m;
   return NDT_OK;
@@ -112,6 +111,7 @@ int32_t ndt3d_multi_align_dev(ndt3d_multi* m, const float* const* d_tx, const fl
     total += n_pairs[d];
   }
   if (total == 0) return NDT_ERR_INVALID_ARG;
+  { const int32_t rs = require_rccl(); if (rs != NDT_OK) return rs; }
   if (m->comms.empty()) {
     // one communicator per context, all in this process (ncclCommInitAll); a device listed twice
     // cannot take part in a collective with itself
@@ -122,27 +122,16 @@ int32_t ndt3d_multi_align_dev(ndt3d_multi* m, const float* const* d_tx, const fl
         if (devs[e] == devs[d]) { ndt::set_error("the RCCL gather needs distinct devices"); return NDT_ERR_INVALID_ARG; }
     }
     m->comms.assign(nd, nullptr);
-    const ncclResult_t r = ncclCommInitAll(m->comms.data(), nd, devs.data());
+    const ncclResult_t r = ndt::rccl().CommInitAll(m->comms.data(), nd, devs.data());
     if (r != ncclSuccess) {
       m->comms.clear();
-      ndt::last_error() = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
+      ndt::last_error() = std::string("ncclCommInitAll: ") + ndt::rccl().GetErrorString(r);
       return NDT_ERR_RCCL;
     }
   }
   if (longest > m->gather_cap) {
-    m->d_send.resize(nd, nullptr);
-    m->d_recv.resize(nd, nullptr);
-    const size_t want = longest + longest / 4 + 16;
-    for (int d = 0; d < nd; ++d) {
-      HIP_TRY(hipSetDevice(m->ctx[d]->device));
-      HIP_TRY(hipStreamSynchronize(m->ctx[d]->stream));
-      if (m->d_send[d]) (void)hipFree(m->d_send[d]);
-      if (m->d_recv[d]) (void)hipFree(m->d_recv[d]);
-      m->d_send[d] = m->d_recv[d] = nullptr;
-      HIP_TRY(hipMalloc((void**)&m->d_send[d], want * sizeof(ndt3d_result)));
-      HIP_TRY(hipMalloc((void**)&m->d_recv[d], want * nd * sizeof(ndt3d_result)));
-    }
-    m->gather_cap = want;
+    const int32_t gs = grow_gather_buffers(m->ctx, m->d_send, m->d_recv, &m->gather_cap, longest + longest / 4 + 16);
+    if (gs != NDT_OK) return gs;
   }
   // the gather moves `stride` rows per shard: the longest shard (padding rows are zero)
   const size_t stride = longest;
@@ -163,16 +152,16 @@ int32_t ndt3d_multi_align_dev(ndt3d_multi* m, const float* const* d_tx, const fl
   ndt::TraceRange range("ndt3d_multi: RCCL all-gather of the result rows");
   static_assert(sizeof(ndt3d_result) % sizeof(double) == 0, "rows travel as doubles");
   const size_t count = stride * (sizeof(ndt3d_result) / sizeof(double));
-  RCCL_TRY(ncclGroupStart());
+  RCCL_TRY(ndt::rccl().GroupStart());
   for (int d = 0; d < nd; ++d) {
-    const ncclResult_t r = ncclAllGather(m->d_send[d], m->d_recv[d], count, ncclDouble, m->comms[d], m->ctx[d]->stream);
+    const ncclResult_t r = ndt::rccl().AllGather(m->d_send[d], m->d_recv[d], count, ncclDouble, m->comms[d], m->ctx[d]->stream);
     if (r != ncclSuccess) {
-      (void)ncclGroupEnd();
-      ndt::last_error() = std::string("ncclAllGather: ") + ncclGetErrorString(r);
+      (void)ndt::rccl().GroupEnd();
+      ndt::last_error() = std::string("ncclAllGather: ") + ndt::rccl().GetErrorString(r);
       return NDT_ERR_RCCL;
     }
   }
-  RCCL_TRY(ncclGroupEnd());
+  RCCL_TRY(ndt::rccl().GroupEnd());
   if (results) {     // global pair order, padding dropped, from the first device's copy of the gather
     HIP_TRY(hipSetDevice(m->ctx[0]->device));
     size_t k = 0;

@@ -3,9 +3,10 @@
 // cache, and the host half of the converged-mode protocol (flags in pinned host memory).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <string>
+
+#include "ndt_dyn.hpp"
 
 namespace ndt {
 
@@ -20,10 +21,11 @@ inline void set_error(const char* msg) { last_error() = msg ? msg : ""; }
 namespace ndt {
 
 // roctx range over an API call (SURVEY.md section 5 "tracing"): shows up in rocprofv3 --marker-trace around
-// the kernels the call enqueues; a few nanoseconds when no profiler is attached.
+// the kernels the call enqueues; a few nanoseconds when no profiler is attached, nothing at all when the marker
+// library is not on the machine (ndt_dyn.hpp).
 struct TraceRange {
-  explicit TraceRange(const char* name) { (void)roctxRangePushA(name); }
-  ~TraceRange() { (void)roctxRangePop(); }
+  explicit TraceRange(const char* name) { if (roctx().RangePushA) (void)roctx().RangePushA(name); }
+  ~TraceRange() { if (roctx().RangePop) (void)roctx().RangePop(); }
   TraceRange(const TraceRange&) = delete;
   TraceRange& operator=(const TraceRange&) = delete;
 };

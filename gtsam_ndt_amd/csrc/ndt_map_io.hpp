@@ -5,6 +5,7 @@
 // re-finalised under other validity rules without the raw points.  A front end can drop a submap from device
 // memory and bring it back, or write it to disk, at 48 B (2D) / 80 B (3D) per cell.
 #pragma once
+#include <cmath>
 #include <cstring>
 
 static_assert(sizeof(ndt_map_header) == 104, "ndt_map_header is part of the ABI");
@@ -33,10 +34,56 @@ int32_t check_map_header(const ndt_map_header& m, size_t bytes, int dims, uint32
   if (m.magic != NDT_MAP_MAGIC || m.version != kMapVersion) { set_error("not an NDT map of this format version"); return NDT_ERR_INVALID_ARG; }
   if (m.dims != dims || m.cell_bytes != cell_bytes) { set_error("map has another dimension"); return NDT_ERR_INVALID_ARG; }
   if (m.width < 1 || m.height < 1 || m.depth < 1 || (m.ngrid != 1 && m.ngrid != 4)) { set_error("map header: extents"); return NDT_ERR_INVALID_ARG; }
+  if (dims == 2 && m.depth != 1) { set_error("map header: a 2D map has depth 1"); return NDT_ERR_INVALID_ARG; }
+  for (int q = 0; q < (m.ngrid == 4 ? 4 : 1); ++q)
+    for (int a = 0; a < dims; ++a)
+      if (!std::isfinite(m.origin[q][a])) { set_error("map header: origin is not finite"); return NDT_ERR_INVALID_ARG; }
   const double nc = (double)m.width * m.height * m.depth * m.ngrid;
   if (nc > (double)kMaxCells || (uint64_t)nc != m.n_cells) { set_error("map header: cell count"); return NDT_ERR_INVALID_ARG; }
   if (bytes < sizeof(ndt_map_header) + (size_t)m.n_cells * cell_bytes) { set_error("map buffer is shorter than its header says"); return NDT_ERR_INVALID_ARG; }
   if (m.cell_size != cell_size) { set_error("map was built with another cell_size than this handle's"); return NDT_ERR_INVALID_ARG; }
+  return NDT_OK;
+}
+
+// The per-cell blocks of a map are trusted by the finalise kernels (they are the library's own exact sums), so a
+// buffer that did not come from ndt*_save_map is checked on the host before it is uploaded: a cell of n points holds
+// fixed-point coordinates |U| <= 2^21 (checked against 2^22: the rounding of a boundary point), so
+// |sum U| <= n 2^22, 0 <= sum U^2 <= n 2^44, |sum UV| <= n 2^44, n <= 2^20 (the capacity the sums are exact for), and
+// the variance numerators n sum U^2 - (sum U)^2 are not negative (Cauchy-Schwarz; 128-bit exact).  Sums inside these
+// bounds finalise into finite records whatever else they are; outside them the map is refused.
+template <int DIM>
+bool cell_sums_plausible(unsigned int n, const long long* s, const long long* ss_diag, const long long* ss_off, int n_off) {
+  if (n > kMaxCellCount) return false;
+  const __int128 nn = n, lim1 = nn << 22, lim2 = nn << 44;
+  for (int a = 0; a < DIM; ++a) {
+    const __int128 su = s[a], suu = ss_diag[a];
+    if (su > lim1 || su < -lim1 || suu < 0 || suu > lim2) return false;
+    if (nn * suu - su * su < 0) return false;
+  }
+  for (int a = 0; a < n_off; ++a)
+    if ((__int128)ss_off[a] > lim2 || (__int128)ss_off[a] < -lim2) return false;
+  return true;
+}
+
+int32_t check_map_cells2(const void* cells, size_t n_cells) {
+  const char* p = static_cast<const char*>(cells);
+  for (size_t k = 0; k < n_cells; ++k, p += sizeof(CellAcc)) {
+    CellAcc c;
+    std::memcpy(&c, p, sizeof c);
+    const long long s[2] = {c.sx, c.sy}, dg[2] = {c.sxx, c.syy}, off[1] = {c.sxy};
+    if (!cell_sums_plausible<2>(c.n, s, dg, off, 1)) { set_error("map cell sums are not those of any point set (forged or damaged map)"); return NDT_ERR_INVALID_ARG; }
+  }
+  return NDT_OK;
+}
+
+int32_t check_map_cells3(const void* cells, size_t n_cells) {
+  const char* p = static_cast<const char*>(cells);
+  for (size_t k = 0; k < n_cells; ++k, p += sizeof(ndt::CellAcc3)) {
+    ndt::CellAcc3 c;
+    std::memcpy(&c, p, sizeof c);
+    const long long dg[3] = {c.ss[0], c.ss[3], c.ss[5]}, off[3] = {c.ss[1], c.ss[2], c.ss[4]};
+    if (!cell_sums_plausible<3>(c.n, c.s, dg, off, 3)) { set_error("map cell sums are not those of any point set (forged or damaged map)"); return NDT_ERR_INVALID_ARG; }
+  }
   return NDT_OK;
 }
 
@@ -79,6 +126,7 @@ int32_t ndt2d_load_map(ndt2d_handle* h, const void* buf, size_t bytes) {
   std::memcpy(&m, buf, sizeof m);
   { const int32_t cs = check_map_header(m, bytes, 2, (uint32_t)sizeof(CellAcc), h->prm.cell_size); if (cs != NDT_OK) return cs; }
   if (m.ngrid != (h->prm.overlap_grids == 4 ? 4 : 1)) { set_error("map and handle differ in overlap_grids"); return NDT_ERR_INVALID_ARG; }
+  { const int32_t cs = check_map_cells2((const char*)buf + sizeof m, (size_t)m.n_cells); if (cs != NDT_OK) return cs; }
   HIP_TRY(hipSetDevice(h->device));
   { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   h->has_target = false;
@@ -148,6 +196,7 @@ int32_t ndt3d_load_map(ndt3d_handle* h, const void* buf, size_t bytes) {
   std::memcpy(&m, buf, sizeof m);
   { const int32_t cs = check_map_header(m, bytes, 3, (uint32_t)sizeof(CellAcc3), h->prm.cell_size); if (cs != NDT_OK) return cs; }
   if (m.ngrid != 1) { set_error("a 3D map has one grid"); return NDT_ERR_INVALID_ARG; }
+  { const int32_t cs = check_map_cells3((const char*)buf + sizeof m, (size_t)m.n_cells); if (cs != NDT_OK) return cs; }
   HIP_TRY(hipSetDevice(h->device));
   { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
   h->has_target = false;

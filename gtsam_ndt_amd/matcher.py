@@ -96,11 +96,6 @@ class NdtMatcher2D:
         for k, v in (tuning or {}).items():
             self.set_tuning(k, v)
 
-    @property
-    def team_fallbacks(self) -> int:
-        """Calls whose team kernel gave up (GPU busy) and that ran through the launch-per-iteration path."""
-        return int(self._lib.ndt2d_team_fallback_count(self._h))
-
     def set_tuning(self, knob: str, value: int):
         L.check(self._lib.ndt2d_set_tuning(self._h, L.TUNING[knob], int(value)), "ndt2d_set_tuning")
 

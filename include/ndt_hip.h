@@ -245,11 +245,6 @@ int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const fl
  *   NDT_TUNE_SHORT_SCAN_KERNEL  1 (default): scans of <= 4096 points run the whole loop in one workgroup
  *   NDT_TUNE_CHUNK_LAUNCHES     converged mode: launches per graph replay, 2..128 (default 8)
  *   NDT_TUNE_BINNED_BUILD       1 (default): LDS-binned grid build; 0: scattered global atomics
- *   NDT_TUNE_TEAM_KERNEL        0 (default): one launch per iteration (k_iterate).  1: scans between 4097 points
- *                               and the wide threshold run the whole loop in one launch of 32-workgroup teams
- *                               that synchronise through one XCD's L2 (a start per team in multi-start calls).
- *                               Measured: 7.9 us per iteration against 4.6 for one start (32 CUs are too few
- *                               for 100k points), 16 % faster than the chain at 8 starts; DESIGN.md section 5.1d
  *   NDT_TUNE_SPLIT_FROM         multi-start / multi-scan calls of at least this many starts run two kernels per
  *                               iteration (one workgroup per start solves, then everybody evaluates) instead of
  *                               the fused kernel whose every workgroup repeats its starts' solves (default 12)
@@ -260,9 +255,12 @@ int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const fl
  *   NDT_TUNE_BATCH_SMALL_VARIANT (batch contexts) 1 (default): lidar-sized pairs run on the 256-thread
  *                               variant of the batch kernel first; 0: every pair on the 1024-thread one
  *   NDT_TUNE_BATCH_GLOBAL_WORKGROUPS (batch contexts, 2D and 3D) workgroups of the global-table variant, each with its own
- *                               table slab in device memory: 1..256, default 256 (0.95 GB per 2D context, 2.0 GB per 3D
- *                               context; 64 of them: a quarter of that, and a batch of over-capacity pairs about 2.8x slower).
- *                               Results do not depend on it */
+ *                               table slab in device memory (3.7 MB in 2D, 7.9 MB in 3D): 1..256.  Unset, a context starts
+ *                               with 8 (30 MB / 63 MB) and grows ONCE to one per CU (0.95 GB / 2.0 GB) at the start of the
+ *                               first call after one in which a pair needed that variant - a context whose pairs all fit
+ *                               on chip never pays for it; the call that first meets over-capacity pairs runs them on the
+ *                               8.  Setting the knob fixes the number (64: a batch of over-capacity pairs about 2.8x
+ *                               slower than on 256).  Results do not depend on it */
 enum {
   NDT_TUNE_LAUNCH_GRAPHS = 1,
   NDT_TUNE_WIDE_THRESHOLD = 2,
@@ -270,15 +268,12 @@ enum {
   NDT_TUNE_CHUNK_LAUNCHES = 4,
   NDT_TUNE_BINNED_BUILD = 5,
   NDT_TUNE_BATCH_SMALL_VARIANT = 6,
-  NDT_TUNE_TEAM_KERNEL = 7,
+  /* 7: was the one-XCD team kernel of round 2 (measured slower than the default, moved to tools/experiments) */
   NDT_TUNE_SPLIT_FROM = 8,
   NDT_TUNE_SINGLE_SYNC_BUILD = 9,
   NDT_TUNE_BATCH_GLOBAL_WORKGROUPS = 10
 };
 int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value);
-/* Diagnostic: calls on this handle whose team kernel could not assemble its 32-workgroup teams (the GPU
- * was busy with other work) and that were run through the launch-per-iteration path instead. */
-int64_t ndt2d_team_fallback_count(const ndt2d_handle* h);
 /* hipStream_t the handle enqueues on (as void*), for event timing by the caller */
 void* ndt2d_stream(ndt2d_handle* h);
 /* Stream ordering of the device-pointer entry points.  A handle enqueues on its own non-blocking
@@ -521,8 +516,8 @@ int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
  * variant with its last records in global memory).
  * Beyond that a pair gets status NDT_ERR_CAPACITY from the _dev entry point, and the host-pointer entry
  * point re-runs it through the single-pair path transparently.  Stream semantics as ndt2d_batch_align_dev.
- * A context holds about 2.1 GB of device memory (per-workgroup slabs of the build and of the global-memory variant;
- * NDT_TUNE_BATCH_GLOBAL_WORKGROUPS trades most of it against that variant's rate).
+ * A context holds about 0.2 GB of device memory (per-workgroup slabs of the build, 8 slabs of the global-memory variant)
+ * and 2.1 GB once a call has needed the global-memory variant (NDT_TUNE_BATCH_GLOBAL_WORKGROUPS).
  * Results do not depend on the order of a cloud's points beyond float32 summation order (the grid not at all);
  * the grid build is fastest on scans left in the order a 64-beam driver delivers them (all beams of one bearing, then
  * the next bearing): it walks a cloud in rows of 64 points and combines a lane's consecutive rows in registers. */

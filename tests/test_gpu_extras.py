@@ -180,11 +180,10 @@ def test_launch_chain_drivers_agree(gpu_lib, env):
     from gtsam_ndt_amd.matcher import NdtMatcher2D
     d = synth.make_pair(2, n_tgt=30000, n_src=30000)
     sx, sy = torch.from_numpy(d["sx"]).cuda(), torch.from_numpy(d["sy"]).cuda()
-    # (the launch-per-iteration path on both sides: the team kernel sums in another order)
-    with NdtMatcher2D(tuning={"team_kernel": 0}) as m:
+    with NdtMatcher2D() as m:
         m.set_target(d["tx"], d["ty"])
         ref = m.align(sx, sy, d["init"])
-    with NdtMatcher2D(tuning=dict(env, team_kernel=0)) as m:
+    with NdtMatcher2D(tuning=dict(env)) as m:
         m.set_target(d["tx"], d["ty"])
         for src in ((sx, sy), (d["sx"], d["sy"])):
             for _ in range(3):
@@ -206,7 +205,7 @@ def test_wide_workgroups_for_large_scans_equal_the_narrow_ones(gpu_lib):
     tx, ty, sx, sy = (torch.from_numpy(d[k]).cuda() for k in ("tx", "ty", "sx", "sy"))
     res = {}
     for off in ("0", "1"):
-        with NdtMatcher2D(tuning={"wide_threshold": 0, "team_kernel": 0} if off == "1" else {"team_kernel": 0}) as m:
+        with NdtMatcher2D(tuning={"wide_threshold": 0} if off == "1" else {}) as m:
             m.set_target(tx, ty)
             res[off] = (m.align(sx, sy, d["init"]), m.align(sx, sy, d["init"]))
     for off in ("0", "1"):

@@ -134,3 +134,64 @@ def test_2d_load_keeps_the_outer_ring_empty(gpu_lib):
         for x, y in zip(a.grid(), b.grid()):
             assert np.array_equal(x, y)                                # the ring is empty again, nothing else changed
         assert b.grid_info().n_valid == a.grid_info().n_valid
+
+
+def test_forged_maps_are_refused(gpu_lib):
+    """A buffer that did not come from ndt*_save_map: a 2D header with depth > 1, a non-finite origin, a
+    cell count beyond the capacity the sums are exact for, sums no point set can have (negative sum of squares, a
+    variance numerator below zero, coordinates outside the cell) - each is refused with NDT_ERR_INVALID_ARG before
+    anything is uploaded, and the handle keeps working afterwards; the untouched blob still loads."""
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtMatcher2D, NdtMatcher3D
+    d = synth.make_pair(1)
+    d3 = synth3d.make_pair3d(n_elev=16, n_azim=256)
+
+    def refused(h, buf):
+        with pytest.raises(L.NdtError) as e:
+            h.load_map(buf)
+        assert e.value.code == L.NDT_ERR_INVALID_ARG
+
+    with NdtMatcher2D() as a, NdtMatcher2D() as b:
+        a.set_target(d["tx"], d["ty"])
+        blob = a.save_map().copy()
+        hdr = L.MapHeader.from_buffer_copy(blob[:104].tobytes())
+        off = {name: getattr(L.MapHeader, name).offset for name, _ in L.MapHeader._fields_}
+
+        def with_header(**kw):
+            out = blob.copy()
+            h2 = L.MapHeader.from_buffer_copy(blob[:104].tobytes())
+            for k, v in kw.items():
+                setattr(h2, k, v)
+            out[:104] = np.frombuffer(bytes(h2), dtype=np.uint8)
+            return out
+
+        # depth 2 with the cell count to match (and a buffer long enough): still not a 2D map
+        deep = np.concatenate([with_header(depth=2, n_cells=2 * hdr.n_cells), blob[104:]])
+        refused(b, deep)
+        for bad_value in (np.float32(np.nan), np.float32(np.inf)):
+            nanmap = blob.copy()
+            nanmap[off["origin"]:off["origin"] + 4] = np.frombuffer(bad_value.tobytes(), dtype=np.uint8)
+            refused(b, nanmap)
+        cells_of = lambda buf: buf[104:].view(np.int64).reshape(-1, 6)       # sx sy sxx sxy syy (n | pad)
+        k = int(np.argmax(cells_of(blob)[:, 5] & 0xFFFFFFFF))
+        for col, value in ((5, (1 << 20) + 1), (2, -5), (0, 1 << 62), (3, -(1 << 62))):
+            forged = blob.copy()
+            cells_of(forged)[k, col] = value
+            refused(b, forged)
+        forged = blob.copy()                                                   # n * sxx < sx^2: no such point set
+        c = cells_of(forged)[k]
+        c[2] = (int(c[0]) * int(c[0])) // int(c[5] & 0xFFFFFFFF) - 10
+        refused(b, forged)
+        b.load_map(blob)                                                       # the real thing still loads ...
+        assert a.align(d["sx"], d["sy"], d["init"]).pose == b.align(d["sx"], d["sy"], d["init"]).pose
+    with NdtMatcher3D() as a3, NdtMatcher3D() as b3:
+        a3.set_target(d3["tx"], d3["ty"], d3["tz"])
+        blob3 = a3.save_map().copy()
+        cells3 = lambda buf: buf[104:].view(np.int64).reshape(-1, 10)          # s[3] ss[6] (n | pad)
+        k = int(np.argmax(cells3(blob3)[:, 9] & 0xFFFFFFFF))
+        for col, value in ((9, (1 << 20) + 7), (3, -1), (1, -(1 << 61)), (7, 1 << 62)):
+            forged = blob3.copy()
+            cells3(forged)[k, col] = value
+            refused(b3, forged)
+        b3.load_map(blob3)
+        assert a3.align(d3["sx"], d3["sy"], d3["sz"], d3["init"]).pose == b3.align(d3["sx"], d3["sy"], d3["sz"], d3["init"]).pose

@@ -211,7 +211,7 @@ def test_3d_kernels_reduce_to_the_2d_kernels_on_planar_data(gpu_lib):
     d = synth.make_pair(2, n_tgt=30000, n_src=20000)
     z, zs = np.zeros_like(d["tx"]), np.zeros_like(d["sx"])
     idx, other = [0, 1, 5], [2, 3, 4]
-    with NdtMatcher2D(min_points=5, tuning={"team_kernel": 0}) as m2, \
+    with NdtMatcher2D(min_points=5) as m2, \
             NdtMatcher3D(cell_size=0.5, min_points=5, step_max_trans=0.5, min_hits=3) as m3:
         i2 = m2.set_target(d["tx"], d["ty"])
         i3 = m3.set_target(d["tx"], d["ty"], z)

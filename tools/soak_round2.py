@@ -1,5 +1,5 @@
 """Soak of the round-2 host protocols: converged-mode multi-start chains (flags raised one launch after the
-last start finishes), the opt-in team kernel, 3D async calls and the batch kernel's capacity hand-over,
+last start finishes), 3D async calls and the batch kernel's capacity hand-over,
 many calls each with varying shapes; every call is checked against a reference computed once."""
 import sys, time
 sys.path.insert(0, ".")
@@ -13,8 +13,8 @@ d = synth.make_pair(2, n_tgt=60_000, n_src=30_000)
 sx, sy = torch.from_numpy(d["sx"]).cuda(), torch.from_numpy(d["sy"]).cuda()
 pool = [(d["init"][0] + 0.01 * k, d["init"][1] - 0.007 * k, 0.0005 * k) for k in range(64)]
 t0 = time.time()
-for team in (0, 1):
-    with NdtMatcher2D(tuning={"team_kernel": team}) as m:
+for team in (0,):
+    with NdtMatcher2D() as m:
         m.set_target(d["tx"], d["ty"])
         ref = {k: m.align(sx, sy, pool[k]) for k in range(64)}
         bad = 0
@@ -30,7 +30,7 @@ for team in (0, 1):
                 r = ref[k]
                 if not (g.pose == r.pose and g.iterations == r.iterations and g.status == r.status):
                     bad += 1
-        print(f"team={team}: {N} multi-start calls, mismatches {bad}, fallbacks {m.team_fallbacks}, {time.time()-t0:.1f}s", flush=True)
+        print(f"team={team}: {N} multi-start calls, mismatches {bad}, {time.time()-t0:.1f}s", flush=True)
         assert bad == 0
 d3 = synth3d.make_pair3d(n_azim=512)
 s3 = [torch.from_numpy(d3[k]).cuda() for k in ("sx", "sy", "sz")]
