@@ -6,8 +6,9 @@ form at 1e-9; parity unpinned: the reference holds no code).  VERDICT r2 weak #2
 
 The second test settles VERDICT r2 weak #3: the bench's 3D batch leg reports a few pairs that end more than 1 cm from
 their generating pose after the 30 fixed iterations.  Those same scenes (deterministic seeds) are aligned by the oracle
-with the same 30 fixed iterations: kernel and oracle agree to 1e-4 on them, so the strays are where this score's
-iteration goes from those starts (a slow basin), not a defect of the kernel."""
+with the same 30 fixed iterations and in converged mode: the oracle is as far from truth after 30 iterations as the kernel
+(both still moving: the two trajectories agree to 1e-3 in flight), and where the iteration ENDS the kernel is within 1e-4
+of the oracle - the strays are where this score's iteration goes from those starts (a slow basin), not a kernel defect."""
 import numpy as np
 import pytest
 
@@ -77,7 +78,7 @@ def test_converged_pose_of_the_full_config5_pair_through_every_3d_driver(gpu_lib
 def test_the_bench_legs_stray_scenes_are_the_scores_basin_not_a_kernel_defect(gpu_lib, cport):
     """bench.py's batch_3d leg: 256 distinct scenes (clutter seed 5 + k, noise seeds 1000 + 2k / 1001 + 2k, relative pose
     from default_rng(5)), fixed 30 iterations.  Find the pairs that end > 1 cm from truth, align exactly those (and a few
-    that do not stray) with the oracle under the same 30 fixed iterations: kernel == oracle to 1e-4 on every one."""
+    that do not stray) with the oracle, under the same 30 fixed iterations and to convergence."""
     import torch
     from gtsam_ndt_amd import synth_dev
     from gtsam_ndt_amd.matcher import NdtBatch3D, NdtMatcher3D
@@ -102,7 +103,12 @@ def test_the_bench_legs_stray_scenes_are_the_scores_basin_not_a_kernel_defect(gp
     strays = [int(k) for k in np.nonzero(errs > 1e-2)[0]]
     sample = strays + [k for k in (0, 64, 128, 192) if k not in strays]
     prm = o3.Ndt3Params(fixed_iterations=30)
-    worst = 0.0
+    worst_fixed = worst_conv = 0.0
+    # converged mode on the same scenes: where each pair's iteration ENDS is the contract (1e-4), and the strays end
+    # where the oracle's ends
+    with NdtBatch3D() as b:
+        conv = b.decode(b.align_dev(t, off, s, off, init))
+    report = []
     with NdtMatcher3D(fixed_iterations=30) as m:
         for k in sample:
             sl = slice(k * npts, (k + 1) * npts)
@@ -110,15 +116,26 @@ def test_the_bench_legs_stray_scenes_are_the_scores_basin_not_a_kernel_defect(gp
             sh = [c[sl].cpu().numpy() for c in s]
             cg = cport.CGrid3(*th, prm)
             ref = cg.align(*sh, (0.0,) * 6, threads=8)
+            ref_conv = cg.align(*sh, (0.0,) * 6, threads=8, fixed_iterations=0)
             cg.close()
-            assert ref["iterations"] == 30
-            ok, e = _close(res[k].pose, ref["pose"])
-            assert ok, (k, e, errs[k])                             # batch kernel vs oracle on this scene
+            assert ref["iterations"] == 30 and ref_conv["status"] == 0
             m.set_target(*th)
             r1 = m.align(*(c[sl].contiguous() for c in s), (0.0,) * 6)
-            ok1, e1 = _close(r1.pose, ref["pose"])
-            assert ok1, (k, e1)                                    # single-pair kernel vs oracle on this scene
-            worst = max(worst, float(e.max()), float(e1.max()))
-            if k in strays:                                        # the oracle strays as far: it is the basin
+            e = np.abs(np.array(res[k].pose) - np.array(ref["pose"]))
+            e1 = np.abs(np.array(r1.pose) - np.array(ref["pose"]))
+            ec = np.abs(np.array(conv[k].pose) - np.array(ref_conv["pose"]))
+            report.append((k, float(errs[k]), float(e.max()), float(e1.max()), float(ec.max()), conv[k].iterations, ref_conv["iterations"]))
+            # fixed 30 iterations: a pair that is not a stray has arrived (1e-4); a stray is still moving centimetres per
+            # ten iterations, and two float32 / float64 trajectories in flight are compared at 1e-3
+            tol = 1e-3 if k in strays else 1e-4
+            assert e.max() < tol and e1.max() < tol, (k, e, e1, errs[k])
+            assert conv[k].status == 0 and ec[:3].max() < 1e-4 and ec[3:].max() < 1e-4, (k, ec)     # where the iteration ends
+            assert abs(conv[k].iterations - ref_conv["iterations"]) <= max(3, ref_conv["iterations"] // 10), (k, conv[k].iterations, ref_conv["iterations"])
+            worst_fixed = max(worst_fixed, float(e.max()), float(e1.max()))
+            worst_conv = max(worst_conv, float(ec.max()))
+            if k in strays:                                        # the oracle is as far from truth after 30 iterations: the basin
                 assert np.abs(np.array(ref["pose"]) - np.array(poses[k])).max() > 0.5e-2
-    print(f"strays {strays} (max err vs truth {errs.max():.3f} m); kernel vs oracle on {len(sample)} scenes: max {worst:.2e}")
+    for row in report:
+        print("pair %3d: err vs truth after 30 its %.4f m | batch vs oracle (30 its) %.2e | single vs oracle (30 its) %.2e | "
+              "converged batch vs converged oracle %.2e (%d / %d iterations)" % row)
+    print(f"strays {strays}; kernel vs oracle on {len(sample)} scenes: fixed-30 max {worst_fixed:.2e}, converged max {worst_conv:.2e}")
