@@ -14,6 +14,7 @@
 #include "ndt2d_kernels.hpp"
 #include "ndt2d_small.hpp"
 #include "ndt2d_build.hpp"
+#include "ndt2d_build_sorted.hpp"
 #include "ndt2d_multi_start.hpp"
 #include "ndt_host.hpp"
 
@@ -34,7 +35,7 @@ struct ndt2d_handle {
   unsigned int* d_bounds = nullptr;        // [4]
   int* d_counters = nullptr;               // [2] valid cells, overflowed cells
   unsigned long long* d_outside = nullptr; // [1]
-  void* h_small = nullptr;                 // pinned scratch (64 B)
+  void* h_small = nullptr;                 // pinned scratch (256 B: counter shards at 0, the outside count at 128)
   // staging for host-pointer entry points
   float* d_tx = nullptr; float* d_ty = nullptr; size_t tcap = 0;
   float* d_sx = nullptr; float* d_sy = nullptr; size_t scap = 0;
@@ -58,6 +59,10 @@ struct ndt2d_handle {
   bool static_on_device = false;           // d_static holds this handle's parameters (some upload_static has run)
   bool one_round_trip = true;              // NDT_TUNE_SINGLE_SYNC_BUILD
   bool use_binned_build = true;
+  int build_variant = 1;                   // NDT_TUNE_BINNED_BUILD: 1 chunk-sorted build (ndt2d_build_sorted.hpp), 2 the round-1 binned build
+  float2* d_bxy = nullptr; size_t bxy_cap = 0;             // chunk-sorted copy of the cloud ([chunks][chunk points])
+  unsigned int* d_table = nullptr; size_t table_cap = 0;   // [tiles][chunks]: start | len << 16 of every run
+  float4* d_parts = nullptr;               // [kBoundsParts]: per-workgroup partial bounding boxes
   // hipGraph of the launch chain (launch-bound inner loop: one replay instead of K+1 launches)
   ChainGraphCache graphs;
   hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
@@ -135,29 +140,122 @@ int32_t upload_static(ndt2d_handle* h);
 
 int32_t finalise_grid(ndt2d_handle* h) {
   const size_t ncell = (size_t)h->grid.W * h->grid.H * h->grid.ngrid;
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, ndt::kCountInts * sizeof(int), h->stream));
   hipLaunchKernelGGL(k_finalise, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      h->stream, h->grid, h->prm.min_points, h->prm.eig_ratio, h->d_counters);
   HIP_TRY(hipGetLastError());
   int* hc = (int*)h->h_small;
-  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, ndt::kCountInts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->n_valid = hc[0];
-  if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+  int n_valid_sum = 0, n_over_sum = 0;
+  sum_count_shards(hc, &n_valid_sum, &n_over_sum);
+  h->n_valid = n_valid_sum;
+  if (n_over_sum > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
   return NDT_OK;
+}
+
+// ---- chunk-sorted build (ndt2d_build_sorted.hpp): host side -------------------------------------------------------
+struct SortPlan { int P = 0, chunk = 0, nchunks = 0; };
+
+// Points per thread of k_chunk_sort (chunk = 256 P points): small clouds take small chunks so that more CUs share
+// the work (a 100k-point scan: 98 chunks of 1024), large ones the longest runs.  false: the table would exceed its
+// bounds (tiles x chunks <= 2^20, chunks <= 4096) - the caller takes the round-1 path.
+bool plan_sorted(size_t n, long long ntile, SortPlan* sp) {
+  int P = n <= 131072 ? 4 : (n <= 524288 ? 8 : 16);
+  for (;; P *= 2) {
+    const size_t C = (size_t)kSortThreads * P, nch = (n + C - 1) / C;
+    if (nch <= (size_t)kSortMaxChunks && nch * (size_t)ntile <= kSortMaxTable) { sp->P = P; sp->chunk = (int)C; sp->nchunks = (int)nch; return true; }
+    if (P == 16) return false;
+  }
+}
+
+int32_t ensure_sorted_buffers(ndt2d_handle* h, const SortPlan& sp, size_t ntile) {
+  const size_t need_pts = (size_t)sp.nchunks * sp.chunk, need_tab = ntile * (size_t)sp.nchunks;
+  if (need_pts > h->bxy_cap) {
+    if (h->d_bxy) (void)hipFree(h->d_bxy);
+    h->d_bxy = nullptr; h->bxy_cap = 0;
+    const size_t want = need_pts + need_pts / 4 + 4096;
+    HIP_TRY(hipMalloc((void**)&h->d_bxy, want * sizeof(float2)));
+    h->bxy_cap = want;
+  }
+  if (need_tab > h->table_cap) {
+    if (h->d_table) (void)hipFree(h->d_table);
+    h->d_table = nullptr; h->table_cap = 0;
+    const size_t want = need_tab + need_tab / 4 + 1024;
+    HIP_TRY(hipMalloc((void**)&h->d_table, want * sizeof(unsigned int)));
+    h->table_cap = want;
+  }
+  return NDT_OK;
+}
+
+void launch_chunk_sort(ndt2d_handle* h, const SortPlan& sp, const float* d_x, const float* d_y, size_t n, const BinGeom& bg,
+                       int hist_tiles, const MoveArgs& mv, unsigned long long* d_outside, const GeomArgs& ga) {
+  const size_t lds = (size_t)sp.chunk * sizeof(float2) + (size_t)hist_tiles * sizeof(unsigned int);
+#define NDT_SORT(PP) hipLaunchKernelGGL((k_chunk_sort<PP>), dim3((unsigned)sp.nchunks), dim3(kSortThreads), lds, h->stream, d_x, d_y, n, \
+                                        bg, sp.nchunks, mv, h->d_bxy, h->d_table, d_outside, ga)
+  if (sp.P == 4) NDT_SORT(4); else if (sp.P == 8) NDT_SORT(8); else NDT_SORT(16);
+#undef NDT_SORT
+}
+
+// the bounding box of a cloud as per-workgroup partials in h->d_parts; returns the number of partials
+int launch_bounds_parts(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n, GeomDev* zero = nullptr) {
+  int nb = stream_blocks(n);
+  if (nb > kBoundsParts) nb = kBoundsParts;
+  const bool vec = (((uintptr_t)d_x | (uintptr_t)d_y) & 15u) == 0;
+  if (vec) hipLaunchKernelGGL((k_bounds_parts<true>), dim3(nb), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_parts, zero);
+  else hipLaunchKernelGGL((k_bounds_parts<false>), dim3(nb), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_parts, zero);
+  return nb;
 }
 
 // a2 + a3 for n points: binned LDS build when the tile histogram fits in LDS (always, below
 // ~2.9 km x 2.9 km at 0.5 m cells), else scattered global atomics + k_finalise.  merge = add to
 // the cached sums (incremental submap update) instead of starting from zero.
 int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* d_y, size_t n, bool merge,
-                                unsigned long long* h_outside) {
+                                unsigned long long* h_outside, const MoveArgs* move = nullptr) {
   TraceRange range(merge ? "ndt2d: submap update (moments + finalise)" : "ndt2d: moments + finalise");
   GridDev& g = h->grid;
   const size_t ncell1 = (size_t)g.W * g.H, ncell = ncell1 * g.ngrid;
   const int ntx = (g.W + kTile - 1) >> kTileShift, nty = (g.H + kTile - 1) >> kTileShift;
   const long long ntile_ll = (long long)ntx * nty;
   HIP_TRY(hipMemsetAsync(h->d_outside, 0, sizeof(unsigned long long), h->stream));
+  SortPlan sp;
+  if (h->use_binned_build && h->build_variant == 1 && ntile_ll <= kBinMaxTiles && plan_sorted(n, ntile_ll, &sp)) {
+    // chunk-sorted build: sort every chunk of the cloud by tile, then one workgroup per tile gathers its runs
+    const int ntile = (int)ntile_ll;
+    { const int32_t es = ensure_sorted_buffers(h, sp, (size_t)ntile); if (es != NDT_OK) return es; }
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, ndt::kCountInts * sizeof(int), h->stream));
+    const MoveArgs none{1.f, 0.f, 0.f, 0.f, 0};
+    for (int q = 0; q < g.ngrid; ++q) {
+      BinGeom bg{g.gx[q], g.gy[q], g.inv_c, g.W, g.H, ntx, ntile};
+      launch_chunk_sort(h, sp, d_x, d_y, n, bg, ntile, move ? *move : none, q == 0 ? h->d_outside : (unsigned long long*)nullptr,
+                        GeomArgs{});
+      hipLaunchKernelGGL(k_tile_gather, dim3(ntile), dim3(kGatherThreads), 0, h->stream, (const float2*)h->d_bxy, (const unsigned int*)h->d_table,
+                         sp.nchunks, sp.chunk, g, q, ntx, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, h->d_counters,
+                         (const GeomDev*)nullptr, (const GridDev*)nullptr);
+      HIP_TRY(hipGetLastError());
+    }
+    h->last_ntile = ntile;
+    int* hc = (int*)h->h_small;
+    unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 128);
+    HIP_TRY(hipMemcpyAsync(hc, h->d_counters, ndt::kCountInts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int n_valid_sum = 0, n_over_sum = 0;
+    sum_count_shards(hc, &n_valid_sum, &n_over_sum);
+    h->n_valid = merge ? h->n_valid + n_valid_sum : n_valid_sum;       // merge: the gather kernel counts the change, tile by touched tile
+    if (h_outside) *h_outside = *ho;
+    if (n_over_sum > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+    return NDT_OK;
+  }
+  // the other paths take the points as they are: move them into the map frame first
+  if (move && move->use) {
+    const int32_t st = ensure_points(&h->d_tx, &h->d_ty, &h->tcap, n);
+    if (st != NDT_OK) return st;
+    hipLaunchKernelGGL(k_transform_points, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, d_x, d_y,
+                       n, move->cs, move->sn, move->tx, move->ty, h->d_tx, h->d_ty);
+    HIP_TRY(hipGetLastError());
+    d_x = h->d_tx; d_y = h->d_ty;
+  }
   if (h->use_binned_build && ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull) {
     const int ntile = (int)ntile_ll;
     if (n > h->bcap) {
@@ -179,7 +277,7 @@ int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* 
     unsigned int* d_total = h->d_tiles;
     unsigned int* d_start = h->d_tiles + ntile;
     unsigned int* d_cursor = h->d_tiles + 2 * ntile + 1;
-    HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, ndt::kCountInts * sizeof(int), h->stream));
     const size_t chunk = (size_t)kBinThreads * kBinPerThread;
     size_t nb = (n + chunk - 1) / chunk;
     if (nb > 1024) nb = 1024;
@@ -198,20 +296,22 @@ int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* 
     }
     h->last_ntile = ntile;
     int* hc = (int*)h->h_small;
-    unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 32);
-    HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 128);
+    HIP_TRY(hipMemcpyAsync(hc, h->d_counters, ndt::kCountInts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->n_valid = hc[0];
+    int n_valid_sum = 0, n_over_sum = 0;
+    sum_count_shards(hc, &n_valid_sum, &n_over_sum);
+    h->n_valid = n_valid_sum;
     if (h_outside) *h_outside = *ho;
-    if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+    if (n_over_sum > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
     return NDT_OK;
   }
   // fallback: scattered global atomics
   if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc), h->stream));
   hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, g, h->d_outside);
   HIP_TRY(hipGetLastError());
-  unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 32);
+  unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 128);
   HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   const int32_t st = finalise_grid(h);
   if (h_outside) *h_outside = *ho;
@@ -274,6 +374,26 @@ int32_t set_target_single_sync(ndt2d_handle* h, const float* d_x, const float* d
   long long tb = 2ll * h->last_ntile + 16;
   if (tb > kBinMaxTiles) tb = kBinMaxTiles;
   const int tile_bound = (int)tb;
+  if (!h->d_geom) {
+    HIP_TRY(hipMalloc((void**)&h->d_geom, sizeof(GeomDev)));
+    HIP_TRY(hipHostMalloc((void**)&h->h_geom, sizeof(GeomDev), hipHostMallocDefault));
+  }
+  GeomDev* dg = h->d_geom;
+  SortPlan sp;
+  if (h->build_variant == 1 && plan_sorted(n, tile_bound, &sp)) {
+    // chunk-sorted build: bounds partials -> chunk sort (reduce + geometry in its prologue) -> one workgroup per tile
+    { const int32_t es = ensure_sorted_buffers(h, sp, (size_t)tile_bound); if (es != NDT_OK) return es; }
+    const int nparts = launch_bounds_parts(h, d_x, d_y, n, dg);
+    const BinGeom none{};
+    const MoveArgs stay{1.f, 0.f, 0.f, 0.f, 0};
+    GeomArgs ga{};
+    ga.parts = h->d_parts; ga.nparts = nparts; ga.tile_bound = tile_bound; ga.cell = h->prm.cell_size;
+    ga.cell_capacity = (unsigned long long)h->cell_capacity; ga.grid = &h->d_static->grid; ga.out = dg;
+    launch_chunk_sort(h, sp, d_x, d_y, n, none, tile_bound, stay, &dg->n_outside, ga);
+    hipLaunchKernelGGL(k_tile_gather, dim3(tile_bound), dim3(kGatherThreads), 0, h->stream, (const float2*)h->d_bxy,
+                       (const unsigned int*)h->d_table, sp.nchunks, sp.chunk, h->grid, 0, 0, 0, h->prm.min_points, h->prm.eig_ratio,
+                       &dg->counters[0], (const GeomDev*)dg, (const GridDev*)&h->d_static->grid);
+  } else {
   if (n > h->bcap) {
     if (h->d_bx) (void)hipFree(h->d_bx);
     if (h->d_by) (void)hipFree(h->d_by);
@@ -290,15 +410,10 @@ int32_t set_target_single_sync(ndt2d_handle* h, const float* d_x, const float* d
     HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
     h->tile_cap = tneed;
   }
-  if (!h->d_geom) {
-    HIP_TRY(hipMalloc((void**)&h->d_geom, sizeof(GeomDev)));
-    HIP_TRY(hipHostMalloc((void**)&h->h_geom, sizeof(GeomDev), hipHostMallocDefault));
-  }
   // tile tables laid out for the bound: total[tb] | start[tb+1] | cursor[tb]
   unsigned int* d_total = h->d_tiles;
   unsigned int* d_start = h->d_tiles + tile_bound;
   unsigned int* d_cursor = h->d_tiles + 2 * tile_bound + 1;
-  GeomDev* dg = h->d_geom;
   hipLaunchKernelGGL(k_build_init, dim3(1), dim3(1024), 0, h->stream, dg, d_total, tile_bound);
   hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > kBoundsBlocks ? kBoundsBlocks : stream_blocks(n)), dim3(kBlock), 0, h->stream,
                      d_x, d_y, n, &dg->bounds[0]);
@@ -316,6 +431,7 @@ int32_t set_target_single_sync(ndt2d_handle* h, const float* d_x, const float* d
   hipLaunchKernelGGL(k_tile_accumulate, dim3(tile_bound), dim3(kBinThreads), 0, h->stream, h->d_bx, h->d_by, d_start, h->grid, 0, 0,
                      0, h->prm.min_points, h->prm.eig_ratio, &dg->counters[0], (const GeomDev*)dg,
                      (const GridDev*)&h->d_static->grid);
+  }
   HIP_TRY(hipGetLastError());
   GeomDev* hg = h->h_geom;
   HIP_TRY(hipMemcpyAsync(hg, dg, sizeof(GeomDev), hipMemcpyDeviceToHost, h->stream));
@@ -331,8 +447,10 @@ int32_t set_target_single_sync(ndt2d_handle* h, const float* d_x, const float* d
   if (h->grid.W != hg->bin.W || h->grid.H != hg->bin.H || h->grid.ox != hg->bin.ox || h->grid.oy != hg->bin.oy) return NDT_OK;
   h->h_static->grid = h->grid;                           // what d_static holds already
   h->last_ntile = hg->bin.ntile;
-  h->n_valid = hc[0];
-  if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+  int n_valid_sum = 0, n_over_sum = 0;
+  sum_count_shards(hc, &n_valid_sum, &n_over_sum);
+  h->n_valid = n_valid_sum;
+  if (n_over_sum > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
   *done = true;
   return NDT_OK;
 }
@@ -356,8 +474,10 @@ int32_t set_target_impl(ndt2d_handle* h, const float* d_x, const float* d_y, siz
     std::memcpy(hb, fast_bounds, sizeof(init));
   } else {
     std::memcpy(hb, init, sizeof(init));
-    HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, sizeof(init), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_bounds, dim3(stream_blocks(n) > kBoundsBlocks ? kBoundsBlocks : stream_blocks(n)), dim3(kBlock), 0, h->stream, d_x, d_y, n, h->d_bounds);
+    {
+      const int nparts = launch_bounds_parts(h, d_x, d_y, n);
+      hipLaunchKernelGGL(k_bounds_reduce, dim3(1), dim3(64), 0, h->stream, (const float4*)h->d_parts, nparts, h->d_bounds);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, sizeof(init), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -696,7 +816,15 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipSetDevice(device_id) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipMalloc((void**)&h->d_bounds, 4 * sizeof(unsigned int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
-  if (hipMalloc((void**)&h->d_counters, 2 * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_counters, ndt::kCountInts * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_parts, kBoundsParts * sizeof(float4)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  {   // k_chunk_sort: 32 KB of points + up to 32 KB of tile histogram, just over the 64 KB a kernel gets without asking
+    const int lds = 4096 * (int)sizeof(float2) + kBinMaxTiles * (int)sizeof(unsigned int);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chunk_sort<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chunk_sort<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chunk_sort<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return fail(NDT_ERR_HIP);
+  }
   if (hipMalloc((void**)&h->d_outside, sizeof(unsigned long long)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_static, sizeof(AlignStatic)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_call, sizeof(AlignCall)) != hipSuccess) return fail(NDT_ERR_ALLOC);
@@ -706,7 +834,7 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipEventCreateWithFlags(&h->upload_ev, hipEventDisableTiming) != hipSuccess) return fail(NDT_ERR_HIP);
   *h->h_flag = 0;
-  if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc(&h->h_small, 256, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(AlignDyn)) != hipSuccess) return fail(NDT_ERR_HIP);
   *out = h;
   return NDT_OK;
@@ -719,7 +847,7 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
   if (h->h_state_multi) (void)hipHostFree(h->h_state_multi);
-  void* dev[] = {h->d_geom, h->d_dyn_multi, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
+  void* dev[] = {h->d_bxy, h->d_table, h->d_parts, h->d_geom, h->d_dyn_multi, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
                  h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_geom, h->h_static, h->h_state, h->h_small, h->h_flag};
@@ -742,7 +870,9 @@ int32_t ndt2d_set_tuning(ndt2d_handle* h, int32_t knob, int64_t value) {
     case NDT_TUNE_WIDE_THRESHOLD: h->use_wide = value > 0; if (value > 0) h->wide_threshold = (size_t)value; return NDT_OK;
     case NDT_TUNE_SHORT_SCAN_KERNEL: h->use_small = value != 0; return NDT_OK;
     case NDT_TUNE_CHUNK_LAUNCHES: if (value < 2 || value > 128) return NDT_ERR_INVALID_ARG; h->check_every = (int)value; return NDT_OK;
-    case NDT_TUNE_BINNED_BUILD: h->use_binned_build = value != 0; return NDT_OK;
+    case NDT_TUNE_BINNED_BUILD:
+      if (value < 0 || value > 2) return NDT_ERR_INVALID_ARG;
+      h->use_binned_build = value != 0; if (value) h->build_variant = (int)value; return NDT_OK;
     case NDT_TUNE_SPLIT_FROM: if (value < 1 || value > 1000) return NDT_ERR_INVALID_ARG; h->split_from = (int)value; return NDT_OK;
     case NDT_TUNE_SINGLE_SYNC_BUILD: h->one_round_trip = value != 0; return NDT_OK;
     default: return NDT_ERR_INVALID_ARG;
@@ -801,19 +931,11 @@ int32_t ndt2d_add_target_points_dev(ndt2d_handle* h, const float* d_x, const flo
   { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
   // order after the caller's producer stream, as ndt2d_set_target_dev does
   if (stream) HIP_TRY(order_after(h->stream, (hipStream_t)stream));
-  const float* px = d_x;
-  const float* py = d_y;
-  if (pose) {
-    const int32_t st = ensure_points(&h->d_tx, &h->d_ty, &h->tcap, n);
-    if (st != NDT_OK) return st;
-    const float cs = (float)std::cos(pose[2]), sn = (float)std::sin(pose[2]);
-    hipLaunchKernelGGL(k_transform_points, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, d_x, d_y,
-                       n, cs, sn, (float)pose[0], (float)pose[1], h->d_tx, h->d_ty);
-    HIP_TRY(hipGetLastError());
-    px = h->d_tx; py = h->d_ty;
-  }
+  // the scan is moved into the map frame inside the build's first kernel (k_chunk_sort; k_transform_points on the other paths)
+  MoveArgs mv{1.f, 0.f, 0.f, 0.f, 0};
+  if (pose) { mv.cs = (float)std::cos(pose[2]); mv.sn = (float)std::sin(pose[2]); mv.tx = (float)pose[0]; mv.ty = (float)pose[1]; mv.use = 1; }
   unsigned long long outside = 0;
-  const int32_t fs = accumulate_and_finalise(h, px, py, n, /*merge=*/true, &outside);
+  const int32_t fs = accumulate_and_finalise(h, d_x, d_y, n, /*merge=*/true, &outside, &mv);
   if (n_outside) *n_outside = (size_t)outside;
   if (fs != NDT_OK) { h->has_target = false; return fs; }
   h->n_points += n - (size_t)outside;

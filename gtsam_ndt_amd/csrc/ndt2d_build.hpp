@@ -31,7 +31,7 @@ struct GeomDev {
   BinGeom bin;
   int ok;
   unsigned int bounds[4];     // the ordered-float bounding box (k_bounds accumulates here), for the host
-  int counters[2];            // valid cells, overflowed cells (k_tile_accumulate)
+  int counters[kCountInts];   // valid cells, overflowed cells, in shards (ndt_device.hpp: block_count_add)
   unsigned long long n_outside;
 };
 
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(1024) void k_build_init(GeomDev* __restrict__ geom,
   if (threadIdx.x == 0) {
     geom->ok = 0;
     geom->bounds[0] = 0xFFFFFFFFu; geom->bounds[1] = 0u; geom->bounds[2] = 0xFFFFFFFFu; geom->bounds[3] = 0u;
-    geom->counters[0] = 0; geom->counters[1] = 0;
+    for (int k = 0; k < kCountInts; ++k) geom->counters[k] = 0;
     geom->n_outside = 0ull;
   }
 }
@@ -284,14 +284,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate(const float* __
       g.rec[2 * k + 1] = rb;
     }
   }
-  // one counter atomic per wave
-  const int lane = threadIdx.x & 63;
-  nvalid = (int)wave_sum((float)nvalid);
-  nover = (int)wave_sum((float)nover);
-  if (lane == 0) {
-    if (nvalid) atomicAdd(&counters[0], nvalid);
-    if (nover) atomicAdd(&counters[1], nover);
-  }
+  block_count_add(counters, nvalid, nover);       // one add per workgroup, sharded (ndt_device.hpp)
 }
 
 }  // namespace ndt

@@ -273,7 +273,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float* __restrict__
 // ------------------------------------------------------------------------- a3 finalise
 // One thread per cell.
 __global__ __launch_bounds__(kBlock) void k_finalise(GridDev g, int min_points, double eig_ratio,
-                                                      int* __restrict__ counters /*[2]: valid, overflow*/) {
+                                                      int* __restrict__ counters /*[kCountShards][2]: valid, overflow*/) {
+  counters = count_shard(counters);
   const size_t ncell = (size_t)g.W * g.H;
   const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= ncell * g.ngrid) return;

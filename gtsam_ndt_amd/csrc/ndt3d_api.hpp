@@ -16,7 +16,7 @@ struct ndt3d_handle {
   int n_valid = 0;
   unsigned int* d_bounds = nullptr;   // [6]
   int* d_counters = nullptr;          // [2]
-  void* h_small = nullptr;            // pinned 64 B
+  void* h_small = nullptr;            // pinned 256 B (counter shards at 0, the outside count at 128)
   float *d_t[3] = {nullptr, nullptr, nullptr}; size_t tcap = 0;
   float *d_b[3] = {nullptr, nullptr, nullptr}; size_t bcap = 0;      // binned build scratch
   unsigned int* d_tiles = nullptr; size_t tile_cap = 0;
@@ -79,7 +79,7 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
   Grid3Dev& g = h->grid;
   const size_t ncell = (size_t)g.W * g.H * g.D;
   HIP_TRY(hipMemsetAsync(h->d_outside, 0, sizeof(unsigned long long), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, ndt::kCountInts * sizeof(int), h->stream));
   const int ntx = (g.W + (1 << kT3x) - 1) >> kT3x, nty = (g.H + (1 << kT3y) - 1) >> kT3y, ntz = (g.D + (1 << kT3z) - 1) >> kT3z;
   const long long ntile_ll = (long long)ntx * nty * ntz;
   if (ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull) {
@@ -121,13 +121,15 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
     HIP_TRY(hipGetLastError());
   }
   int* hc = (int*)h->h_small;
-  unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 32);
-  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 128);
+  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, ndt::kCountInts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h_outside) *h_outside = *ho;
-  h->n_valid = hc[0];
-  if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+  int n_valid_sum = 0, n_over_sum = 0;
+  sum_count_shards(hc, &n_valid_sum, &n_over_sum);
+  h->n_valid = n_valid_sum;
+  if (n_over_sum > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
   return NDT_OK;
 }
 
@@ -375,7 +377,7 @@ int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** ou
   if (hipSetDevice(device_id) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipMalloc((void**)&h->d_bounds, 32) != hipSuccess) return fail(NDT_ERR_ALLOC);
-  if (hipMalloc((void**)&h->d_counters, 2 * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_counters, ndt::kCountInts * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_outside, sizeof(unsigned long long)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_static, sizeof(ndt::AlignStatic3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_call, sizeof(ndt::AlignCall3)) != hipSuccess) return fail(NDT_ERR_ALLOC);
@@ -385,7 +387,7 @@ int32_t ndt3d_create(const ndt3d_params* p, int32_t device_id, ndt3d_handle** ou
   if (hipHostMalloc((void**)&h->h_state, sizeof(ndt::IterState3), hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   *h->h_flag = 0;
-  if (hipHostMalloc(&h->h_small, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipHostMalloc(&h->h_small, 256, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMemset(h->d_dyn, 0, sizeof(ndt::AlignDyn3)) != hipSuccess) return fail(NDT_ERR_HIP);
   *out = h;
   return NDT_OK;

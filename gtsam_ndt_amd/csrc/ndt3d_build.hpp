@@ -223,12 +223,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
       g.rec[4 * k] = ra; g.rec[4 * k + 1] = rb; g.rec[4 * k + 2] = rc;
     }
   }
-  nvalid = (int)wave_sum((float)nvalid);
-  nover = (int)wave_sum((float)nover);
-  if ((threadIdx.x & 63) == 0) {
-    if (nvalid) atomicAdd(&counters[0], nvalid);
-    if (nover) atomicAdd(&counters[1], nover);
-  }
+  block_count_add(counters, nvalid, nover);       // one add per workgroup, sharded (ndt_device.hpp)
 }
 
 }  // namespace ndt

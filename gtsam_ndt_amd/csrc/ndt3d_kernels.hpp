@@ -235,7 +235,8 @@ __device__ __forceinline__ bool finalise_sums3(const CellAcc3& c, double cx, dou
 }
 
 __global__ __launch_bounds__(kBlock) void k_finalise3(Grid3Dev g, int min_points, double eig_ratio,
-                                                       int* __restrict__ counters) {
+                                                       int* __restrict__ counters /*[kCountShards][2]*/) {
+  counters = count_shard(counters);
   const size_t ncell = (size_t)g.W * g.H * g.D;
   const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= ncell) return;

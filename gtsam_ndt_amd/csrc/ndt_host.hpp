@@ -20,6 +20,13 @@ inline void set_error(const char* msg) { last_error() = msg ? msg : ""; }
 
 namespace ndt {
 
+// the sharded build counters (ndt_device.hpp: kCountShards pairs of valid / overflowed cells) read back -> their totals
+inline void sum_count_shards(const int* hc, int* valid, int* over) {
+  int v = 0, o = 0;
+  for (int k = 0; k < 16; ++k) { v += hc[2 * k]; o += hc[2 * k + 1]; }
+  *valid = v; *over = o;
+}
+
 // roctx range over an API call (SURVEY.md section 5 "tracing"): shows up in rocprofv3 --marker-trace around
 // the kernels the call enqueues; a few nanoseconds when no profiler is attached, nothing at all when the marker
 // library is not on the machine (ndt_dyn.hpp).

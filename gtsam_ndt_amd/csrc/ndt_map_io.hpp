@@ -217,15 +217,17 @@ int32_t ndt3d_load_map(ndt3d_handle* h, const void* buf, size_t bytes) {
     h->cell_capacity = want;
   }
   HIP_TRY(hipMemcpyAsync(g.acc, (const char*)buf + sizeof m, ncell * sizeof(CellAcc3), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, ndt::kCountInts * sizeof(int), h->stream));
   hipLaunchKernelGGL(k_finalise3, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, g,
                      h->prm.min_points, h->prm.eig_ratio, h->d_counters);
   HIP_TRY(hipGetLastError());
   int* hc = (int*)h->h_small;
-  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, ndt::kCountInts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));      // buf is free on return
-  h->n_valid = hc[0];
-  if (hc[1] > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+  int n_valid_sum = 0, n_over_sum = 0;
+  sum_count_shards(hc, &n_valid_sum, &n_over_sum);
+  h->n_valid = n_valid_sum;
+  if (n_over_sum > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
   h->has_target = true;
   return upload_static3(h);
 }

@@ -204,33 +204,51 @@ def test_edge_cases(Matcher, gpu_lib):
 
 
 def test_binned_build_equals_atomic_build(Matcher):
-    """The LDS-binned grid build (fast path) and the scattered-global-atomic build produce the
-    same exact sums, hence bit-identical records - for a one-shot build, an incremental update
-    and overlapping grids, at the full 1M-point size."""
+    """The three grid builds - chunk-sorted (default: ndt2d_build_sorted.hpp), the round-1 binned build
+    (count / scan / scatter) and scattered global atomics - produce the same exact sums, hence bit-identical
+    records and the same count of valid cells: for a one-shot build, an incremental update (also of a scan moved
+    into the map frame on the way in), a second build on the same handle (the one-round-trip form) and overlapping
+    grids, at the full 1M-point size."""
     d = synth.make_pair(3)
     half = len(d["tx"]) // 2
     ext = np.unique([np.argmin(d["tx"]), np.argmax(d["tx"]), np.argmin(d["ty"]), np.argmax(d["ty"])])
     first = np.union1d(np.arange(half), ext)
     rest = np.setdiff1d(np.arange(len(d["tx"])), first)
     out = {}
-    for name, env in (("binned", "0"), ("atomic", "1")):
-        tune = {"binned_build": 0 if env == "1" else 1}
+    for name, variant in (("sorted", 1), ("binned", 2), ("atomic", 0)):
+        tune = {"binned_build": variant}
         with Matcher(tuning=tune) as m:
             info = m.set_target(d["tx"], d["ty"])
             full = m.grid() + (info.n_valid,)
+            again = m.set_target(d["tx"], d["ty"])                       # the handle holds a grid now: one round trip
+            assert again.n_valid == info.n_valid
+            for u, v in zip(full[:3], m.grid()):
+                np.testing.assert_array_equal(u, v)
             m.set_target(d["tx"][first], d["ty"][first])
             assert m.add_target_points(d["tx"][rest], d["ty"][rest]) == 0
-            inc = m.grid()
+            inc = m.grid() + (m.grid_info().n_valid,)
             assert m.add_target_points(d["tx"][:10] + 1e4, d["ty"][:10]) == 10      # outside: counted, ignored
+            assert m.grid_info().n_valid == inc[3]
+            # a scan merged with the pose an alignment returned (moved into the map frame inside the build)
+            import torch
+            m.add_target_points(torch.from_numpy(d["sx"]).cuda(), torch.from_numpy(d["sy"]).cuda(), pose=d["pose"])
+            moved = m.grid() + (m.grid_info().n_valid,)
         with Matcher(overlap_grids=4, tuning=tune) as m:
             ov = m.set_target(d["tx"][:200000], d["ty"][:200000]).n_valid
             r = m.align(d["sx"], d["sy"], d["init"])
-        out[name] = (full, inc, ov, r.pose)
-    (fa, ia, oa, pa), (fb, ib, ob, pb) = out["binned"], out["atomic"]
-    for u, v in zip(fa[:3], fb[:3]):
-        np.testing.assert_array_equal(u, v)
-    assert fa[3] == fb[3] and oa == ob and pa == pb
-    for u, v in zip(ia, ib):
-        np.testing.assert_array_equal(u, v)
-    for u, v in zip(fa[:3], ia):
+        out[name] = (full, inc, ov, r.pose, moved)
+    fa, ia, oa, pa, ma = out["atomic"]
+    assert ia[3] == fa[3]                                              # an update re-counts the valid cells correctly
+    for name in ("sorted", "binned"):
+        fb, ib, ob, pb, mb = out[name]
+        for u, v in zip(fa[:3], fb[:3]):
+            np.testing.assert_array_equal(u, v)
+        assert fa[3] == fb[3] and oa == ob and pa == pb, name
+        for u, v in zip(ia[:3], ib[:3]):
+            np.testing.assert_array_equal(u, v)
+        assert ia[3] == ib[3], name
+        for u, v in zip(ma[:3], mb[:3]):
+            np.testing.assert_array_equal(u, v)
+        assert ma[3] == mb[3], name
+    for u, v in zip(fa[:3], ia[:3]):
         np.testing.assert_array_equal(u, v)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Per-kernel times of the grid build (tools/quick_build.py) under rocprofv3 --kernel-trace --stats; run on the GPU box.
+set -eo pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
+VARIANTS="${1:-1,2}"
+OUT="$ROOT/gpurun_out/prof_build"
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python3 "$ROOT/tools/quick_build.py" "$VARIANTS"
+rocprofv3 --kernel-trace --stats -d "$OUT" -o build --output-format csv -- python3 "$ROOT/tools/quick_build.py" "$VARIANTS" > "$OUT/run.log" 2>&1
+python3 - "$OUT" <<'PY'
+import csv, glob, sys
+for fn in glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(fn)):
+        print(r['Name'][:78].ljust(78), r['Calls'].rjust(6), ('%.2f' % (float(r['AverageNs']) / 1e3)).rjust(9), ('%.2f' % (float(r['MinNs']) / 1e3)).rjust(9),
+              ('%.2f' % (float(r['MaxNs']) / 1e3)).rjust(9))
+PY
+find "$OUT" -name "*.csv" -size +2M -delete
