@@ -63,6 +63,13 @@ struct ndt2d_handle {
   float2* d_bxy = nullptr; size_t bxy_cap = 0;             // chunk-sorted copy of the cloud ([chunks][chunk points])
   unsigned int* d_table = nullptr; size_t table_cap = 0;   // [tiles][chunks]: start | len << 16 of every run
   float4* d_parts = nullptr;               // [kBoundsParts]: per-workgroup partial bounding boxes
+  unsigned char* d_split = nullptr; size_t split_cap = 0;  // tickets | cursor | touched | parts | pool of the shared tiles (SplitBufs)
+  unsigned int build_seq = 0;              // sorted builds so far on this handle (SplitBufs::seq; never 0 in a launch)
+  // accumulators of the sorted build, ping-pong: half p = 256 bytes: int counters[kCountInts] | u64 outside at 128.  A build
+  // adds to half acc_parity and clears the other one for the next build (k_tile_gather), so no fill launch precedes it.
+  unsigned char* d_acc2 = nullptr;
+  int acc_parity = 0;
+  bool acc_clean = false;                  // both halves known to be zero where the next build needs it
   // hipGraph of the launch chain (launch-bound inner loop: one replay instead of K+1 launches)
   ChainGraphCache graphs;
   hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
@@ -188,11 +195,55 @@ int32_t ensure_sorted_buffers(ndt2d_handle* h, const SortPlan& sp, size_t ntile)
   return NDT_OK;
 }
 
+// the buffers the workgroups that share a tile use (ndt2d_build_sorted.hpp: SplitBufs), sized for `tiles` tiles and n points
+int32_t ensure_split_buffers(ndt2d_handle* h, size_t n, int tiles, SplitBufs* sb) {
+  const size_t pool_entries = n < (size_t)tiles * kGatherSplit * kTileCells ? n : (size_t)tiles * kGatherSplit * kTileCells;
+  const size_t off_touched = ((size_t)tiles + 1) * sizeof(unsigned int);
+  const size_t off_part = (off_touched + (size_t)tiles * sizeof(unsigned int) + 15) / 16 * 16;
+  const size_t off_pool = off_part + (size_t)tiles * kGatherSplit * sizeof(uint2);
+  const size_t need = off_pool + (pool_entries + 1) * sizeof(CellAcc);
+  if (need > h->split_cap) {
+    if (h->d_split) (void)hipFree(h->d_split);
+    h->d_split = nullptr; h->split_cap = 0;
+    const size_t want = need + need / 4;
+    HIP_TRY(hipMalloc((void**)&h->d_split, want));
+    HIP_TRY(hipMemsetAsync(h->d_split, 0, want, h->stream));       // (the touched numbers must not start as garbage)
+    h->split_cap = want;
+    h->build_seq = 0;
+  }
+  if (++h->build_seq == 0u) {                                      // wrapped: start the numbers over
+    HIP_TRY(hipMemsetAsync(h->d_split, 0, h->split_cap, h->stream));
+    h->build_seq = 1u;
+  }
+  sb->ticket = reinterpret_cast<unsigned int*>(h->d_split);
+  sb->touched = reinterpret_cast<unsigned int*>(h->d_split + off_touched);
+  sb->part = reinterpret_cast<uint2*>(h->d_split + off_part);
+  sb->pool = reinterpret_cast<CellAcc*>(h->d_split + off_pool);
+  sb->tiles = tiles;
+  sb->seq = h->build_seq;
+  // a tile is shared so that no workgroup sums much more than a CU's share of the cloud; clouds too small to fill the
+  // chip are cut finer, down to 1024 points per workgroup
+  size_t sp = n / 200;
+  sb->split_points = (int)(sp < 1024 ? 1024 : (sp > (size_t)1 << 24 ? (size_t)1 << 24 : sp));
+  return NDT_OK;
+}
+
+// Workgroups per tile (grid.y of k_tile_gather).  A cloud that fills most of the grid's tiles keeps most CUs busy with one
+// workgroup per tile (169 tiles of a 1M-point submap: sharing them measured slower - the surplus workgroups cost more
+// than the 87 idle CUs could give back); a cloud that lands on a few tiles (a 100k-point scan touches about 16) is
+// where sharing pays: its tiles get up to kGatherSplit workgroups each.
+int gather_split(size_t n, int tiles) {
+  size_t touched = n / 6000 + 1;
+  if (touched > (size_t)tiles) touched = (size_t)tiles;
+  size_t s = 256 / touched;
+  return (int)(s < 1 ? 1 : (s > (size_t)kGatherSplit ? (size_t)kGatherSplit : s));
+}
+
 void launch_chunk_sort(ndt2d_handle* h, const SortPlan& sp, const float* d_x, const float* d_y, size_t n, const BinGeom& bg,
-                       int hist_tiles, const MoveArgs& mv, unsigned long long* d_outside, const GeomArgs& ga) {
+                       int hist_tiles, const MoveArgs& mv, unsigned long long* d_outside, const GeomArgs& ga, const SplitBufs& sb) {
   const size_t lds = (size_t)sp.chunk * sizeof(float2) + (size_t)hist_tiles * sizeof(unsigned int);
 #define NDT_SORT(PP) hipLaunchKernelGGL((k_chunk_sort<PP>), dim3((unsigned)sp.nchunks), dim3(kSortThreads), lds, h->stream, d_x, d_y, n, \
-                                        bg, sp.nchunks, mv, h->d_bxy, h->d_table, d_outside, ga)
+                                        bg, sp.nchunks, mv, h->d_bxy, h->d_table, d_outside, ga, sb.ticket, sb.tiles + 1, sb.touched, sb.seq)
   if (sp.P == 4) NDT_SORT(4); else if (sp.P == 8) NDT_SORT(8); else NDT_SORT(16);
 #undef NDT_SORT
 }
@@ -217,29 +268,39 @@ int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* 
   const size_t ncell1 = (size_t)g.W * g.H, ncell = ncell1 * g.ngrid;
   const int ntx = (g.W + kTile - 1) >> kTileShift, nty = (g.H + kTile - 1) >> kTileShift;
   const long long ntile_ll = (long long)ntx * nty;
-  HIP_TRY(hipMemsetAsync(h->d_outside, 0, sizeof(unsigned long long), h->stream));
   SortPlan sp;
   if (h->use_binned_build && h->build_variant == 1 && ntile_ll <= kBinMaxTiles && plan_sorted(n, ntile_ll, &sp)) {
     // chunk-sorted build: sort every chunk of the cloud by tile, then one workgroup per tile gathers its runs
     const int ntile = (int)ntile_ll;
     { const int32_t es = ensure_sorted_buffers(h, sp, (size_t)ntile); if (es != NDT_OK) return es; }
-    HIP_TRY(hipMemsetAsync(h->d_counters, 0, ndt::kCountInts * sizeof(int), h->stream));
+    SplitBufs sb{};
+    { const int32_t es = ensure_split_buffers(h, n, ntile, &sb); if (es != NDT_OK) return es; }
+    const int split = gather_split(n, ntile);
+    if (!h->acc_clean) HIP_TRY(hipMemsetAsync(h->d_acc2, 0, 512, h->stream));      // (first build, or one that failed half-way)
+    h->acc_clean = false;
+    unsigned char* cur = h->d_acc2 + 256 * h->acc_parity;
+    unsigned char* nxt = h->d_acc2 + 256 * (1 - h->acc_parity);
+    int* d_cnt = reinterpret_cast<int*>(cur);
+    unsigned long long* d_out = reinterpret_cast<unsigned long long*>(cur + 128);
     const MoveArgs none{1.f, 0.f, 0.f, 0.f, 0};
     for (int q = 0; q < g.ngrid; ++q) {
       BinGeom bg{g.gx[q], g.gy[q], g.inv_c, g.W, g.H, ntx, ntile};
-      launch_chunk_sort(h, sp, d_x, d_y, n, bg, ntile, move ? *move : none, q == 0 ? h->d_outside : (unsigned long long*)nullptr,
-                        GeomArgs{});
-      hipLaunchKernelGGL(k_tile_gather, dim3(ntile), dim3(kGatherThreads), 0, h->stream, (const float2*)h->d_bxy, (const unsigned int*)h->d_table,
-                         sp.nchunks, sp.chunk, g, q, ntx, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, h->d_counters,
-                         (const GeomDev*)nullptr, (const GridDev*)nullptr);
+      launch_chunk_sort(h, sp, d_x, d_y, n, bg, ntile, move ? *move : none, q == 0 ? d_out : (unsigned long long*)nullptr,
+                        GeomArgs{}, sb);
+      hipLaunchKernelGGL(k_tile_gather, dim3(ntile, split), dim3(kGatherThreads), 0, h->stream, (const float2*)h->d_bxy, (const unsigned int*)h->d_table,
+                         sp.nchunks, sp.chunk, g, q, ntx, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, d_cnt,
+                         (const GeomDev*)nullptr, (const GridDev*)nullptr, sb,
+                         q == g.ngrid - 1 ? reinterpret_cast<unsigned int*>(nxt) : (unsigned int*)nullptr);
       HIP_TRY(hipGetLastError());
     }
     h->last_ntile = ntile;
     int* hc = (int*)h->h_small;
     unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 128);
-    HIP_TRY(hipMemcpyAsync(hc, h->d_counters, ndt::kCountInts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    static_assert(ndt::kCountInts * sizeof(int) == 128, "the accumulator halves mirror h_small: counters at 0, outside at 128");
+    HIP_TRY(hipMemcpyAsync(hc, cur, 136, hipMemcpyDeviceToHost, h->stream));        // counter shards and outside count in one copy
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->acc_parity ^= 1;
+    h->acc_clean = true;
     int n_valid_sum = 0, n_over_sum = 0;
     sum_count_shards(hc, &n_valid_sum, &n_over_sum);
     h->n_valid = merge ? h->n_valid + n_valid_sum : n_valid_sum;       // merge: the gather kernel counts the change, tile by touched tile
@@ -256,6 +317,7 @@ int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* 
     HIP_TRY(hipGetLastError());
     d_x = h->d_tx; d_y = h->d_ty;
   }
+  HIP_TRY(hipMemsetAsync(h->d_outside, 0, sizeof(unsigned long long), h->stream));
   if (h->use_binned_build && ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull) {
     const int ntile = (int)ntile_ll;
     if (n > h->bcap) {
@@ -383,16 +445,19 @@ int32_t set_target_single_sync(ndt2d_handle* h, const float* d_x, const float* d
   if (h->build_variant == 1 && plan_sorted(n, tile_bound, &sp)) {
     // chunk-sorted build: bounds partials -> chunk sort (reduce + geometry in its prologue) -> one workgroup per tile
     { const int32_t es = ensure_sorted_buffers(h, sp, (size_t)tile_bound); if (es != NDT_OK) return es; }
+    SplitBufs sb{};
+    { const int32_t es = ensure_split_buffers(h, n, tile_bound, &sb); if (es != NDT_OK) return es; }
+    const int split = gather_split(n, tile_bound);
     const int nparts = launch_bounds_parts(h, d_x, d_y, n, dg);
     const BinGeom none{};
     const MoveArgs stay{1.f, 0.f, 0.f, 0.f, 0};
     GeomArgs ga{};
     ga.parts = h->d_parts; ga.nparts = nparts; ga.tile_bound = tile_bound; ga.cell = h->prm.cell_size;
     ga.cell_capacity = (unsigned long long)h->cell_capacity; ga.grid = &h->d_static->grid; ga.out = dg;
-    launch_chunk_sort(h, sp, d_x, d_y, n, none, tile_bound, stay, &dg->n_outside, ga);
-    hipLaunchKernelGGL(k_tile_gather, dim3(tile_bound), dim3(kGatherThreads), 0, h->stream, (const float2*)h->d_bxy,
+    launch_chunk_sort(h, sp, d_x, d_y, n, none, tile_bound, stay, &dg->n_outside, ga, sb);
+    hipLaunchKernelGGL(k_tile_gather, dim3(tile_bound, split), dim3(kGatherThreads), 0, h->stream, (const float2*)h->d_bxy,
                        (const unsigned int*)h->d_table, sp.nchunks, sp.chunk, h->grid, 0, 0, 0, h->prm.min_points, h->prm.eig_ratio,
-                       &dg->counters[0], (const GeomDev*)dg, (const GridDev*)&h->d_static->grid);
+                       &dg->counters[0], (const GeomDev*)dg, (const GridDev*)&h->d_static->grid, sb, (unsigned int*)nullptr);
   } else {
   if (n > h->bcap) {
     if (h->d_bx) (void)hipFree(h->d_bx);
@@ -818,6 +883,7 @@ int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** ou
   if (hipMalloc((void**)&h->d_bounds, 4 * sizeof(unsigned int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_counters, ndt::kCountInts * sizeof(int)) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&h->d_parts, kBoundsParts * sizeof(float4)) != hipSuccess) return fail(NDT_ERR_ALLOC);
+  if (hipMalloc((void**)&h->d_acc2, 512) != hipSuccess) return fail(NDT_ERR_ALLOC);
   {   // k_chunk_sort: 32 KB of points + up to 32 KB of tile histogram, just over the 64 KB a kernel gets without asking
     const int lds = 4096 * (int)sizeof(float2) + kBinMaxTiles * (int)sizeof(unsigned int);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chunk_sort<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
@@ -847,7 +913,7 @@ int32_t ndt2d_destroy(ndt2d_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
   if (h->h_state_multi) (void)hipHostFree(h->h_state_multi);
-  void* dev[] = {h->d_bxy, h->d_table, h->d_parts, h->d_geom, h->d_dyn_multi, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
+  void* dev[] = {h->d_acc2, h->d_split, h->d_bxy, h->d_table, h->d_parts, h->d_geom, h->d_dyn_multi, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_bx, h->d_by, h->d_tiles, h->d_tx, h->d_ty, h->d_sx, h->d_sy,
                  h->grid.rec, h->grid.acc};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_geom, h->h_static, h->h_state, h->h_small, h->h_flag};

@@ -13,7 +13,13 @@
 //   k_tile_gather     one 1024-thread workgroup per tile walks the tile's row of the table, reads its runs (short
 //                     contiguous reads), sums into LDS (cell slots padded to a stride of 33 so that a wall along y does
 //                     not put a whole wave on one bank), finalises and writes sums and records with coalesced stores.
-//                     In merge mode (submap update) tiles that received no point return at once.
+//                     In merge mode (submap update) tiles that received no point return at once.  A tile with many
+//                     points is SHARED by up to kGatherSplit workgroups (grid.y): each sums its share of the runs, all
+//                     but the last to finish leave their non-empty cells as a short list in global memory, the last
+//                     one (a ticket per tile) adds the lists to its own sums and finalises - exact integers, so any
+//                     split gives the same bits.  One workgroup per tile left the kernel waiting for the fullest
+//                     tiles (11 000 of a million points on one CU's LDS atomic unit) with a third of the CUs idle, and
+//                     a submap update on the 16 CUs of the 16 tiles a scan touches.
 // The sums are the same exact integers as on every other path, so the records are bit-identical
 // (tests/test_gpu_ndt2d.py::test_binned_build_equals_atomic_build pins all three builds against each other).
 // The table has tiles x chunks entries: the path is taken while that is <= 2^20 and a row fits the gather kernel's LDS
@@ -30,6 +36,21 @@ constexpr size_t kSortMaxTable = size_t(1) << 20;    // tiles x chunks
 constexpr int kBoundsParts = 256;                    // workgroups of k_bounds_parts (one partial each)
 constexpr int kTileStride = kTile + 1;               // LDS cell slots per tile row: 33, see above
 constexpr int kTileSlots = kTileStride * kTile;
+constexpr int kGatherSplit = 8;                      // workgroups that may share a tile (grid.y of k_tile_gather)
+
+// what the workgroups that share a tile hand to the one that finishes it (all in one allocation of the handle)
+struct SplitBufs {
+  unsigned int* ticket;      // [tiles]: arrivals per tile; [tiles]: the pool's cursor.  Cleared by k_chunk_sort
+  unsigned int* touched;     // [tiles]: the call number `seq` where this call's cloud put a point into the tile (k_chunk_sort;
+                             // never cleared: an older number means "not this time") - lets the surplus workgroups of tiles
+                             // that received nothing leave after one scalar load instead of after the tile's table row
+  unsigned int seq;
+  uint2* part;               // [tiles][kGatherSplit]: (first entry, entries) of a workgroup's list in the pool
+  CellAcc* pool;             // the lists: a cell's sums with its LDS slot in `pad`; one entry per (workgroup, non-empty
+                             // cell), so never more entries than points
+  int tiles;                 // launch bound on the number of tiles (the cursor sits behind the tickets)
+  int split_points;          // a tile is shared by ceil(points / split_points) workgroups, at most kGatherSplit
+};
 
 // ---- bounds: one partial per workgroup -------------------------------------------------------------------------
 // parts[b] = (xmin, xmax, ymin, ymax) over the finite points workgroup b saw (+inf / -inf when it saw none).
@@ -165,7 +186,7 @@ struct GeomArgs {
   GeomDev* out;               // bin, ok, bounds (the accumulators in it were cleared by k_bounds_parts)
 };
 
-#if defined(NDT_EXP_GATHER) && NDT_EXP_GATHER == 9
+#if defined(NDT_BUILD_PHASE_CLOCKS)
 __device__ unsigned long long g_sort_stamps[4096][2];        // tools-only: start / end clock of every k_chunk_sort workgroup
 #endif
 // ---- chunk sort ---------------------------------------------------------------------------------------------------
@@ -180,7 +201,9 @@ template <int P>
 __global__ __launch_bounds__(kSortThreads) void k_chunk_sort(const float* __restrict__ x, const float* __restrict__ y, size_t n,
                                                               BinGeom g, int nchunks, MoveArgs mv, float2* __restrict__ binned,
                                                               unsigned int* __restrict__ table,
-                                                              unsigned long long* __restrict__ n_outside, GeomArgs ga) {
+                                                              unsigned long long* __restrict__ n_outside, GeomArgs ga,
+                                                              unsigned int* __restrict__ ticket, int n_ticket,
+                                                              unsigned int* __restrict__ touched, unsigned int seq) {
 #pragma clang fp contract(off)      // the motion must round as k_transform_points does (products, then sums)
   constexpr int C = kSortThreads * P;
   static_assert(C <= 4096, "start and length of a run are 16-bit fields");
@@ -212,7 +235,9 @@ __global__ __launch_bounds__(kSortThreads) void k_chunk_sort(const float* __rest
   __shared__ unsigned int s_wave[kSortThreads / 64];
   __shared__ unsigned int s_total;
   const int chunk = blockIdx.x;
-#if defined(NDT_EXP_GATHER) && NDT_EXP_GATHER == 9
+  if (chunk == 0)                     // the tickets and the pool cursor of the gather kernel that follows
+    for (int t = threadIdx.x; t < n_ticket; t += kSortThreads) ticket[t] = 0u;
+#if defined(NDT_BUILD_PHASE_CLOCKS)
   if (threadIdx.x == 0) g_sort_stamps[blockIdx.x & 4095][0] = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int t = threadIdx.x; t < g.ntile; t += kSortThreads) s_hist[t] = 0u;
@@ -262,6 +287,7 @@ __global__ __launch_bounds__(kSortThreads) void k_chunk_sort(const float* __rest
       const unsigned int len = s_hist[t];
       s_hist[t] = run;
       table[(size_t)t * nchunks + chunk] = run | (len << 16);
+      if (len) touched[t] = seq;            // (every chunk that has points in the tile stores the same number)
       run += len;
     }
   }
@@ -278,12 +304,12 @@ __global__ __launch_bounds__(kSortThreads) void k_chunk_sort(const float* __rest
     outside = (unsigned int)wave_sum((float)outside);        // <= 64 * P: exact in float
     if (lane == 0 && outside) atomicAdd(n_outside, (unsigned long long)outside);
   }
-#if defined(NDT_EXP_GATHER) && NDT_EXP_GATHER == 9
+#if defined(NDT_BUILD_PHASE_CLOCKS)
   if (threadIdx.x == 0) g_sort_stamps[blockIdx.x & 4095][1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
-#if defined(NDT_EXP_GATHER) && NDT_EXP_GATHER == 9
+#if defined(NDT_BUILD_PHASE_CLOCKS)
 __device__ unsigned long long g_gather_stamps[1024][8];      // tools-only: 100 MHz clock per phase, per workgroup
 __device__ unsigned long long g_gather_wave_end[1024][16];   // ... and the end of every wave
 #define NDT_STAMP(k) do { if (threadIdx.x == 0) g_gather_stamps[blockIdx.x & 1023][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -296,13 +322,14 @@ __device__ unsigned long long g_gather_wave_end[1024][16];   // ... and the end 
 __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(const float2* __restrict__ binned, const unsigned int* __restrict__ table,
                                                                  int nchunks, int chunk_points, GridDev g, int q, int ntx, int merge,
                                                                  int min_points, double eig_ratio, int* __restrict__ counters,
-                                                                 const GeomDev* __restrict__ dg, const GridDev* __restrict__ dgrid) {
+                                                                 const GeomDev* __restrict__ dg, const GridDev* __restrict__ dgrid,
+                                                                 SplitBufs sb, unsigned int* __restrict__ zero_next) {
   // LDS: the five 64-bit sums and the counts of the tile's cells (SoA, slot = ly * 33 + lx), the tile's row of the
   // run table; the finished float32 records are staged over the sums at the end (s_rec) for whole-line stores.
   __shared__ __attribute__((aligned(16))) unsigned long long s_sum[5][kTileSlots];
   __shared__ unsigned int s_n[kTileSlots];
   __shared__ unsigned int s_runs[kSortMaxChunks];
-  __shared__ int s_any;
+  __shared__ unsigned int s_total, s_list, s_last;
   float4* const s_rec = reinterpret_cast<float4*>(&s_sum[0][0]);      // [1024 cells][2], 32 KB of the 42 KB
   static_assert(sizeof(float4) * 2 * kTileCells <= sizeof(unsigned long long) * 5 * kTileSlots, "the records overlay the sums");
   const int tile = blockIdx.x;
@@ -322,16 +349,27 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(const float2* __
     ox = dgrid->gx[0]; oy = dgrid->gy[0];        // (a device-decided geometry is a single grid)
   }
   NDT_STAMP(0);
-  if (threadIdx.x == 0) s_any = 0;
+  const int sub = blockIdx.y;
+  // the NEXT build's accumulators (counter shards + outside count: the other half of a ping-pong pair, which nothing adds
+  // to in this call) are cleared here instead of by two fill launches in front of every build
+  if (zero_next && tile == 0 && sub == 0 && threadIdx.x < kCountInts + 2) zero_next[threadIdx.x] = 0u;
+  if (__builtin_amdgcn_readfirstlane(sb.touched[tile]) != sb.seq && (sub > 0 || merge)) return;    // nothing arrived (uniform)
+  if (threadIdx.x == 0) { s_total = 0u; s_list = 0u; }
   __syncthreads();
   {
-    unsigned int any = 0;
+    unsigned int pts = 0;
     const unsigned int* row = table + (size_t)tile * nchunks;
-    for (int k = threadIdx.x; k < nchunks; k += kGatherThreads) { const unsigned int e = row[k]; s_runs[k] = e; any |= e >> 16; }
-    if (any) s_any = 1;            // benign race: every writer stores 1
+    for (int k = threadIdx.x; k < nchunks; k += kGatherThreads) { const unsigned int e = row[k]; s_runs[k] = e; pts += e >> 16; }
+    pts = (unsigned int)wave_sum_u32(pts);
+    if ((threadIdx.x & 63) == 0 && pts) atomicAdd(&s_total, pts);
   }
   __syncthreads();
-  if (merge && !s_any) return;     // submap update: this tile received no point, its cells stand as they are (uniform)
+  const unsigned int tile_points = s_total;                   // the same in every workgroup of the tile
+  if (merge && tile_points == 0u) return;   // submap update: this tile received no point, its cells stand as they are (uniform)
+  int nsub = (int)((tile_points + (unsigned)sb.split_points - 1u) / (unsigned)sb.split_points);
+  nsub = nsub < 1 ? 1 : (nsub > (int)gridDim.y ? (int)gridDim.y : nsub);
+  if (sub >= nsub) return;                                    // uniform
+  const bool shared_tile = nsub > 1;
   const int tx0 = (tile % ntx) << kTileShift, ty0 = (tile / ntx) << kTileShift;
   const size_t gbase = (size_t)q * W * H;
   // one cell per thread: cell (lx, ly) of the tile lives in LDS slot ly * 33 + lx
@@ -342,7 +380,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(const float2* __
   const size_t cell = gbase + (size_t)iy * W + ix;
   {
     CellAcc a = {0, 0, 0, 0, 0, 0u, 0u};
-    if (merge && in_grid) a = acc[cell];
+    if (merge && !shared_tile && in_grid) a = acc[cell];       // (a shared tile's cached sums are added by the workgroup that finishes it)
     s_n[slot] = a.n;
     s_sum[0][slot] = (unsigned long long)a.sx; s_sum[1][slot] = (unsigned long long)a.sy;
     s_sum[2][slot] = (unsigned long long)a.sxx; s_sum[3][slot] = (unsigned long long)a.sxy;
@@ -351,50 +389,33 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(const float2* __
   __syncthreads();
   NDT_STAMP(1);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#ifndef NDT_EXP_GATHER
-#define NDT_EXP_GATHER 0       // tools-only ablations: 1 no LDS atomics, 2 count atomic only, 3 no float64 coordinate arithmetic,
-                               // 4 no point loop, 5 no finalise arithmetic, 6 neither (init + stores only)
-#endif
-  unsigned long long exp_sink = 0; (void)exp_sink;
   auto add_point = [&](float2 p) {
     const float fx = (p.x - ox) * inv_c, fy = (p.y - oy) * inv_c;
     const int cx = (int)fx, cy = (int)fy;              // in range: the point was binned by the same formula
-#if NDT_EXP_GATHER == 3
-    const int ux = (int)((fx - (float)cx) * 4194304.f), uy = (int)((fy - (float)cy) * 4194304.f);
-#else
     const int ux = fix_coord(p.x, cell_centre(ox, cx, cell_size), fix_scale);
     const int uy = fix_coord(p.y, cell_centre(oy, cy, cell_size), fix_scale);
-#endif
     const int c = (cy - ty0) * kTileStride + (cx - tx0);
-#if NDT_EXP_GATHER == 1
-    exp_sink += (unsigned long long)c + prod64(ux, uy);
-#elif NDT_EXP_GATHER == 2
-    atomicAdd(&s_n[c], 1u);
-    exp_sink += prod64(ux, uy);
-#else
     atomicAdd(&s_n[c], 1u);
     atomicAdd(&s_sum[0][c], (unsigned long long)(long long)ux);
     atomicAdd(&s_sum[1][c], (unsigned long long)(long long)uy);
     atomicAdd(&s_sum[2][c], prod64(ux, ux));
     atomicAdd(&s_sum[3][c], prod64(ux, uy));
     atomicAdd(&s_sum[4][c], prod64(uy, uy));
-#endif
   };
-#if NDT_EXP_GATHER == 4 || NDT_EXP_GATHER == 6
-  if (nchunks < 0)
-#endif
   // A wave per run, four runs in flight: wave w takes the runs w, w + 16, ... of this tile.  The loads of four runs
   // are issued before any point is summed - one load per lane and run covers a run of up to 64 points, which is
   // nearly every run of a large cloud (a tile's share of a 4096-point chunk); a loop with one dependent load per
   // trip ran at the memory latency (10 us per tile, seen with in-kernel clocks).  Longer runs (a sorted scan puts
   // whole chunks into one tile) go on in blocks of 256 points, again with four loads in flight.
-  for (int k0 = wave; k0 < nchunks; k0 += 16 * 4) {
+  // (workgroup `sub` of the nsub that share the tile takes the runs sub, sub + nsub, ...; wave w every 16th of those)
+  const int kstep = 16 * nsub;
+  for (int k0 = sub + nsub * wave; k0 < nchunks; k0 += 4 * kstep) {
     const float2* r[4];
     unsigned int len[4];
     float2 p[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int kk = k0 + 16 * j;
+      const int kk = k0 + kstep * j;
       const unsigned int e = kk < nchunks ? s_runs[kk] : 0u;
       len[j] = e >> 16;
       r[j] = binned + (size_t)kk * chunk_points + (e & 0xFFFFu);
@@ -420,35 +441,81 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(const float2* __
       }
     }
   }
-#if NDT_EXP_GATHER != 0
-  if (exp_sink == 0x123456789ull) s_n[0] = 1u;        // keeps the ablated arithmetic alive
-#endif
   NDT_STAMP(2);
   __syncthreads();
+  if (shared_tile) {
+    // This workgroup's non-empty cells as a list in the pool: the cell's sums, its LDS slot in `pad`.
+    const unsigned int my_n = s_n[slot];
+    unsigned int my_idx = 0;
+    if (my_n) my_idx = atomicAdd(&s_list, 1u);
+    __syncthreads();
+    const unsigned int my_count = s_list;
+    if (threadIdx.x == 0) s_total = my_count ? atomicAdd(&sb.ticket[sb.tiles], my_count) : 0u;       // the pool's cursor
+    __syncthreads();
+    const unsigned int my_base = s_total;
+    // The hand-off avoids agent-scope fences: a release fence writes back every dirty line of the XCD's L2 (the sort's
+    // output sits there: 7-9 us per workgroup, measured) - instead EVERY handed-off byte is stored write-through (sc1,
+    // agent-scope atomic stores) and loaded with sc1 loads, every storing wave drains its stores, the workgroup meets,
+    // and one lane takes the tile's ticket (MI355X_MICROARCH.md, "Valid forms" and the table under it: signal = one
+    // lane's agent-scope atomic add for all the workgroup's stores, the consumer is the workgroup whose add came last).
+    if (my_n) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(sb.pool + my_base + my_idx);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) __hip_atomic_store(dst + j, s_sum[j][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 5, (unsigned long long)my_n | ((unsigned long long)(unsigned int)slot << 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);                                   // (n, pad = the cell's LDS slot)
+    }
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(sb.part + (size_t)tile * kGatherSplit + sub),
+                         (unsigned long long)my_base | ((unsigned long long)my_count << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&sb.ticket[tile], 1u) == (unsigned int)(nsub - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;                                       // uniform
+    // the other workgroups' lists, one wave per list (read one after the other they cost two dependent memory round
+    // trips each: 7 lists were 9 us)
+    if (wave < nsub && wave != sub) {
+      const int o = wave;
+      const unsigned long long pw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(sb.part + (size_t)tile * kGatherSplit + o),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written before o's ticket
+      const unsigned int base = (unsigned int)(pw & 0xffffffffull), count = (unsigned int)(pw >> 32);
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(sb.pool + base);
+      for (unsigned int i = lane; i < count; i += 64) {
+        // agent-scope loads (sc1: served by L2, never by a stale line of this CU's L1)
+        unsigned long long w[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) w[j] = __hip_atomic_load(src + 6 * (size_t)i + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int en = (unsigned int)(w[5] & 0xffffffffull), es = (unsigned int)(w[5] >> 32);
+        atomicAdd(&s_n[es], en);                               // (other waves add other lists to the same cells)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) atomicAdd(&s_sum[j][es], w[j]);
+      }
+    }
+    __syncthreads();
+    if (merge && in_grid) {                                    // the cached sums of a submap update, once per tile
+      const CellAcc a = acc[cell];
+      s_n[slot] += a.n;
+      s_sum[0][slot] += (unsigned long long)a.sx; s_sum[1][slot] += (unsigned long long)a.sy;
+      s_sum[2][slot] += (unsigned long long)a.sxx; s_sum[3][slot] += (unsigned long long)a.sxy;
+      s_sum[4][slot] += (unsigned long long)a.syy;
+    }
+    __syncthreads();                                           // the write-back below reads other threads' slots
+  }
   NDT_STAMP(3);
   int nvalid = 0, nover = 0;
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
-#if NDT_EXP_GATHER == 8
-  const long long sx_dbg = (long long)s_sum[0][slot];
-#endif
   if (in_grid) {
     const unsigned int n = s_n[slot];
     const long long sx = (long long)s_sum[0][slot], sy = (long long)s_sum[1][slot], sxx = (long long)s_sum[2][slot],
                     sxy = (long long)s_sum[3][slot], syy = (long long)s_sum[4][slot];
     if (merge) nvalid -= rec[2 * cell + 1].z > 0.f ? 1 : 0;       // a valid record carries its point count there
     if (n > kMaxCellCount) nover++;
-#if NDT_EXP_GATHER != 5 && NDT_EXP_GATHER != 6 && NDT_EXP_GATHER != 8
     else if ((int)n >= min_points &&
              finalise_sums((int)n, sx, sy, sxx, sxy, syy, cell_centre(ox, ix, cell_size), cell_centre(oy, iy, cell_size),
                            fix_scale, min_points, eig_ratio, ra, rb))
       nvalid++;
-#endif
   }
-#if NDT_EXP_GATHER == 7        // the arithmetic runs, zeros are stored
-  if (ra.x != 12345.678f) { ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = ra; }
-#elif NDT_EXP_GATHER == 8      // no arithmetic, non-zero records are stored
-  if (in_grid && s_n[slot] >= 3u) { ra = make_float4((float)sx_dbg, 2.f, 3.f, 4.f); rb = make_float4(5.f, 6.f, (float)s_n[slot], 0.f); }
-#endif
   NDT_STAMP(4);
   // Write-back in whole lines.  A lane that stores its own cell's 48-byte sums and 32-byte record writes 16-byte
   // pieces 48 / 32 bytes apart: a third / a half of every line per instruction, and the 80 KB of a tile took 15 us to
@@ -483,14 +550,14 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(const float2* __
   }
   NDT_STAMP(5);
   block_count_add(counters, nvalid, nover);       // one add per workgroup, sharded (ndt_device.hpp)
-#if defined(NDT_EXP_GATHER) && NDT_EXP_GATHER == 9
+#if defined(NDT_BUILD_PHASE_CLOCKS)
   if (lane == 0) g_gather_wave_end[blockIdx.x & 1023][wave] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
 }  // namespace ndt
 
-#if defined(NDT_EXP_GATHER) && NDT_EXP_GATHER == 9
+#if defined(NDT_BUILD_PHASE_CLOCKS)
 extern "C" int ndt_exp_read_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ndt::g_gather_stamps), sizeof(ndt::g_gather_stamps));
 }

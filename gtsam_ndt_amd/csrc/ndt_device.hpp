@@ -50,6 +50,13 @@ __device__ __forceinline__ double read_lane63(double v) {
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) { return read_lane63(wave_sum_lane63(v)); }
 
+// exact integer sum over the wave, in every lane (cold paths)
+__device__ __forceinline__ unsigned int wave_sum_u32(unsigned int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += (unsigned int)__shfl_xor((int)v, m, 64);
+  return v;
+}
+
 // min / max over the wave via xor shuffles (cold path: bounds kernel only)
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll

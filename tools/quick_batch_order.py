@@ -39,5 +39,23 @@ stx, sty = sort_by_bearing(t["tx"], t["ty"])
 ssx, ssy = sort_by_bearing(t["sx"], t["sy"])
 r1 = run(stx, sty, ssx, ssy, "sorted by bearing   ")
 r2 = run(t["tx"], t["ty"], ssx, ssy, "source sorted only  ")
+
+
+def sort_by_cell(x, y, cell=0.5, tile=None):
+    """The upper bound for an in-kernel counting sort of the source by cell: sources sorted by the
+    row-major key of the 0.5 m cell they fall in under the initial pose (identity here: config 4 starts at zero)."""
+    xs, ys = x.view(n_pairs, npts), y.view(n_pairs, npts)
+    ix = torch.floor((xs - xs.min(dim=1, keepdim=True).values) / cell).to(torch.int64)
+    iy = torch.floor((ys - ys.min(dim=1, keepdim=True).values) / cell).to(torch.int64)
+    if tile:
+        ix, iy = ix // tile, iy // tile
+    order = torch.argsort(iy * 4096 + ix, dim=1, stable=True)
+    return torch.gather(xs, 1, order).reshape(-1).contiguous(), torch.gather(ys, 1, order).reshape(-1).contiguous()
+
+
+csx, csy = sort_by_cell(t["sx"], t["sy"])
+r3 = run(t["tx"], t["ty"], csx, csy, "source sorted by cell (row-major)      ")
+bsx, bsy = sort_by_cell(t["sx"], t["sy"], tile=8)
+r4 = run(t["tx"], t["ty"], bsx, bsy, "source sorted by 8 x 8-cell block only ")
 err = max(np.abs(np.array(a.pose) - np.array(b.pose)).max() for a, b in zip(r0, r1))
 print("max pose difference between the orders (float32 summation order):", err)

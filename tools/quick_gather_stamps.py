@@ -1,8 +1,8 @@
-"""Scratch: per-phase clocks of k_tile_gather (needs tools/bin/libndt_gather9.so: -DNDT_EXP_GATHER=9)."""
+"""Scratch: per-phase clocks of k_tile_gather (needs tools/bin/libndt_phase_clocks.so: -DNDT_BUILD_PHASE_CLOCKS)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["NDT_HIP_LIB"] = os.path.join(ROOT, "tools", "bin", "libndt_gather9.so")
+os.environ["NDT_HIP_LIB"] = os.path.join(ROOT, "tools", "bin", "libndt_phase_clocks.so")
 import numpy as np, torch
 from gtsam_ndt_amd import synth, _lib
 from gtsam_ndt_amd.matcher import NdtMatcher2D
