@@ -148,6 +148,46 @@ def single_pair_rate(dev, dev_index, cfg: int, steps: int, warmup: int, n_src: i
             "frac_of_8TBps": round(alg / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
 
 
+def build_legs(m, tx, ty, sx, sy, pose, reps: int = 30):
+    """The step in front of the path: ndt2d_set_target_dev of the 1M-point submap and
+    ndt2d_add_target_points_dev of the 100k-point scan moved into the map frame by a pose (a front end pays one of them per
+    scan).  Host call to return, and the GPU-side span by HIP events on the handle's stream (first kernel's start to the end
+    of the counters' read-back: kernels + launch boundaries + a 136-byte copy).  Roofline numerator = SURVEY 8d's B_grid:
+    8 B per point + 24 B per cell of the grid (for the update: the cells of the tiles the scan touches are not known to
+    the host, so its figure counts the points only)."""
+    st = torch.cuda.ExternalStream(m.stream)
+
+    def timed(fn):
+        host, span = [], []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(st); fn(); e1.record(st)
+            host.append(time.perf_counter() - t0)
+            e1.synchronize()
+            span.append(e0.elapsed_time(e1))
+        return 1e3 * float(np.median(host[3:])), float(np.median(span[3:]))
+
+    info = m.set_target(tx, ty)
+    h_ms, g_ms = timed(lambda: m.set_target(tx, ty))
+    n_t, cells = int(tx.numel()), int(info.width) * int(info.height)
+    b_grid = 8 * n_t + 24 * cells
+    grid = {"workload": f"ndt2d_set_target_dev: {n_t} points -> {info.width} x {info.height} cells of 0.5 m ({info.n_valid} valid)",
+            "ms_per_call": round(h_ms, 4), "gpu_span_us": round(1e3 * g_ms, 2),
+            "kernels": "k_bounds_parts -> k_chunk_sort (geometry in its prologue) -> k_tile_gather",
+            "roofline": {"bound": "hbm", "algorithmic_bytes": b_grid, "bytes_rule": "SURVEY 8d B_grid = 8 B x points + 24 B x cells",
+                         "achieved": round(b_grid / (g_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(b_grid / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "timing": "HIP events on the handle's stream around the call (three kernels, their boundaries and the read-back)"}}
+    h_ms, g_ms = timed(lambda: m.add_target_points(sx, sy, pose=pose))
+    n_s = int(sx.numel())
+    upd = {"workload": f"ndt2d_add_target_points_dev: a {n_s}-point scan moved by a pose and merged into the {n_t}-point submap "
+                       "(exact: the grid equals a rebuild from all points)",
+           "ms_per_call": round(h_ms, 4), "gpu_span_us": round(1e3 * g_ms, 2), "kernels": "k_chunk_sort (motion fused) -> k_tile_gather",
+           "algorithmic_GBps": round(8 * n_s / (g_ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(8 * n_s / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    return grid, upd
+
+
 def multi_start_rate(dev_index, tx, ty, sx, sy, init, m: int, steps: int, warmup: int):
     """ndt2d_align_multi_start_dev on the headline pair: m starts around the initial guess carried by one
     launch chain, fixed K iterations each (every start bit-identical to its single-start alignment).
@@ -851,10 +891,9 @@ def main():
         tx, ty, sx, sy = (torch.from_numpy(d[k]).to(dev) for k in ("tx", "ty", "sx", "sy"))
         torch.cuda.synchronize()
         m = NdtMatcher2D(device=dev_index, fixed_iterations=K_GN)
-        tg = []
-        for _ in range(5):
-            t0 = time.perf_counter(); m.set_target(tx, ty); tg.append(time.perf_counter() - t0)
-        grid_ms = 1e3 * float(np.median(tg[1:]))
+        grid_build, submap_update = build_legs(m, tx, ty, sx, sy, d["pose"])
+        grid_ms = grid_build["ms_per_call"]
+        m.set_target(tx, ty)                   # (the timed alignments run against the plain 1M-point submap again)
         n_src = int(sx.numel())
 
         def step():
@@ -925,6 +964,9 @@ def main():
                        "gn_iterations_per_step": K_GN, "hessian": "gauss-newton"},
             "roofline": roofline,
             "grid_build_ms": round(grid_ms, 4),
+            "grid_build": grid_build,
+            "submap_update": submap_update,
+            "submap_update_ms": submap_update["ms_per_call"],
             "converged_align": None if rc is None else {"ms_per_call": None if conv_ms is None else round(conv_ms, 4), "iterations": rc.iterations,
                                 "note": "ndt2d_align_dev in converged mode, host call to result in host memory "
                                         "(8-launch chunks, progress and done flag written to pinned host memory); median of 20",

@@ -124,6 +124,7 @@ SIGNATURES = {
     "ndt_status_string": (C.c_char_p, [C.c_int32]),
     "ndt_last_error": (C.c_char_p, []),
     "ndt_device_count": (C.c_int32, []),
+    "ndt_set_host_wait": (C.c_int32, [C.c_int32]),
     "ndt2d_default_params": (None, [C.POINTER(Params2D)]),
     "ndt2d_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),
     "ndt2d_destroy": (C.c_int32, [_vp]),

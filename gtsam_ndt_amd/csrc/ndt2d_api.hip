@@ -797,6 +797,12 @@ const char* ndt_status_string(int32_t s) {
 
 const char* ndt_last_error(void) { return last_error().c_str(); }
 
+int32_t ndt_set_host_wait(int32_t mode) {
+  if (mode != 0 && mode != 1) return NDT_ERR_INVALID_ARG;
+  ndt::host_wait_mode().store(mode, std::memory_order_relaxed);
+  return NDT_OK;
+}
+
 int32_t ndt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

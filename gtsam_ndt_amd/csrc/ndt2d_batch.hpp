@@ -664,12 +664,29 @@ __global__ __launch_bounds__(Cfg::kThreads) void k_batch(BatchArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(BatchGlobal::kThreads) void k_batch_fallback(BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  for (int pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
-    if (__builtin_amdgcn_readfirstlane(a.fb_marks[pair]) != 0) {              // uniform
-      if (threadIdx.x == 0 && a.fb_seen) __hip_atomic_fetch_add(a.fb_seen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      process_pair<MODE, BatchGlobal>(a, pair, smem);
-      __syncthreads();
-      __threadfence();                                // the next pair rewrites this workgroup's slab
+  // Workgroup b owns the pairs b, b + gridDim.x, ...; its threads read their marks side by side (one dependent scalar
+  // load per pair cost 13 us on the 8 workgroups a context starts with, with nothing marked) and process the marked
+  // ones in turn.
+  int* const fb_any = reinterpret_cast<int*>(smem + BatchGlobal::kLdsMisc) + 15;                     // (a word of the carve no pair uses: the carve fills the CU's LDS)
+  const int owned = (a.n_pairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // pairs of this workgroup
+  for (int base = 0; base < owned; base += (int)blockDim.x) {
+    if (threadIdx.x == 0) *fb_any = 0;
+    __syncthreads();
+    const int j = base + (int)threadIdx.x;
+    const bool mine = j < owned && a.fb_marks[(size_t)blockIdx.x + (size_t)j * gridDim.x] != 0;
+    if (mine) *fb_any = 1;                                // benign race: every writer stores 1
+    __syncthreads();
+    const int any = __builtin_amdgcn_readfirstlane(*fb_any);       // uniform
+    __syncthreads();                                      // (process_pair rewrites the carve)
+    const int last = base + (int)blockDim.x < owned ? base + (int)blockDim.x : owned;
+    for (int jj = base; jj < (any ? last : base); ++jj) {
+      const int pair = (int)blockIdx.x + jj * (int)gridDim.x;
+      if (__builtin_amdgcn_readfirstlane(a.fb_marks[pair]) != 0) {            // uniform
+        if (threadIdx.x == 0 && a.fb_seen) __hip_atomic_fetch_add(a.fb_seen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        process_pair<MODE, BatchGlobal>(a, pair, smem);
+        __syncthreads();
+        __threadfence();                                  // the next pair rewrites this workgroup's slab
+      }
     }
   }
 }

@@ -4,6 +4,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
+#include <atomic>
 #include <string>
 
 #include "ndt_dyn.hpp"
@@ -200,13 +203,24 @@ inline hipError_t chunk_run_begin(ChunkRun& r, hipGraphExec_t exec, hipStream_t 
 // the middle of an alignment, which made an earlier version of this loop return a state a few
 // chunks short of convergence - about one alignment in a hundred with eight busy host threads,
 // tools/soak_threads.py.)  Returns hipSuccess with *ok = ready(), or the stream's error.
+// How a host thread waits for a flag in pinned memory (ndt_set_host_wait): 0 = spin on the core (default: an
+// alignment takes 60-300 us, shorter than a sleep's granularity), 1 = spin for the first ~20 us of a wait, then give the
+// core away between polls (sched_yield) - for a SLAM process that drives several handles from several threads on
+// fewer cores than threads.  Process-wide; results do not depend on it.
+inline std::atomic<int>& host_wait_mode() {
+  static std::atomic<int> mode{0};
+  return mode;
+}
+
 template <class Ready>
 inline hipError_t spin_until(hipStream_t stream, Ready&& ready, bool* ok) {
   unsigned long spins = 0;
   int syncs = 0;
+  const bool yielding = host_wait_mode().load(std::memory_order_relaxed) == 1;
   for (;;) {
     if (ready()) { *ok = true; return hipSuccess; }
-    __builtin_ia32_pause();                              // a polite spin: yields the core's issue slots to its sibling thread
+    if (yielding && spins > 2048) sched_yield();
+    else __builtin_ia32_pause();                         // a polite spin: yields the core's issue slots to its sibling thread
     if ((++spins & 0xfffff) != 0) continue;
     const hipError_t q = hipStreamQuery(stream);
     if (q != hipSuccess && q != hipErrorNotReady) { *ok = false; return q; }

@@ -124,6 +124,11 @@ const char* ndt_status_string(int32_t status);
 const char* ndt_last_error(void);
 /* number of visible HIP devices (0 when there is none; never fails) */
 int32_t ndt_device_count(void);
+/* How a host thread waits for an alignment's end flag (pinned host memory).  0 (default): it spins on its core - a
+ * call takes 60-300 us, less than a sleep's granularity.  1: it spins for the first ~20 us of a wait and then gives the
+ * core away between polls (sched_yield) - for a process that drives several handles from more threads than it has
+ * cores.  Process-wide, takes effect at the next wait; results do not depend on it. */
+int32_t ndt_set_host_wait(int32_t mode);
 
 void ndt2d_default_params(ndt2d_params* p);
 int32_t ndt2d_create(const ndt2d_params* p, int32_t device_id, ndt2d_handle** out);

@@ -122,3 +122,43 @@ def test_3d_contexts_on_four_threads(gpu_lib):
         t.join(timeout=300)
     assert not errs, repr(errs)
     assert not bad, bad
+
+
+def test_yielding_host_wait_gives_the_same_results(gpu_lib):
+    """ndt_set_host_wait(1): waiting host threads give their core away between polls instead of spinning (a SLAM process
+    with more matcher threads than cores).  Eight threads on eight handles, converged alignments: every result equals the
+    spinning default's, bit for bit."""
+    import threading
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    lib = L.load()
+    assert lib.ndt_set_host_wait(2) == L.NDT_ERR_INVALID_ARG
+    d = synth.make_pair(2, n_tgt=40_000, n_src=20_000)
+    with NdtMatcher2D() as m:
+        m.set_target(d["tx"], d["ty"])
+        want = m.align(d["sx"], d["sy"], d["init"])
+    assert want.status == 0
+    bad, errs = [], []
+
+    def work(k):
+        try:
+            with NdtMatcher2D() as m:
+                m.set_target(d["tx"], d["ty"])
+                for rep in range(40):
+                    r = m.align(d["sx"], d["sy"], d["init"])
+                    if not (r.pose == want.pose and r.iterations == want.iterations and r.status == 0):
+                        bad.append((k, rep))
+        except Exception as e:
+            errs.append(e)
+
+    assert lib.ndt_set_host_wait(1) == 0
+    try:
+        th = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+    finally:
+        assert lib.ndt_set_host_wait(0) == 0
+    assert not errs, repr(errs)
+    assert not bad, bad

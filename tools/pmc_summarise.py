@@ -93,6 +93,16 @@ if ba:
 if b3:
     summary["k_batch3"] = dict(b3, pairs=256, algorithmic_bytes=256 * 131072 * 12 * 31)
     summary["batch3_bytes_per_launch"] = b3["read_bytes"] + b3["write_bytes"]
+# the grid build (round 3: k_bounds_parts -> k_chunk_sort -> k_tile_gather).  The profiled command builds the 1M-point
+# config-3 submap (ndt2d_set_target_dev) and merges the 100k-point scan into it (ndt2d_add_target_points_dev) the same
+# number of times, so k_chunk_sort / k_tile_gather averages mix the two; the per-call split is in the kernel trace.
+gb = {}
+for name in ("k_bounds_parts", "k_chunk_sort<16>", "k_chunk_sort<4>", "k_tile_gather"):
+    t = traffic(name)
+    if t:
+        gb[name] = t
+if gb:
+    summary["grid_build_kernels"] = gb
 with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
     json.dump(summary, f, indent=1)
 
