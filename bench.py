@@ -152,7 +152,7 @@ def build_legs(m, tx, ty, sx, sy, pose, reps: int = 30):
     """The step in front of the path: ndt2d_set_target_dev of the 1M-point submap and
     ndt2d_add_target_points_dev of the 100k-point scan moved into the map frame by a pose (a front end pays one of them per
     scan).  Host call to return, and the GPU-side span by HIP events on the handle's stream (first kernel's start to the end
-    of the counters' read-back: kernels + launch boundaries + a 136-byte copy).  Roofline numerator = SURVEY 8d's B_grid:
+    of the one-wave kernel that publishes the counters to pinned host memory: kernels + launch boundaries).  Roofline numerator = SURVEY 8d's B_grid:
     8 B per point + 24 B per cell of the grid (for the update: the cells of the tiles the scan touches are not known to
     the host, so its figure counts the points only)."""
     st = torch.cuda.ExternalStream(m.stream)
@@ -178,7 +178,7 @@ def build_legs(m, tx, ty, sx, sy, pose, reps: int = 30):
             "roofline": {"bound": "hbm", "algorithmic_bytes": b_grid, "bytes_rule": "SURVEY 8d B_grid = 8 B x points + 24 B x cells",
                          "achieved": round(b_grid / (g_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(b_grid / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "timing": "HIP events on the handle's stream around the call (three kernels, their boundaries and the read-back)"}}
+                         "timing": "HIP events on the handle's stream around the call (three kernels, their boundaries and the one-wave publish kernel)"}}
     h_ms, g_ms = timed(lambda: m.add_target_points(sx, sy, pose=pose))
     n_s = int(sx.numel())
     upd = {"workload": f"ndt2d_add_target_points_dev: a {n_s}-point scan moved by a pose and merged into the {n_t}-point submap "

@@ -70,6 +70,7 @@ struct ndt2d_handle {
   unsigned char* d_acc2 = nullptr;
   int acc_parity = 0;
   bool acc_clean = false;                  // both halves known to be zero where the next build needs it
+  int publish_seq = 0;                     // k_build_publish's flag value of the build in flight (h_small + 192)
   // hipGraph of the launch chain (launch-bound inner loop: one replay instead of K+1 launches)
   ChainGraphCache graphs;
   hipGraphExec_t graph_exec = nullptr;     // the one ensure_graph selected last (owned by `graphs`)
@@ -258,6 +259,25 @@ int launch_bounds_parts(ndt2d_handle* h, const float* d_x, const float* d_y, siz
   return nb;
 }
 
+// The read-back of a sorted build: k_build_publish writes `nwords` words from device memory into pinned host memory and
+// raises the flag at h_small + 192; the host spins on it.  If the flag does not come (a stream error, or a second of
+// silence), a plain copy after a stream synchronisation is the safety net.
+int32_t publish_and_wait(ndt2d_handle* h, const void* d_src, void* h_dst, int nwords) {
+  int* flag = reinterpret_cast<int*>(static_cast<char*>(h->h_small) + 192);
+  h->publish_seq = h->publish_seq == 0x7fffffff ? 1 : h->publish_seq + 1;
+  hipLaunchKernelGGL(k_build_publish, dim3(1), dim3(64), 0, h->stream, (const unsigned int*)d_src, (unsigned int*)h_dst, nwords, flag,
+                     h->publish_seq);
+  HIP_TRY(hipGetLastError());
+  bool seen = false;
+  const int want = h->publish_seq;
+  HIP_TRY(spin_until(h->stream, [&]() { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want; }, &seen));
+  if (!seen) {
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)nwords * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return NDT_OK;
+}
+
 // a2 + a3 for n points: binned LDS build when the tile histogram fits in LDS (always, below
 // ~2.9 km x 2.9 km at 0.5 m cells), else scattered global atomics + k_finalise.  merge = add to
 // the cached sums (incremental submap update) instead of starting from zero.
@@ -297,8 +317,7 @@ int32_t accumulate_and_finalise(ndt2d_handle* h, const float* d_x, const float* 
     int* hc = (int*)h->h_small;
     unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 128);
     static_assert(ndt::kCountInts * sizeof(int) == 128, "the accumulator halves mirror h_small: counters at 0, outside at 128");
-    HIP_TRY(hipMemcpyAsync(hc, cur, 136, hipMemcpyDeviceToHost, h->stream));        // counter shards and outside count in one copy
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    { const int32_t ps = publish_and_wait(h, cur, hc, 34); if (ps != NDT_OK) return ps; }   // counter shards + outside count
     h->acc_parity ^= 1;
     h->acc_clean = true;
     int n_valid_sum = 0, n_over_sum = 0;
@@ -499,8 +518,8 @@ int32_t set_target_single_sync(ndt2d_handle* h, const float* d_x, const float* d
   }
   HIP_TRY(hipGetLastError());
   GeomDev* hg = h->h_geom;
-  HIP_TRY(hipMemcpyAsync(hg, dg, sizeof(GeomDev), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  static_assert(sizeof(GeomDev) % 4 == 0, "GeomDev travels to the host word by word");
+  { const int32_t ps = publish_and_wait(h, dg, hg, (int)(sizeof(GeomDev) / 4)); if (ps != NDT_OK) return ps; }
   const int* hc = hg->counters;
   for (int j = 0; j < 4; ++j) hb_out[j] = hg->bounds[j];
   *have_bounds = true;

@@ -555,6 +555,17 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(const float2* __
 #endif
 }
 
+// The end of a build on the host's side: the build's few result words (counter shards, outside count; the device-decided
+// geometry) go straight into pinned host memory and a flag follows them - the host spins on the flag (as the alignments
+// do) instead of paying a copy launch and a stream synchronisation's wake-up for 136 bytes.  One wave.
+__global__ __launch_bounds__(64) void k_build_publish(const unsigned int* __restrict__ src, unsigned int* __restrict__ host_dst,
+                                                       int nwords, int* __restrict__ host_flag, int seq) {
+  for (int i = threadIdx.x; i < nwords; i += 64) __hip_atomic_store(host_dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace ndt
 
 #if defined(NDT_BUILD_PHASE_CLOCKS)
