@@ -15,7 +15,8 @@ struct ndt3d_handle {
   bool has_target = false;
   int n_valid = 0;
   unsigned int* d_bounds = nullptr;   // [6]
-  int* d_counters = nullptr;          // [2]
+  int* d_counters = nullptr;          // counter shards of ndt3d_load_map's finalise (the builds keep theirs in d_tiles)
+  int publish_seq = 0;                // k_build_publish's flag value of the build in flight (h_small + 192)
   void* h_small = nullptr;            // pinned 256 B (counter shards at 0, the outside count at 128)
   float *d_t[3] = {nullptr, nullptr, nullptr}; size_t tcap = 0;
   float *d_b[3] = {nullptr, nullptr, nullptr}; size_t bcap = 0;      // binned build scratch
@@ -78,53 +79,68 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
   using namespace ndt;
   Grid3Dev& g = h->grid;
   const size_t ncell = (size_t)g.W * g.H * g.D;
-  HIP_TRY(hipMemsetAsync(h->d_outside, 0, sizeof(unsigned long long), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, ndt::kCountInts * sizeof(int), h->stream));
   const int ntx = (g.W + (1 << kT3x) - 1) >> kT3x, nty = (g.H + (1 << kT3y) - 1) >> kT3y, ntz = (g.D + (1 << kT3z) - 1) >> kT3z;
   const long long ntile_ll = (long long)ntx * nty * ntz;
-  if (ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull) {
+  const bool binned = ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull;
+  const int ntile = binned ? (int)ntile_ll : 0;
+  // One block of device words carries everything a build adds into, so that ONE fill launch clears it (round 2: four) and
+  // one publish brings the results back:  counter shards [32] | outside count (u64) | pad to 64 | tile totals [ntile] |
+  // tickets of the shared tiles [ntile] | tile starts [ntile + 1] | scatter cursors [ntile]
+  const size_t tneed = 64 + 4 * (size_t)ntile + 4;
+  if (tneed > h->tile_cap) {
+    if (h->d_tiles) (void)hipFree(h->d_tiles);
+    h->d_tiles = nullptr; h->tile_cap = 0;
+    HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
+    h->tile_cap = tneed;
+  }
+  int* d_cnt = reinterpret_cast<int*>(h->d_tiles);
+  unsigned long long* d_out = reinterpret_cast<unsigned long long*>(h->d_tiles + 32);
+  unsigned int* d_total = h->d_tiles + 64;
+  unsigned int* d_ticket = d_total + ntile;
+  unsigned int* d_start = d_ticket + ntile;
+  unsigned int* d_cursor = d_start + ntile + 1;
+  HIP_TRY(hipMemsetAsync(h->d_tiles, 0, (64 + 2 * (size_t)ntile) * sizeof(unsigned int), h->stream));
+  if (binned) {
     // binned build (ndt3d_build.hpp)
-    const int ntile = (int)ntile_ll;
     int32_t st = ensure3(h->d_b, &h->bcap, n);
     if (st != NDT_OK) return st;
-    const size_t tneed = 4 * (size_t)ntile + 4;          // total | start (+1) | cursor | tickets of the shared tiles
-    if (tneed > h->tile_cap) {
-      if (h->d_tiles) (void)hipFree(h->d_tiles);
-      h->d_tiles = nullptr; h->tile_cap = 0;
-      HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
-      h->tile_cap = tneed;
-    }
-    unsigned int* d_total = h->d_tiles;
-    unsigned int* d_start = h->d_tiles + ntile;
-    unsigned int* d_cursor = h->d_tiles + 2 * ntile + 1;
     const BinGeom3 bg{g.ox, g.oy, g.oz, g.inv_c, g.W, g.H, g.D, ntx, nty, ntile};
     size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
     if (nb > 1024) nb = 1024;
-    HIP_TRY(hipMemsetAsync(d_total, 0, ntile * sizeof(unsigned int), h->stream));
     hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
-                       dz, n, bg, d_total, h->d_outside);
+                       dz, n, bg, d_total, d_out);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, (const GeomDev*)nullptr);
     hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
                        dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2]);
-    unsigned int* d_ticket = h->d_tiles + 3 * ntile + 1;
-    HIP_TRY(hipMemsetAsync(d_ticket, 0, ntile * sizeof(unsigned int), h->stream));
     if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));      // shared tiles add into the sums
     hipLaunchKernelGGL(k_tile_accumulate3, dim3(ntile, kTile3Split), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1],
-                       h->d_b[2], d_start, g, ntx, nty, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, h->d_counters, d_ticket);
+                       h->d_b[2], d_start, g, ntx, nty, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, d_cnt, d_ticket);
     HIP_TRY(hipGetLastError());
   } else {
     if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));
-    hipLaunchKernelGGL(k_accumulate3, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, g, h->d_outside);
+    hipLaunchKernelGGL(k_accumulate3, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, g, d_out);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_finalise3, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, g,
-                       h->prm.min_points, h->prm.eig_ratio, h->d_counters);
+                       h->prm.min_points, h->prm.eig_ratio, d_cnt);
     HIP_TRY(hipGetLastError());
   }
+  // counter shards and outside count to the host through pinned memory and a flag (k_build_publish, as the 2D build)
   int* hc = (int*)h->h_small;
   unsigned long long* ho = (unsigned long long*)((char*)h->h_small + 128);
-  HIP_TRY(hipMemcpyAsync(hc, h->d_counters, ndt::kCountInts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(ho, h->d_outside, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  {
+    int* flag = reinterpret_cast<int*>(static_cast<char*>(h->h_small) + 192);
+    h->publish_seq = h->publish_seq == 0x7fffffff ? 1 : h->publish_seq + 1;
+    hipLaunchKernelGGL(k_build_publish, dim3(1), dim3(64), 0, h->stream, (const unsigned int*)h->d_tiles, (unsigned int*)hc, 34, flag,
+                       h->publish_seq);
+    HIP_TRY(hipGetLastError());
+    bool seen = false;
+    const int want = h->publish_seq;
+    HIP_TRY(spin_until(h->stream, [&]() { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want; }, &seen));
+    if (!seen) {
+      HIP_TRY(hipMemcpyAsync(hc, h->d_tiles, 136, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+  }
   if (h_outside) *h_outside = *ho;
   int n_valid_sum = 0, n_over_sum = 0;
   sum_count_shards(hc, &n_valid_sum, &n_over_sum);
