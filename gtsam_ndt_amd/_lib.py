@@ -171,6 +171,7 @@ SIGNATURES = {
     "ndt2d_multi_align": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ndt2d_multi_align_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ndt2d_multi_plan": (C.c_int32, [C.c_int32, _vp, _vp, C.c_size_t, C.c_int32, _vp]),
+    "ndt2d_multi_plan_hinted": (C.c_int32, [C.c_int32, _vp, _vp, C.c_size_t, C.c_int32, _vp, _vp]),
     "ndt3d_default_params": (None, [C.POINTER(Params2D)]),
     "ndt3d_create": (C.c_int32, [C.POINTER(Params2D), C.c_int32, C.POINTER(_vp)]),
     "ndt3d_destroy": (C.c_int32, [_vp]),

@@ -208,6 +208,16 @@ __global__ __launch_bounds__(kSortThreads) void k_chunk_sort(const float* __rest
   constexpr int C = kSortThreads * P;
   static_assert(C <= 4096, "start and length of a run are 16-bit fields");
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  // the chunk's points are requested first: they do not depend on the geometry, and the loads fly while the prologue
+  // below reduces the partial boxes and decides the grid
+  float px[P], py[P];
+  const size_t base = (size_t)blockIdx.x * C;
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const size_t i = base + (size_t)u * kSortThreads + threadIdx.x;
+    px[u] = i < n ? x[i] : NAN;
+    py[u] = i < n ? y[i] : NAN;
+  }
   if (ga.parts) {                                          // geometry decided here (see GeomArgs)
     __shared__ BinGeom s_bin;
     __shared__ int s_ok;
@@ -242,16 +252,8 @@ __global__ __launch_bounds__(kSortThreads) void k_chunk_sort(const float* __rest
 #endif
   for (int t = threadIdx.x; t < g.ntile; t += kSortThreads) s_hist[t] = 0u;
   __syncthreads();
-  float px[P], py[P];
   int tile[P];
   unsigned int rank[P];
-  const size_t base = (size_t)chunk * C;
-#pragma unroll
-  for (int u = 0; u < P; ++u) {
-    const size_t i = base + (size_t)u * kSortThreads + threadIdx.x;
-    px[u] = i < n ? x[i] : NAN;
-    py[u] = i < n ? y[i] : NAN;
-  }
   unsigned int outside = 0;
 #pragma unroll
   for (int u = 0; u < P; ++u) {

@@ -131,12 +131,17 @@ int32_t ndt2d_multi_device_count(const ndt2d_multi* m) { return m ? static_cast<
 
 // shard_begin[d] .. shard_begin[d+1] = the pairs device slot d would receive for these offsets
 // (exposed so a caller can pre-place data, and so the split is testable without devices)
-int32_t ndt2d_multi_plan(int32_t n_shards, const uint64_t* toff, const uint64_t* soff, size_t n_pairs,
-                         int32_t iterations_hint, uint64_t* shard_begin) {
+int32_t ndt2d_multi_plan_hinted(int32_t n_shards, const uint64_t* toff, const uint64_t* soff, size_t n_pairs,
+                                int32_t iterations_hint, const int32_t* pair_iterations, uint64_t* shard_begin) {
   if (n_shards <= 0 || !toff || !soff || !shard_begin) return NDT_ERR_INVALID_ARG;
   const double kk = iterations_hint > 0 ? iterations_hint : 30;
-  // work of a pair = its target points once (grid build) + its source points per iteration
-  auto work = [&](size_t k) { return 3.0 * double(toff[k + 1] - toff[k]) + kk * double(soff[k + 1] - soff[k]) + 1.0; };
+  // work of a pair = its target points once (grid build: three passes) + its source points per iteration; the
+  // iterations from the caller's per-pair hint where it gives one (converged-mode batches: what the candidate took at
+  // the coarser level, or last time), else the common hint
+  auto work = [&](size_t k) {
+    const double it = pair_iterations && pair_iterations[k] > 0 ? (double)pair_iterations[k] : kk;
+    return 3.0 * double(toff[k + 1] - toff[k]) + it * double(soff[k + 1] - soff[k]) + 1.0;
+  };
   double total = 0;
   for (size_t k = 0; k < n_pairs; ++k) {
     if (toff[k + 1] < toff[k] || soff[k + 1] < soff[k]) return NDT_ERR_INVALID_ARG;
@@ -152,6 +157,11 @@ int32_t ndt2d_multi_plan(int32_t n_shards, const uint64_t* toff, const uint64_t*
     shard_begin[d] = d == n_shards ? n_pairs : k;
   }
   return NDT_OK;
+}
+
+int32_t ndt2d_multi_plan(int32_t n_shards, const uint64_t* toff, const uint64_t* soff, size_t n_pairs,
+                         int32_t iterations_hint, uint64_t* shard_begin) {
+  return ndt2d_multi_plan_hinted(n_shards, toff, soff, n_pairs, iterations_hint, nullptr, shard_begin);
 }
 
 int32_t ndt2d_multi_align(ndt2d_multi* m, const float* tx, const float* ty, const uint64_t* toff,

@@ -320,14 +320,22 @@ def _concat_pairs(targets, sources, inits):
     return n, tx, ty, toff, sx, sy, soff, init
 
 
-def multi_plan(n_shards: int, toff, soff, iterations_hint: int = 0) -> np.ndarray:
-    """The pair split ndt2d_multi_align uses (ndt2d_multi_plan; needs no device)."""
+def multi_plan(n_shards: int, toff, soff, iterations_hint: int = 0, pair_iterations=None) -> np.ndarray:
+    """The pair split ndt2d_multi_align uses (ndt2d_multi_plan; needs no device).  pair_iterations: optional per-pair
+    iteration hints (ndt2d_multi_plan_hinted) for converged-mode batches."""
     lib = L.load()
     toff = np.ascontiguousarray(toff, dtype=np.uint64)
     soff = np.ascontiguousarray(soff, dtype=np.uint64)
-    begin = np.zeros(max(n_shards, 0) + 1, dtype=np.uint64)
-    L.check(lib.ndt2d_multi_plan(int(n_shards), toff.ctypes.data, soff.ctypes.data, len(toff) - 1,
-                                 int(iterations_hint), begin.ctypes.data), "ndt2d_multi_plan")
+    begin = np.zeros(int(n_shards) + 1, dtype=np.uint64)
+    if pair_iterations is None:
+        L.check(lib.ndt2d_multi_plan(int(n_shards), toff.ctypes.data, soff.ctypes.data, len(toff) - 1,
+                                     int(iterations_hint), begin.ctypes.data), "ndt2d_multi_plan")
+    else:
+        hints = np.ascontiguousarray(pair_iterations, dtype=np.int32)
+        if hints.shape != (len(toff) - 1,):
+            raise ValueError("pair_iterations needs one entry per pair")
+        L.check(lib.ndt2d_multi_plan_hinted(int(n_shards), toff.ctypes.data, soff.ctypes.data, len(toff) - 1,
+                                            int(iterations_hint), hints.ctypes.data, begin.ctypes.data), "ndt2d_multi_plan_hinted")
     return begin
 
 

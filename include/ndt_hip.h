@@ -401,6 +401,11 @@ int32_t ndt2d_multi_align_dev(ndt2d_multi* m, const float* const* d_tx, const fl
  * source points (iterations_hint <= 0: 30).  Needs no device. */
 int32_t ndt2d_multi_plan(int32_t n_shards, const uint64_t* toff, const uint64_t* soff, size_t n_pairs,
                          int32_t iterations_hint, uint64_t* shard_begin);
+/* The same split with a per-pair work hint (pairs of a converged-mode batch need different numbers
+ * of iterations - 14 to 53 in this repository's tests): pair_iterations[k] > 0 replaces iterations_hint for pair k
+ * (NULL: ndt2d_multi_plan).  For callers that place device-resident shards themselves (ndt2d_multi_align_dev). */
+int32_t ndt2d_multi_plan_hinted(int32_t n_shards, const uint64_t* toff, const uint64_t* soff, size_t n_pairs,
+                                int32_t iterations_hint, const int32_t* pair_iterations, uint64_t* shard_begin);
 
 /* ---- 3D NDT, SE(3) (BASELINE config 5) ----------------------- */
 /* Same pipeline in 3D: dense voxel grid with per-cell mean / 3x3 covariance (eigenvalue clamp

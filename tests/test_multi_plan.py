@@ -85,3 +85,24 @@ def test_plan_properties_hold_for_random_inputs(ndt_lib):
             assert work[b[d]: b[d + 1]].sum() <= share + work.max() + 1e-6
 
     check()
+
+
+def test_per_pair_iteration_hints_move_the_split(ndt_lib):
+    """ndt2d_multi_plan_hinted: equal clouds, but the first quarter of the candidates needs 50 iterations and the rest 15 -
+    the shards balance the hinted work, not the pair count; without hints the split is even."""
+    n = 128
+    toff = _offsets([2000] * n)
+    soff = _offsets([2000] * n)
+    hints = np.array([50] * 32 + [15] * 96, dtype=np.int32)
+    even = M.multi_plan(4, toff, soff, 30).astype(np.int64)
+    assert np.diff(even).tolist() == [32, 32, 32, 32]
+    b = M.multi_plan(4, toff, soff, 30, pair_iterations=hints).astype(np.int64)
+    assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) > 0)
+    work = 3.0 * 2000 + hints * 2000.0 + 1.0
+    per = [work[b[d]: b[d + 1]].sum() for d in range(4)]
+    assert max(per) - min(per) <= 2 * work.max()
+    assert b[1] < 24                                   # the heavy candidates are spread over more than one shard
+    zero = M.multi_plan(4, toff, soff, 30, pair_iterations=np.zeros(n, np.int32))     # hint 0 = "no hint for this pair"
+    assert np.array_equal(zero.astype(np.int64), even)
+    with pytest.raises(ValueError):
+        M.multi_plan(4, toff, soff, 30, pair_iterations=hints[:5])
