@@ -17,6 +17,7 @@ struct ndt3d_handle {
   unsigned int* d_bounds = nullptr;   // [6]
   int* d_counters = nullptr;          // counter shards of ndt3d_load_map's finalise (the builds keep theirs in d_tiles)
   int publish_seq = 0;                // k_build_publish's flag value of the build in flight (h_small + 192)
+  float* d_parts3 = nullptr;          // [256][8]: per-workgroup partial bounding boxes (k_bounds3_parts)
   void* h_small = nullptr;            // pinned 256 B (counter shards at 0, the outside count at 128)
   float *d_t[3] = {nullptr, nullptr, nullptr}; size_t tcap = 0;
   float *d_b[3] = {nullptr, nullptr, nullptr}; size_t bcap = 0;      // binned build scratch
@@ -190,13 +191,28 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
   TraceRange range("ndt3d_set_target: voxel grid build");
   h->has_target = false;
   unsigned int* hb = (unsigned int*)h->h_small;
-  for (int a = 0; a < 3; ++a) { hb[2 * a] = 0xFFFFFFFFu; hb[2 * a + 1] = 0u; }
-  HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, 24, hipMemcpyHostToDevice, h->stream));
-  const int sb = stream_blocks(n) > kBoundsBlocks ? kBoundsBlocks : stream_blocks(n);   // few blocks: each ends in six atomics on the same six words
-  hipLaunchKernelGGL(k_bounds3, dim3(sb), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_bounds);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, 24, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  {
+    // bounding box: one partial per workgroup, then one wave reduces them into pinned host memory and raises a flag
+    if (!h->d_parts3) HIP_TRY(hipMalloc((void**)&h->d_parts3, 256 * 8 * sizeof(float)));
+    int sb = stream_blocks(n);
+    if (sb > 256) sb = 256;
+    int* flag = reinterpret_cast<int*>(static_cast<char*>(h->h_small) + 192);
+    h->publish_seq = h->publish_seq == 0x7fffffff ? 1 : h->publish_seq + 1;
+    hipLaunchKernelGGL(k_bounds3_parts, dim3(sb), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_parts3);
+    hipLaunchKernelGGL(k_bounds3_publish, dim3(1), dim3(64), 0, h->stream, (const float*)h->d_parts3, sb, hb, flag, h->publish_seq);
+    HIP_TRY(hipGetLastError());
+    bool seen = false;
+    const int want = h->publish_seq;
+    HIP_TRY(spin_until(h->stream, [&]() { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want; }, &seen));
+    if (!seen) {                                           // safety net: the atomic form with a copy each way
+      for (int a = 0; a < 3; ++a) { hb[2 * a] = 0xFFFFFFFFu; hb[2 * a + 1] = 0u; }
+      HIP_TRY(hipMemcpyAsync(h->d_bounds, hb, 24, hipMemcpyHostToDevice, h->stream));
+      hipLaunchKernelGGL(k_bounds3, dim3(sb > kBoundsBlocks ? kBoundsBlocks : sb), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_bounds);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(hb, h->d_bounds, 24, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+  }
   if (hb[0] == 0xFFFFFFFFu || hb[1] == 0u) { set_error("target has no finite point"); return NDT_ERR_INVALID_ARG; }
   float lo[3], hi[3];
   for (int a = 0; a < 3; ++a) { lo[a] = ordered_to_float(hb[2 * a]); hi[a] = ordered_to_float(hb[2 * a + 1]); }
@@ -415,7 +431,7 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   (void)finish_align3(h);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->graphs.clear();
-  void* dev[] = {h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
+  void* dev[] = {h->d_parts3, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
                  h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->grid.rec, h->grid.acc, h->d_dyn_multi};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag, h->h_state_multi};

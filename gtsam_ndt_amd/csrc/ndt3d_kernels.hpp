@@ -144,6 +144,66 @@ __global__ __launch_bounds__(kBlock) void k_bounds3(const float* __restrict__ x,
   }
 }
 
+// [r3] The same without same-line atomics and without a copy in either direction: one partial box per workgroup (plain
+// stores), then one wave reduces the partials and writes the six ordered bounds straight into pinned host memory, a flag
+// behind them (the host spins on it, as for the alignments).  k_bounds3's six atomics per workgroup all land on ONE
+// 64-byte line and serialise at the memory side: 128 workgroups x 6 x ~10 ns were most of its 12 us.
+__global__ __launch_bounds__(kBlock) void k_bounds3_parts(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ z, size_t n, float* __restrict__ parts /*[grid][8]*/) {
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += 4 * stride) {          // four points in flight
+    float p[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t ii = i + u * stride;
+      p[u][0] = ii < n ? x[ii] : NAN; p[u][1] = ii < n ? y[ii] : NAN; p[u][2] = ii < n ? z[ii] : NAN;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (isfinite(p[u][0]) && isfinite(p[u][1]) && isfinite(p[u][2])) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], p[u][a]); mx[a] = fmaxf(mx[a], p[u][a]); }
+      }
+  }
+  __shared__ float s_b[kBlock / 64][6];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]);
+    if ((threadIdx.x & 63) == 0) { s_b[wave][2 * a] = mn[a]; s_b[wave][2 * a + 1] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < 3; ++a) {
+      for (int w = 1; w < kBlock / 64; ++w) { mn[a] = fminf(mn[a], s_b[w][2 * a]); mx[a] = fmaxf(mx[a], s_b[w][2 * a + 1]); }
+      parts[8 * blockIdx.x + 2 * a] = mn[a];
+      parts[8 * blockIdx.x + 2 * a + 1] = mx[a];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bounds3_publish(const float* __restrict__ parts, int nparts, unsigned int* __restrict__ host_out /*[6]*/,
+                                                         int* __restrict__ host_flag, int seq) {
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < nparts; i += 64) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], parts[8 * i + 2 * a]); mx[a] = fmaxf(mx[a], parts[8 * i + 2 * a + 1]); }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const bool none = !(mn[a] <= mx[a]);                 // no finite point: k_bounds3's "empty" encoding
+      __hip_atomic_store(host_out + 2 * a, none ? 0xFFFFFFFFu : float_to_ordered(mn[a]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host_out + 2 * a + 1, none ? 0u : float_to_ordered(mx[a]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---------------------------------------------------------------------------- accumulate
 __global__ __launch_bounds__(kBlock) void k_accumulate3(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ z, size_t n, Grid3Dev g,

@@ -115,7 +115,7 @@ if sq_path:
             per[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     sq = {}
     for k, cs in per.items():
-        if not any(t in k for t in ("k_iterate", "k_batch", "k_align_small", "k_tile")):
+        if not any(t in k for t in ("k_iterate", "k_batch", "k_align_small", "k_tile", "k_chunk_sort", "k_bounds_parts")):
             continue
         e = {c: sum(v) / len(v) for c, v in cs.items()}
         e["dispatches"] = len(next(iter(cs.values())))
