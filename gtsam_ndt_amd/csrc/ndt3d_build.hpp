@@ -181,12 +181,16 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
         for (int j = 0; j < 6; ++j) atomicAdd(reinterpret_cast<unsigned long long*>(&a->ss[j]), s_sum[3 + j][c]);
       }
     }
-    __threadfence();
+    // [r3] No fences: everything handed over is written with agent-scope atomic adds (performed at the memory side, never
+    // in this CU's L1 or this XCD's L2) and read back with agent-scope atomic loads, so all the hand-off needs is that
+    // every wave's adds have completed before the workgroup's ticket is taken (MI355X_MICROARCH.md "Valid forms": agent
+    // atomics on both sides).  A __threadfence() here is a write-back AND an invalidate of the whole L2, in all 256
+    // threads, twice per shared workgroup: 5-7 us of the fullest tiles' critical path.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(&tile_ticket[tile], 1u) == (unsigned)(nsub - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;                             // uniform
-    __threadfence();
     // the last of the tile's workgroups: every share is in the grid's sums - read them back for the finalise below
     for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
       const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
