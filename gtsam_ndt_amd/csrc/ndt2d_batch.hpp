@@ -223,8 +223,13 @@ constexpr int kBatchMaxCloud = 1 << 29;   // points per cloud of a pair: byte of
 // One pair, start to finish, on the calling workgroup.  Early outs are plain returns: the
 // caller's queue loop then has a single back edge (with `continue`s inside the loop body
 // hipcc's loop restructuring produced a kernel that re-read the same queue slot forever).
-template <int MODE, class Cfg>
+// NG = 4: Biber's four overlapping grids (every grid shifted by half a cell against the others, the terms of all four
+// summed: k_iterate's NG, oracle/ndt2d.py build_grids) - on the global-table variant only: on chip four grids would
+// quarter the capacity to 71 x 71 cells, less than a config-4 room.  The four grids lie back to back in the tables
+// (cell q * W * H + key, slots handed out in that order); one extra column and row, as on the single-pair path.
+template <int MODE, class Cfg, int NG = 1>
 __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair, unsigned char* smem) {
+  static_assert(NG == 1 || (NG == 4 && Cfg::kGlobalTables), "overlapping grids: global-table variant only");
   using IdxT = typename Cfg::IdxT;
   using KeyT = typename Cfg::KeyT;
   // the grid tables: LDS, or this workgroup's slab of global memory
@@ -308,10 +313,15 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
           ox = (float)((floor((double)xmin / a.cell) - 1.0) * a.cell);
           oy = (float)((floor((double)ymin / a.cell) - 1.0) * a.cell);
           const float kx = floorf((xmax - ox) * inv_c), ky = floorf((ymax - oy) * inv_c);
-          if (!(kx >= 0.f) || !(ky >= 0.f) || (double)(kx + 2.f) * (double)(ky + 2.f) > (double)Cfg::kMaxCells) {
+          constexpr float kExtent = NG > 1 ? 3.f : 2.f;        // overlapping grids: one extra column and row
+          if (!(kx >= 0.f) || !(ky >= 0.f) || (double)(kx + kExtent) * (double)(ky + kExtent) * NG > (double)Cfg::kMaxCells) {
             st = kStatusCapacity;
           } else {
-            W = (int)kx + 2; H = (int)ky + 2;
+            W = (int)kx + (int)kExtent; H = (int)ky + (int)kExtent;
+          }
+          if (NG > 1) {                                        // the origins moved down by half a cell
+            reinterpret_cast<float*>(misc)[11] = (float)((floor((double)xmin / a.cell) - 1.5) * a.cell);
+            reinterpret_cast<float*>(misc)[12] = (float)((floor((double)ymin / a.cell) - 1.5) * a.cell);
           }
         }
         misc[1] = W; misc[2] = H; misc[3] = st;
@@ -323,9 +333,17 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     const int W = __builtin_amdgcn_readfirstlane(misc[1]), Hh = __builtin_amdgcn_readfirstlane(misc[2]);
     int status = __builtin_amdgcn_readfirstlane(misc[3]);
     const float ox = uniformf(reinterpret_cast<float*>(misc)[4]), oy = uniformf(reinterpret_cast<float*>(misc)[5]);
+    // grid q's origin: (ox, oy), (ox - c/2, oy), (ox, oy - c/2), (ox - c/2, oy - c/2)
+    float gxq[NG], gyq[NG];
+    gxq[0] = ox; gyq[0] = oy;
+    if constexpr (NG > 1) {
+      const float oxs = uniformf(reinterpret_cast<float*>(misc)[11]), oys = uniformf(reinterpret_cast<float*>(misc)[12]);
+      gxq[1] = oxs; gyq[1] = oy; gxq[2] = ox; gyq[2] = oys; gxq[3] = oxs; gyq[3] = oys;
+    }
     const float inv_c = (float)(1.0 / a.cell);
     const float fWm1 = (float)(W - 1), fHm1 = (float)(Hh - 1);
-    const int ncell = W * Hh;
+    const int ncell1 = W * Hh;                       // cells of one grid
+    const int ncell = NG * ncell1;                   // ... of the tables
     const double fix_scale = 4194304.0 / a.cell;     // 2^kFixShift / c
     static_assert(kFixShift == 22, "fix_scale literal");
     __syncthreads();                                 // misc is rewritten below
@@ -351,10 +369,13 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
         for (int k = tid; k < np; k += Cfg::kThreads) pc[k] = 0u;
         __syncthreads();
         for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
-          const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
-          if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
-            const int r = (int)fy * W + (int)fx - c0;
-            if ((unsigned)r < (unsigned)np) atomicAdd(&pc[r], 1u);
+#pragma unroll
+          for (int q = 0; q < NG; ++q) {
+            const float fx = (px - gxq[q]) * inv_c, fy = (py - gyq[q]) * inv_c;
+            if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
+              const int r = q * ncell1 + (int)fy * W + (int)fx - c0;
+              if ((unsigned)r < (unsigned)np) atomicAdd(&pc[r], 1u);
+            }
           }
         });
         __syncthreads();
@@ -402,6 +423,11 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
       return;
     }
     for (int k = c0; k < c1; ++k) {
+      if constexpr (NG > 1) {                            // the first slot of grids 1, 2, 3 (the slots of a grid are consecutive)
+        if (k == ncell1) misc[7] = s;
+        else if (k == 2 * ncell1) misc[13] = s;
+        else if (k == 3 * ncell1) misc[14] = s;
+      }
       const unsigned int n = cell_count(k);              // read before idx[k] is overwritten (same thread, same k)
       if (n >= (unsigned)minpts) {
         idx[k] = (IdxT)(s + 1);
@@ -422,19 +448,22 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
         for (int j = tid; j < 5 * np; j += Cfg::kThreads) ps[j] = 0ull;
         __syncthreads();
         for_each_target_point<Cfg>(tx, ty, nt, [&](float px, float py) {
-          const float fx = (px - ox) * inv_c, fy = (py - oy) * inv_c;
-          if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
-            const int ix = (int)fx, iy = (int)fy;
-            const int r = (int)idx[iy * W + ix] - 1 - s0;               // slot 0 (no record) gives r < 0
-            if ((unsigned)r < (unsigned)np) {
-              const int ux = fix_coord(px, cell_centre(ox, ix, a.cell), fix_scale);
-              const int uy = fix_coord(py, cell_centre(oy, iy, a.cell), fix_scale);
-              unsigned long long* q = ps + r;
-              atomicAdd(q, (unsigned long long)(long long)ux);
-              atomicAdd(q + np, (unsigned long long)(long long)uy);
-              atomicAdd(q + 2 * np, prod64(ux, ux));
-              atomicAdd(q + 3 * np, prod64(ux, uy));
-              atomicAdd(q + 4 * np, prod64(uy, uy));
+#pragma unroll
+          for (int q = 0; q < NG; ++q) {
+            const float fx = (px - gxq[q]) * inv_c, fy = (py - gyq[q]) * inv_c;
+            if ((fx >= 1.f) & (fx < fWm1) & (fy >= 1.f) & (fy < fHm1)) {   // ring cells stay empty (in_interior)
+              const int ix = (int)fx, iy = (int)fy;
+              const int r = (int)idx[q * ncell1 + iy * W + ix] - 1 - s0;    // slot 0 (no record) gives r < 0
+              if ((unsigned)r < (unsigned)np) {
+                const int ux = fix_coord(px, cell_centre(gxq[q], ix, a.cell), fix_scale);
+                const int uy = fix_coord(py, cell_centre(gyq[q], iy, a.cell), fix_scale);
+                unsigned long long* w = ps + r;
+                atomicAdd(w, (unsigned long long)(long long)ux);
+                atomicAdd(w + np, (unsigned long long)(long long)uy);
+                atomicAdd(w + 2 * np, prod64(ux, ux));
+                atomicAdd(w + 3 * np, prod64(ux, uy));
+                atomicAdd(w + 4 * np, prod64(uy, uy));
+              }
             }
           }
         });
@@ -474,14 +503,21 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     if constexpr (Cfg::kGlobalTables) {
       int nvalid = 0;
       for (int sl = tid; sl < nslot; sl += Cfg::kThreads) {
-        const int key = (int)slot_key[sl];
+        int key = (int)slot_key[sl];
         const int n = (int)slot_n[sl];
+        float cox = ox, coy = oy;                      // the origin of the grid the cell belongs to
+        if constexpr (NG > 1) {
+          const int q = key / ncell1;
+          key -= q * ncell1;
+          cox = (q & 1) ? gxq[1] : ox;
+          coy = (q & 2) ? gyq[2] : oy;
+        }
         float4 ra, rb;
         const bool ok = n <= (int)kMaxCellCount &&
                         finalise_sums(n, (long long)sums[sl], (long long)sums[sl + Cfg::kMaxSlots],
                                       (long long)sums[sl + 2 * Cfg::kMaxSlots], (long long)sums[sl + 3 * Cfg::kMaxSlots],
-                                      (long long)sums[sl + 4 * Cfg::kMaxSlots], cell_centre(ox, key % W, a.cell),
-                                      cell_centre(oy, key / W, a.cell), fix_scale, a.min_points, a.eig_ratio, ra, rb);
+                                      (long long)sums[sl + 4 * Cfg::kMaxSlots], cell_centre(cox, key % W, a.cell),
+                                      cell_centre(coy, key / W, a.cell), fix_scale, a.min_points, a.eig_ratio, ra, rb);
         if (!ok) { ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = make_float4(0.f, 0.f, 0.f, 0.f); }
         recA[sl + 1] = ra; recB[sl + 1] = rb;
         nvalid += ok ? 1 : 0;
@@ -535,6 +571,31 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
     // line-search state lives in LDS so that it is not held in registers across the point loop
     LineSearch* ls_lds = reinterpret_cast<LineSearch*>(smem + Cfg::kLdsLs);
     if (tid == 0) { ls_lds->valid = 0; ls_lds->trials = 0; }
+    // Overlapping grids: the four grids TAKE TURNS on chip.  Per iteration and grid the grid's slice of the index table
+    // (as u16 local slots) and its records are copied from the slab into the LDS the build's passes used, and the
+    // source streams past them as in the on-chip variants - four streams of the source per iteration (L2-resident)
+    // instead of three dependent gathers through L2 per point and grid (measured 56 ms per config-4 pair that way,
+    // against 1.6 ms for one grid on chip).  A grid too large for that keeps the gathers.
+    bool turns = false;
+    unsigned short* lidx = nullptr;
+    float4 *lrecA = nullptr, *lrecB = nullptr;
+    if constexpr (NG > 1) {
+      const int b1 = __builtin_amdgcn_readfirstlane(misc[7]), b2 = __builtin_amdgcn_readfirstlane(misc[13]),
+                b3 = __builtin_amdgcn_readfirstlane(misc[14]);
+      int n_max = b1;
+      n_max = b2 - b1 > n_max ? b2 - b1 : n_max;
+      n_max = b3 - b2 > n_max ? b3 - b2 : n_max;
+      n_max = nslot - b3 > n_max ? nslot - b3 : n_max;
+      const int idx_bytes = (2 * ncell1 + 15) & ~15;
+      turns = n_max + 1 <= 0xffff && (long long)idx_bytes + 32ll * (n_max + 1) <= 40ll * Cfg::kPassSlots;      // uniform
+      lidx = reinterpret_cast<unsigned short*>(smem + Cfg::kLdsPass);
+      lrecA = reinterpret_cast<float4*>(smem + Cfg::kLdsPass + idx_bytes);
+      lrecB = lrecA + (n_max + 1);
+      __syncthreads();                               // (every wave has read the bases before s_scan is rewritten)
+      if (tid == 0) { s_scan[0] = 0; s_scan[1] = b1; s_scan[2] = b2; s_scan[3] = b3; s_scan[4] = nslot; }
+      __threadfence();                               // the records were stored to the slab by other waves of this workgroup
+      __syncthreads();
+    }
     for (;;) {
       float acc[kNumAcc];
       {
@@ -572,20 +633,72 @@ __device__ __forceinline__ void process_pair(const BatchArgs& a, const int pair,
         };
         auto consume_set = [&](int base, const float* xs, const float* ys) {
           PointRec r[kBatchUnroll];
+          if constexpr (NG == 1) {
 #pragma unroll
-          for (int u = 0; u < kBatchUnroll; ++u)
-            lookup_point_lds(P, idx, recA, recB, xs[u], ys[u], (base + u * Cfg::kThreads) < ns, r[u]);
+            for (int u = 0; u < kBatchUnroll; ++u)
+              lookup_point_lds(P, idx, recA, recB, xs[u], ys[u], (base + u * Cfg::kThreads) < ns, r[u]);
 #pragma unroll
-          for (int u = 0; u < kBatchUnroll; ++u) accumulate_point<MODE>(P, r[u], A);
-        };
-        if (ns > 0) {                                  // uniform; an empty source must not touch sx[-1]
-          load_set(tid, xa, ya);
-          for (int i = tid; i < ns; i += 2 * kTrip) {
-            load_set(i + kTrip, xb, yb);
-            consume_set(i, xa, ya);
-            load_set(i + 2 * kTrip, xa, ya);
-            if (i + kTrip < ns) consume_set(i + kTrip, xb, yb);     // wave-uniform except at the tail
+            for (int u = 0; u < kBatchUnroll; ++u) accumulate_point<MODE>(P, r[u], A);
+          } else {                                     // the same image point scores against every grid
+#pragma unroll
+            for (int u = 0; u < kBatchUnroll; ++u) image_point(P, xs[u], ys[u], r[u]);
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+#pragma unroll
+              for (int u = 0; u < kBatchUnroll; ++u) {
+                const int slot = idx[q * ncell1 + image_key(P, gxq[q], gyq[q], r[u], (base + u * Cfg::kThreads) < ns)];
+                r[u].A = recA[slot];
+                r[u].B = recB[slot];
+              }
+#pragma unroll
+              for (int u = 0; u < kBatchUnroll; ++u) accumulate_point<MODE>(P, r[u], A);
+            }
           }
+        };
+        auto stream_source = [&](auto&& consume) {
+          if (ns > 0) {                                // uniform; an empty source must not touch sx[-1]
+            load_set(tid, xa, ya);
+            for (int i = tid; i < ns; i += 2 * kTrip) {
+              load_set(i + kTrip, xb, yb);
+              consume(i, xa, ya);
+              load_set(i + 2 * kTrip, xa, ya);
+              if (i + kTrip < ns) consume(i + kTrip, xb, yb);       // wave-uniform except at the tail
+            }
+          }
+        };
+        if constexpr (NG > 1) {
+          if (turns) {                                 // uniform
+#pragma unroll 1
+            for (int q = 0; q < NG; ++q) {
+              __syncthreads();                         // the lookups of the grid before are done
+              const int b0 = __builtin_amdgcn_readfirstlane(s_scan[q]), nq = __builtin_amdgcn_readfirstlane(s_scan[q + 1]) - b0;
+              const IdxT* gi = idx + q * ncell1;
+              for (int k = tid; k < ncell1; k += Cfg::kThreads) {
+                const unsigned int v = gi[k];
+                lidx[k] = (unsigned short)(v ? v - (unsigned)b0 : 0u);
+              }
+              for (int j = tid; j <= nq; j += Cfg::kThreads) {      // record 0: the dummy
+                lrecA[j] = j ? recA[b0 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                lrecB[j] = j ? recB[b0 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+              __syncthreads();
+              PoseF Pq = P;
+              Pq.ox = (q & 1) ? gxq[1] : ox;
+              Pq.oy = (q & 2) ? gyq[2] : oy;
+              stream_source([&](int base, const float* xs, const float* ys) {
+                PointRec r[kBatchUnroll];
+#pragma unroll
+                for (int u = 0; u < kBatchUnroll; ++u)
+                  lookup_point_lds(Pq, lidx, lrecA, lrecB, xs[u], ys[u], (base + u * Cfg::kThreads) < ns, r[u]);
+#pragma unroll
+                for (int u = 0; u < kBatchUnroll; ++u) accumulate_point<MODE>(Pq, r[u], A);
+              });
+            }
+          } else {
+            stream_source(consume_set);
+          }
+        } else {
+          stream_source(consume_set);
         }
         acc_store(A, a.prm.d2, acc);
         acc[11] = 0.f;
@@ -661,7 +774,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void k_batch(BatchArgs a) {
 // Third variant: the pairs the large variant handed over (fb_marks), tables in global memory.  No
 // queue: workgroup b looks at pairs b, b + gridDim.x, ... (one scalar load each; with nothing handed
 // over the launch costs a few microseconds).
-template <int MODE>
+template <int MODE, int NG = 1>
 __global__ __launch_bounds__(BatchGlobal::kThreads) void k_batch_fallback(BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Workgroup b owns the pairs b, b + gridDim.x, ...; its threads read their marks side by side (one dependent scalar
@@ -683,7 +796,7 @@ __global__ __launch_bounds__(BatchGlobal::kThreads) void k_batch_fallback(BatchA
       const int pair = (int)blockIdx.x + jj * (int)gridDim.x;
       if (__builtin_amdgcn_readfirstlane(a.fb_marks[pair]) != 0) {            // uniform
         if (threadIdx.x == 0 && a.fb_seen) __hip_atomic_fetch_add(a.fb_seen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        process_pair<MODE, BatchGlobal>(a, pair, smem);
+        process_pair<MODE, BatchGlobal, NG>(a, pair, smem);
         __syncthreads();
         __threadfence();                                  // the next pair rewrites this workgroup's slab
       }

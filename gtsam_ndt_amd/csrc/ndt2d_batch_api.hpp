@@ -107,6 +107,20 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
     a.prm.step_max_trans = p.step_max_trans; a.prm.step_max_rot = p.step_max_rot;
     a.prm.step_scale = p.step_scale > 0.0 ? p.step_scale : 1.0;
     const bool newton = p.hessian_mode == NDT_HESSIAN_NEWTON;
+    const int blocks_fb = (int)(n_pairs < (size_t)b->global_blocks ? n_pairs : (size_t)b->global_blocks);
+    if (p.overlap_grids == 4) {
+      // Biber's four overlapping grids: every pair of this level goes to the global-table variant (process_pair's NG),
+      // so every pair is marked for it (any non-zero word is a mark)
+      HIP_TRY(hipMemsetAsync(b->d_fb_list, 1, n_pairs * sizeof(int), st));
+      a.marks = nullptr;
+      a.queue = b->d_queue + 1;
+      if (newton)
+        hipLaunchKernelGGL((ndt::k_batch_fallback<1, 4>), dim3(blocks_fb), dim3(ndt::BatchGlobal::kThreads), ndt::BatchGlobal::kLdsBytes, st, a);
+      else
+        hipLaunchKernelGGL((ndt::k_batch_fallback<0, 4>), dim3(blocks_fb), dim3(ndt::BatchGlobal::kThreads), ndt::BatchGlobal::kLdsBytes, st, a);
+      HIP_TRY(hipGetLastError());
+      continue;
+    }
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 16, st));
     HIP_TRY(hipMemsetAsync(b->d_fb_list, 0, n_pairs * sizeof(int), st));
     a.marks = nullptr;
@@ -128,7 +142,6 @@ int32_t batch_launch(ndt2d_batch* b, const float* d_tx, const float* d_ty, const
       hipLaunchKernelGGL((ndt::k_batch<0, ndt::BatchLarge>), dim3(blocks), dim3(ndt::kBatchThreads), ndt::kBatchLdsBytes, st, a);
     HIP_TRY(hipGetLastError());
     // pairs whose grid does not fit on chip (handed over through fb_marks): tables in global memory
-    const int blocks_fb = (int)(n_pairs < (size_t)b->global_blocks ? n_pairs : (size_t)b->global_blocks);
     if (newton)
       hipLaunchKernelGGL((ndt::k_batch_fallback<1>), dim3(blocks_fb), dim3(ndt::BatchGlobal::kThreads), ndt::BatchGlobal::kLdsBytes, st, a);
     else
@@ -177,8 +190,9 @@ int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels,
   for (int32_t i = 0; i < n_levels; ++i) {
     const int32_t st = check_params(&levels[i]);
     if (st != NDT_OK) return st;
-    if (levels[i].overlap_grids == 4) { set_error("overlapping grids are implemented on the single-pair path only"); return NDT_ERR_INVALID_ARG; }
   }
+  bool any_overlap = false;
+  for (int32_t i = 0; i < n_levels; ++i) any_overlap = any_overlap || levels[i].overlap_grids == 4;
   const ndt2d_params* p = &levels[n_levels - 1];
   const int ndev = ndt_device_count();
   if (ndev <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return NDT_ERR_NO_DEVICE; }
@@ -194,6 +208,8 @@ int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels,
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(NDT_ERR_HIP);
   b->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(NDT_ERR_HIP);
+  // a level with overlapping grids runs EVERY pair on the global-table variant: one table slab per CU from the start
+  if (any_overlap) b->global_blocks = b->n_cu < ndt::kBatchGlobalBlocks ? b->n_cu : ndt::kBatchGlobalBlocks;
   if (hipMalloc((void**)&b->d_queue, 16) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipMalloc((void**)&b->d_slab, (size_t)b->global_blocks * ndt::BatchGlobal::kTabBytes) != hipSuccess) return fail(NDT_ERR_ALLOC);
   if (hipHostMalloc((void**)&b->h_fb_seen, 64, hipHostMallocDefault) != hipSuccess) return fail(NDT_ERR_ALLOC);
@@ -210,6 +226,10 @@ int32_t ndt2d_batch_create_pyramid(const ndt2d_params* levels, int32_t n_levels,
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch_fallback<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::BatchGlobal::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch_fallback<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::BatchGlobal::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch_fallback<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          ndt::BatchGlobal::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ndt::k_batch_fallback<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           ndt::BatchGlobal::kLdsBytes) != hipSuccess) return fail(NDT_ERR_HIP);
   *out = b;
   return NDT_OK;
@@ -308,12 +328,13 @@ int32_t ndt2d_batch_align(ndt2d_batch* b, const float* tx, const float* ty, cons
   if (st != NDT_OK) return st;
   HIP_TRY(hipMemcpyAsync(results, b->d_out, n_pairs * sizeof(ndt2d_result), hipMemcpyDeviceToHost, s));
   std::vector<int> marks;
-  if (b->use_small) {
+  const bool small_ran = b->use_small && b->levels.back().overlap_grids != 4;     // (an overlapping-grids level runs neither on-chip variant)
+  if (small_ran) {
     marks.resize(n_pairs);
     HIP_TRY(hipMemcpyAsync(marks.data(), b->d_marks, n_pairs * sizeof(int), hipMemcpyDeviceToHost, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
-  b->last_large = b->use_small ? 0 : (int64_t)n_pairs;
+  b->last_large = small_ran ? 0 : (int64_t)n_pairs;
   for (int m : marks) b->last_large += m != 0;
   // pairs whose grid does not fit the on-chip capacity go through the global-memory path
   for (size_t k = 0; k < n_pairs; ++k) {

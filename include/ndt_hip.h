@@ -68,7 +68,8 @@ typedef struct ndt2d_params {
   double step_max_rot;     /* ... and |dtheta| <= step_max_rot                     */
   int32_t min_hits;        /* fewer hits than this => NDT_TOO_FEW_HITS             */
   int32_t overlap_grids;   /* 0 or 1: one grid; 4: Biber's four grids shifted by half a cell, every
-                              point scores against all four (single-pair 2D path only)  */
+                              point scores against all four (2D: ndt2d_align*, ndt2d_batch_*, ndt2d_multi_*;
+                              not the multi-start / multi-scan chains)  */
   int32_t line_search;     /* 0: plain Gauss-Newton steps.  n in 1..16: backtracking line search - an
                               evaluation that scores worse than the pose its step started from (or
                               leaves the map) halves the step and retries from that pose, at most n
@@ -333,7 +334,12 @@ int32_t ndt2d_polar_to_points_dev(const float* d_ranges, size_t n, double angle_
  * call, to a third variant of the kernel that keeps the pair's tables in global memory (up to 512 x 512
  * cells, 32767 occupied: 256 m x 256 m at 0.5 m cells).  Beyond that a pair gets status
  * NDT_ERR_CAPACITY from the _dev entry point, and the host-pointer entry point re-runs it through the
- * single-pair path transparently. */
+ * single-pair path transparently.
+ * overlap_grids = 4: every pair of such a level runs on that third variant (four grids on chip would quarter
+ * the capacity to 71 x 71 cells), its four grids back to back in the tables: 256 x 256 cells per grid
+ * (128 m x 128 m at 0.5 m cells), 32767 occupied cells over the four; the context then holds one table slab
+ * per CU from creation (0.95 GB).  Results equal ndt2d_align's with the same option up to float32 summation
+ * order (tests/test_gpu_batch_overlap.py). */
 typedef struct ndt2d_batch ndt2d_batch;
 int32_t ndt2d_batch_create(const ndt2d_params* p, int32_t device_id, ndt2d_batch** out);
 /* Coarse-to-fine over the batch (loop-closure candidates start from poor guesses): levels[0..n)

@@ -100,8 +100,9 @@ def test_overlapping_grids_match_oracle(gpu_lib, pair, mode):
     assert r.status == 0 == ref["status"]
     e = np.abs(np.array(r.pose) - np.array(ref["pose"]))
     assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 1e-4
-    with pytest.raises(L.NdtError):
-        NdtBatch2D(overlap_grids=4)
+    with NdtBatch2D(overlap_grids=4, hessian_mode=mode) as b:      # the batch path with the same option (more in test_gpu_batch_overlap.py)
+        rb = b.align([(d["tx"], d["ty"])], [(d["sx"], d["sy"])], [d["init"]])[0]
+    assert rb.status == 0 and np.abs(np.array(rb.pose) - np.array(r.pose)).max() < 2e-5
 
 
 CASES3 = [
