@@ -174,3 +174,18 @@ def test_pyramid_with_an_overlapping_fine_level(gpu_lib, pairs):
         assert np.abs(np.array(r.pose) - np.array(pose)).max() < 5e-5
         assert abs(r.iterations - total) <= 3
         assert np.abs(np.array(r.pose) - np.array(p["pose"])).max() < 0.02      # and it is the right basin
+
+
+def test_multi_device_contexts_with_overlapping_grids(gpu_lib, pairs):
+    """ndt2d_multi_* (one batch context per device entry; two on device 0 here) with the option: bit for bit one context's results."""
+    from gtsam_ndt_amd import matcher as M
+    T = [(p["tx"], p["ty"]) for p in pairs[:5]]
+    S = [(p["sx"], p["sy"]) for p in pairs[:5]]
+    I = [p["init"] for p in pairs[:5]]
+    with M.NdtBatch2D(overlap_grids=4) as b:
+        ref = b.align(T, S, I)
+    with M.NdtMulti2D(devices=[0, 0], overlap_grids=4) as mm:
+        out = mm.align(T, S, I)
+    for a, r in zip(out, ref):
+        assert a.status == r.status == 0 and a.iterations == r.iterations and a.n_hit == r.n_hit
+        assert a.pose == r.pose and np.array_equal(a.H, r.H)
