@@ -22,6 +22,7 @@ struct ndt3d_handle {
   float *d_t[3] = {nullptr, nullptr, nullptr}; size_t tcap = 0;
   float *d_b[3] = {nullptr, nullptr, nullptr}; size_t bcap = 0;      // binned build scratch
   unsigned int* d_tiles = nullptr; size_t tile_cap = 0;
+  unsigned char* d_split3 = nullptr; size_t split3_cap = 0;   // shared tiles' hand-off (ndt3d_build.hpp Split3Bufs): part table | slab pool
   float *d_s[3] = {nullptr, nullptr, nullptr}; size_t scap = 0;
   ndt::AlignStatic3* d_static = nullptr;
   ndt::AlignCall3* d_call = nullptr;
@@ -87,7 +88,9 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
   // One block of device words carries everything a build adds into, so that ONE fill launch clears it (round 2: four) and
   // one publish brings the results back:  counter shards [32] | outside count (u64) | pad to 64 | tile totals [ntile] |
   // tickets of the shared tiles [ntile] | tile starts [ntile + 1] | scatter cursors [ntile]
-  const size_t tneed = 64 + 4 * (size_t)ntile + 4;
+  // | number of (tile, share) workgroups [1] | their list [ntile + n / kTile3SubMin + 1]
+  const size_t wg_bound = (size_t)ntile + n / (size_t)kTile3SubMin + 1;
+  const size_t tneed = 64 + 4 * (size_t)ntile + 4 + 1 + wg_bound;
   if (tneed > h->tile_cap) {
     if (h->d_tiles) (void)hipFree(h->d_tiles);
     h->d_tiles = nullptr; h->tile_cap = 0;
@@ -100,22 +103,43 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
   unsigned int* d_ticket = d_total + ntile;
   unsigned int* d_start = d_ticket + ntile;
   unsigned int* d_cursor = d_start + ntile + 1;
+  unsigned int* d_wgtotal = d_cursor + ntile;
+  unsigned int* d_wgmap = d_wgtotal + 1;
   HIP_TRY(hipMemsetAsync(h->d_tiles, 0, (64 + 2 * (size_t)ntile) * sizeof(unsigned int), h->stream));
   if (binned) {
     // binned build (ndt3d_build.hpp)
     int32_t st = ensure3(h->d_b, &h->bcap, n);
     if (st != NDT_OK) return st;
+    // the shared tiles' slabs: a tile of p > kTile3SubMin points is shared by ceil(p / kTile3SubMin) workgroups, so there
+    // are at most n / SubMin shared tiles and at most 2 n / SubMin slabs
+    Split3Bufs sb{};
+    {
+      const size_t slabs = 2 * (n / (size_t)kTile3SubMin) + 2;
+      const size_t off_pool = ((size_t)ntile * kTile3Split * sizeof(unsigned int) + 15) / 16 * 16;
+      const size_t need = off_pool + slabs * kSlabWords * sizeof(unsigned long long);
+      if (need > h->split3_cap) {
+        if (h->d_split3) (void)hipFree(h->d_split3);
+        h->d_split3 = nullptr; h->split3_cap = 0;
+        HIP_TRY(hipMalloc((void**)&h->d_split3, need + need / 4));
+        h->split3_cap = need + need / 4;
+      }
+      sb.cursor = h->d_tiles + 40;                     // (in the pad of the accumulator block: cleared by the fill above)
+      sb.part = reinterpret_cast<unsigned int*>(h->d_split3);
+      sb.pool = reinterpret_cast<unsigned long long*>(h->d_split3 + off_pool);
+      sb.capacity = (unsigned int)(slabs > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : slabs);
+    }
     const BinGeom3 bg{g.ox, g.oy, g.oz, g.inv_c, g.W, g.H, g.D, ntx, nty, ntile};
     size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
                        dz, n, bg, d_total, d_out);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, (const GeomDev*)nullptr);
+    hipLaunchKernelGGL(k_tile_scan3, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, d_wgtotal, d_wgmap);
     hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
                        dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2]);
-    if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));      // shared tiles add into the sums
-    hipLaunchKernelGGL(k_tile_accumulate3, dim3(ntile, kTile3Split), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1],
-                       h->d_b[2], d_start, g, ntx, nty, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, d_cnt, d_ticket);
+    // (no fill of the grid's sums: the workgroup that finishes a tile writes every voxel's sums, empty ones included)
+    hipLaunchKernelGGL(k_tile_accumulate3, dim3((unsigned)wg_bound), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1],
+                       h->d_b[2], d_start, g, ntx, nty, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, d_cnt, d_ticket, sb,
+                       (const unsigned int*)d_wgtotal, (const unsigned int*)d_wgmap);
     HIP_TRY(hipGetLastError());
   } else {
     if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));
@@ -432,7 +456,7 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->graphs.clear();
   void* dev[] = {h->d_parts3, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
-                 h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->grid.rec, h->grid.acc, h->d_dyn_multi};
+                 h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->d_split3, h->grid.rec, h->grid.acc, h->d_dyn_multi};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag, h->h_state_multi};
   for (void* p : host) if (p) (void)hipHostFree(p);

@@ -95,6 +95,75 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_scatter3(const float* __re
   }
 }
 
+// What the workgroups that share a tile hand to the one that finishes it: every one of them leaves its 64 voxels' sums as
+// a slab in a pool (write-through stores; a cursor hands out the slabs), the last to arrive (a ticket per tile) adds the
+// others' slabs to its own sums.  Round 2 added each share to the grid's sums with ten global atomics per voxel - 640 per
+// workgroup, up to eight workgroups on the same 640 words, performed one after the other at the memory side - and read
+// the totals back; that also needed the grid's sums cleared by a fill launch before every build.
+constexpr int kCopies3 = 8;                                       // private copies of a tile's sums in k_tile_accumulate3's point loop
+constexpr int kSlabWords = 9 * kTile3Cells + kTile3Cells / 2;       // 64-bit words: 9 sums per voxel, then the counts as u32 pairs
+struct Split3Bufs {
+  unsigned int* cursor;            // next free slab (cleared with the build's other accumulators)
+  unsigned int* part;              // [tiles][kTile3Split]: slab index of the tile's workgroup `sub` (0xFFFFFFFF: the pool was full)
+  unsigned long long* pool;        // [capacity][kSlabWords]
+  unsigned int capacity;           // slabs; the host sizes it for 2 n / kTile3SubMin + 2: a tile is shared by ceil(points / SubMin)
+                                   // workgroups and only tiles of more than SubMin points are shared
+};
+
+// workgroups that share a tile of `points` points
+__device__ __forceinline__ int tile3_subs(unsigned int points) {
+  const int nsub = (int)((points + kTile3SubMin - 1) / kTile3SubMin);
+  return nsub < 1 ? 1 : (nsub > kTile3Split ? kTile3Split : nsub);
+}
+
+// Exclusive scan of the tile totals (k_tile_scan) and, beside it, of the workgroups each tile gets: wg_map lists the
+// (tile, share) pairs one after the other - tile | share << 24 - so that k_tile_accumulate3 is launched with one
+// workgroup per entry (at most ntile + n / kTile3SubMin) instead of ntile x kTile3Split, most of which had nothing to
+// do and still had to be dispatched: 2904 workgroups for the 363 tiles of a config-5 scan, the last of them starting
+// 15 us into the kernel (in-kernel clocks).  One workgroup; ntile <= kBinMaxTiles.
+__global__ __launch_bounds__(1024) void k_tile_scan3(const unsigned int* __restrict__ tile_total, unsigned int* __restrict__ tile_start,
+                                                      unsigned int* __restrict__ tile_cursor, int ntile,
+                                                      unsigned int* __restrict__ wg_total, unsigned int* __restrict__ wg_map) {
+  __shared__ unsigned int s_wave[2][16];
+  const int per = (ntile + 1023) / 1024;
+  const int t0 = threadIdx.x * per;
+  unsigned int local = 0, lwg = 0;
+  for (int k = 0; k < per; ++k)
+    if (t0 + k < ntile) { const unsigned int c = tile_total[t0 + k]; local += c; lwg += (unsigned int)tile3_subs(c); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int inc = local, iwg = lwg;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned int v = __shfl_up(inc, d, 64), w = __shfl_up(iwg, d, 64);
+    if (lane >= d) { inc += v; iwg += w; }
+  }
+  if (lane == 63) { s_wave[0][wave] = inc; s_wave[1][wave] = iwg; }
+  __syncthreads();
+  unsigned int base = 0, bwg = 0;
+  for (int w = 0; w < wave; ++w) { base += s_wave[0][w]; bwg += s_wave[1][w]; }
+  unsigned int run = base + inc - local, rwg = bwg + iwg - lwg;
+  for (int k = 0; k < per; ++k) {
+    if (t0 + k < ntile) {
+      const unsigned int c = tile_total[t0 + k];
+      tile_start[t0 + k] = run;
+      tile_cursor[t0 + k] = run;
+      run += c;
+      const int ns = tile3_subs(c);
+      for (int sb = 0; sb < ns; ++sb) wg_map[rwg + sb] = (unsigned int)(t0 + k) | ((unsigned int)sb << 24);
+      rwg += (unsigned int)ns;
+    }
+  }
+  if (threadIdx.x == 1023) { tile_start[ntile] = run; *wg_total = rwg; }
+}
+static_assert(kBinMaxTiles <= (1 << 24) && kTile3Split <= 256, "wg_map packs tile | share << 24");
+
+#if defined(NDT_BUILD_PHASE_CLOCKS)
+__device__ unsigned long long g_tile3_stamps[4096][8];       // tools-only: 100 MHz clock per phase, per workgroup
+#define NDT_STAMP3(k) do { if (threadIdx.x == 0) g_tile3_stamps[blockIdx.x & 4095][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define NDT_STAMP3(k) do { } while (0)
+#endif
+
 // per tile: LDS sums, then the finalise of k_finalise3 (shared device function below)
 __device__ __forceinline__ bool finalise_sums3(const CellAcc3& c, double cx, double cy, double cz, double fix_scale,
                                                int min_points, double eig_ratio, float4& ra, float4& rb, float4& rc);
@@ -104,24 +173,34 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
                                                                    const unsigned int* __restrict__ tile_start, Grid3Dev g,
                                                                    int ntx, int nty, int merge, int min_points,
                                                                    double eig_ratio, int* __restrict__ counters,
-                                                                   unsigned int* __restrict__ tile_ticket) {
+                                                                   unsigned int* __restrict__ tile_ticket, Split3Bufs sb,
+                                                                   const unsigned int* __restrict__ wg_total,
+                                                                   const unsigned int* __restrict__ wg_map) {
+  // The point loop adds into kCopies3 private copies of the tile's sums, chosen by lane: neighbouring points of a scan fall
+  // into the same voxel, so a wave's 64 atomics went to one or two LDS words and were performed one after the other - the
+  // fullest tiles' loops took 12-18 us (in-kernel clocks, tools/quick_tile3_stamps.py) and held up every other workgroup
+  // on their CU's LDS.  With a copy per lane % 8 at most eight lanes meet on a word
+  // (16 copies: 83 KB of LDS, one workgroup per CU - measured no faster).
+  __shared__ __attribute__((aligned(16))) unsigned long long s_part[9 * kTile3Cells * kCopies3];    // [(sum, voxel)][copy]
+  __shared__ unsigned int s_npart[kTile3Cells * kCopies3];
+  __shared__ __attribute__((aligned(16))) unsigned long long s_sum[9][kTile3Cells];
   __shared__ unsigned int s_n[kTile3Cells];
-  __shared__ unsigned long long s_sum[9][kTile3Cells];
   __shared__ int s_last;
-  const int tile = blockIdx.x, sub = blockIdx.y;
+  __shared__ unsigned int s_slab;
+  if (blockIdx.x >= __builtin_amdgcn_readfirstlane(*wg_total)) return;       // (the launch covers the host's bound)
+  const unsigned int entry = __builtin_amdgcn_readfirstlane(wg_map[blockIdx.x]);
+  const int tile = (int)(entry & 0xFFFFFFu), sub = (int)(entry >> 24);
   const int tx0 = (tile % ntx) << kT3x, ty0 = ((tile / ntx) % nty) << kT3y, tz0 = (tile / (ntx * nty)) << kT3z;
   // A lidar scan puts thousands of points into the few tiles around the sensor, and one workgroup per tile left the
   // build waiting for the fullest one.  A tile of more than kTile3SubMin points is shared by up to kTile3Split workgroups
-  // (grid.y): each sums its share in LDS, adds it to the grid's sums with atomics (exact integers: any split gives
-  // the same bits; the host zeroes the sums first unless this is a submap update), and the last one to arrive
-  // finalises the tile.
+  // (grid.y): each sums its share in LDS and leaves it as a slab (Split3Bufs); the last one to arrive adds the slabs up
+  // (exact integers: any split gives the same bits) and finalises the tile.
   const unsigned int p0 = tile_start[tile], p1 = tile_start[tile + 1];
-  int nsub = (int)((p1 - p0 + kTile3SubMin - 1) / kTile3SubMin);
-  nsub = nsub < 1 ? 1 : (nsub > kTile3Split ? kTile3Split : nsub);
-  if (sub >= nsub) return;                           // uniform
+  const int nsub = tile3_subs(p1 - p0);              // (sub < nsub: k_tile_scan3 listed the shares by the same rule)
+  NDT_STAMP3(0);
   const bool split = nsub > 1;
-  // init: zeros, or the cached sums of this tile's voxels (merge = incremental submap update; a shared tile adds
-  // to them in place instead)
+  // init: zeros, or the cached sums of this tile's voxels (merge = incremental submap update; a shared tile's cached
+  // sums are added by the workgroup that finishes it)
   for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
     const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
     CellAcc3 a = {};
@@ -132,7 +211,11 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
 #pragma unroll
     for (int j = 0; j < 6; ++j) s_sum[3 + j][c] = (unsigned long long)a.ss[j];
   }
+  for (int e = threadIdx.x; e < 9 * kTile3Cells * kCopies3; e += kBinThreads) s_part[e] = 0ull;
+  for (int e = threadIdx.x; e < kTile3Cells * kCopies3; e += kBinThreads) s_npart[e] = 0u;
   __syncthreads();
+  NDT_STAMP3(1);
+  const int copy = threadIdx.x & (kCopies3 - 1);
   const unsigned int share = (p1 - p0 + nsub - 1) / nsub;
   const unsigned int q0 = p0 + sub * share, q1 = q0 + share < p1 ? q0 + share : p1;
   // 8 points in flight per thread: a one-point loop pays the memory latency on every trip
@@ -155,59 +238,112 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
         const int uy = fix_coord(py, cell_centre(g.oy, iy, g.cell), g.fix_scale);
         const int uz = fix_coord(pz, cell_centre(g.oz, iz, g.cell), g.fix_scale);
         const int c = ((((iz - tz0) << kT3y) + (iy - ty0)) << kT3x) + (ix - tx0);
-        atomicAdd(&s_n[c], 1u);
-        atomicAdd(&s_sum[0][c], (unsigned long long)(long long)ux);
-        atomicAdd(&s_sum[1][c], (unsigned long long)(long long)uy);
-        atomicAdd(&s_sum[2][c], (unsigned long long)(long long)uz);
-        atomicAdd(&s_sum[3][c], prod64(ux, ux));
-        atomicAdd(&s_sum[4][c], prod64(ux, uy));
-        atomicAdd(&s_sum[5][c], prod64(ux, uz));
-        atomicAdd(&s_sum[6][c], prod64(uy, uy));
-        atomicAdd(&s_sum[7][c], prod64(uy, uz));
-        atomicAdd(&s_sum[8][c], prod64(uz, uz));
+        unsigned long long* w = s_part + c * kCopies3 + copy;
+        constexpr int kS = kTile3Cells * kCopies3;          // stride between the nine sums
+        atomicAdd(&s_npart[c * kCopies3 + copy], 1u);
+        atomicAdd(w, (unsigned long long)(long long)ux);
+        atomicAdd(w + kS, (unsigned long long)(long long)uy);
+        atomicAdd(w + 2 * kS, (unsigned long long)(long long)uz);
+        atomicAdd(w + 3 * kS, prod64(ux, ux));
+        atomicAdd(w + 4 * kS, prod64(ux, uy));
+        atomicAdd(w + 5 * kS, prod64(ux, uz));
+        atomicAdd(w + 6 * kS, prod64(uy, uy));
+        atomicAdd(w + 7 * kS, prod64(uy, uz));
+        atomicAdd(w + 8 * kS, prod64(uz, uz));
       }
     }
   }
   __syncthreads();
+  // the copies -> the tile's sums (every (sum, voxel) word has one owner thread; the cached sums of a merge are in s_sum)
+  for (int e = threadIdx.x; e < 9 * kTile3Cells; e += kBinThreads) {
+    unsigned long long tot = 0ull;
+#pragma unroll
+    for (int k = 0; k < kCopies3; ++k) tot += s_part[e * kCopies3 + ((k + threadIdx.x) & (kCopies3 - 1))];   // (rotated: no two lanes on a bank)
+    (&s_sum[0][0])[e] += tot;
+  }
+  if (threadIdx.x < kTile3Cells) {
+    unsigned int tot = 0u;
+#pragma unroll
+    for (int k = 0; k < kCopies3; ++k) tot += s_npart[threadIdx.x * kCopies3 + ((k + threadIdx.x) & (kCopies3 - 1))];
+    s_n[threadIdx.x] += tot;
+  }
+  __syncthreads();
+  NDT_STAMP3(2);
+  int nover = 0;
   if (split) {
-    for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
-      const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
-      if (s_n[c] != 0u && ix < g.W && iy < g.H && iz < g.D) {
-        CellAcc3* a = &g.acc[((size_t)iz * g.H + iy) * g.W + ix];
-        atomicAdd(&a->n, s_n[c]);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) atomicAdd(reinterpret_cast<unsigned long long*>(&a->s[j]), s_sum[j][c]);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) atomicAdd(reinterpret_cast<unsigned long long*>(&a->ss[j]), s_sum[3 + j][c]);
-      }
+    // [r3] No fences (MI355X_MICROARCH.md "Valid forms"): every handed-over word is stored write-through (agent-scope
+    // atomic stores) and loaded with agent-scope loads, every storing wave drains its stores, the workgroup meets, one
+    // lane takes the tile's ticket.  A __threadfence() here is a write-back AND an invalidate of the whole L2.
+    if (threadIdx.x == 0) s_slab = atomicAdd(sb.cursor, 1u);
+    __syncthreads();
+    const unsigned int slab = s_slab;
+    const bool have = slab < sb.capacity;              // (always, by the host's sizing; a full pool is reported, not overrun)
+    if (have) {
+      unsigned long long* dst = sb.pool + (size_t)slab * kSlabWords;
+      const unsigned long long* src = &s_sum[0][0];
+      for (int e = threadIdx.x; e < 9 * kTile3Cells; e += kBinThreads) __hip_atomic_store(dst + e, src[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x < kTile3Cells / 2)
+        __hip_atomic_store(dst + 9 * kTile3Cells + threadIdx.x,
+                           (unsigned long long)s_n[2 * threadIdx.x] | ((unsigned long long)s_n[2 * threadIdx.x + 1] << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    // [r3] No fences: everything handed over is written with agent-scope atomic adds (performed at the memory side, never
-    // in this CU's L1 or this XCD's L2) and read back with agent-scope atomic loads, so all the hand-off needs is that
-    // every wave's adds have completed before the workgroup's ticket is taken (MI355X_MICROARCH.md "Valid forms": agent
-    // atomics on both sides).  A __threadfence() here is a write-back AND an invalidate of the whole L2, in all 256
-    // threads, twice per shared workgroup: 5-7 us of the fullest tiles' critical path.
+    if (threadIdx.x == 0)
+      __hip_atomic_store(sb.part + (size_t)tile * kTile3Split + sub, have ? slab : 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(&tile_ticket[tile], 1u) == (unsigned)(nsub - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;                             // uniform
-    // the last of the tile's workgroups: every share is in the grid's sums - read them back for the finalise below
-    for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
-      const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
-      if (ix < g.W && iy < g.H && iz < g.D) {
-        const CellAcc3* a = &g.acc[((size_t)iz * g.H + iy) * g.W + ix];
-        s_n[c] = __hip_atomic_load(&a->n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the last of the tile's workgroups: the other shares (every thread adds its own words of every slab - no LDS atomics;
+    // all loads of a thread are issued before the first add)
+    {
+      constexpr int kPer = (kSlabWords + kBinThreads - 1) / kBinThreads;       // 3 words per thread and slab
+      unsigned long long w[kTile3Split][kPer];
+      unsigned int idx[kTile3Split];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          s_sum[j][c] = (unsigned long long)__hip_atomic_load(&a->s[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int o = 0; o < kTile3Split; ++o)
+        idx[o] = (o < nsub && o != sub) ? __hip_atomic_load(sb.part + (size_t)tile * kTile3Split + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : 0xFFFFFFFEu;
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          s_sum[3 + j][c] = (unsigned long long)__hip_atomic_load(&a->ss[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int o = 0; o < kTile3Split; ++o) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+          const int e = threadIdx.x + j * kBinThreads;
+          w[o][j] = 0ull;
+          if (idx[o] < sb.capacity && e < kSlabWords)
+            w[o][j] = __hip_atomic_load(sb.pool + (size_t)idx[o] * kSlabWords + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (idx[o] == 0xFFFFFFFFu && threadIdx.x == 0) nover = 1;      // the pool was full: a share is missing, the build reports it
+      }
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        const int e = threadIdx.x + j * kBinThreads;
+        unsigned long long tot = 0ull;
+        unsigned int lo = 0u, hi = 0u;
+#pragma unroll
+        for (int o = 0; o < kTile3Split; ++o) { tot += w[o][j]; lo += (unsigned int)w[o][j]; hi += (unsigned int)(w[o][j] >> 32); }
+        if (e < 9 * kTile3Cells) (&s_sum[0][0])[e] += tot;
+        else if (e < kSlabWords) { s_n[2 * (e - 9 * kTile3Cells)] += lo; s_n[2 * (e - 9 * kTile3Cells) + 1] += hi; }
       }
     }
     __syncthreads();
+    if (merge) {                                     // the cached sums of a submap update, once per tile
+      for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
+        const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
+        if (ix < g.W && iy < g.H && iz < g.D) {
+          const CellAcc3 a = g.acc[((size_t)iz * g.H + iy) * g.W + ix];
+          s_n[c] += a.n;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) s_sum[j][c] += (unsigned long long)a.s[j];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) s_sum[3 + j][c] += (unsigned long long)a.ss[j];
+        }
+      }
+      __syncthreads();
+    }
   }
-  int nvalid = 0, nover = 0;
+  NDT_STAMP3(3);
+  int nvalid = 0;
   for (int c = threadIdx.x; c < kTile3Cells; c += kBinThreads) {
     const int ix = tx0 + (c & ((1 << kT3x) - 1)), iy = ty0 + ((c >> kT3x) & ((1 << kT3y) - 1)), iz = tz0 + (c >> (kT3x + kT3y));
     if (ix < g.W && iy < g.H && iz < g.D) {
@@ -223,11 +359,19 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
       else if (finalise_sums3(a, cell_centre(g.ox, ix, g.cell), cell_centre(g.oy, iy, g.cell), cell_centre(g.oz, iz, g.cell),
                               g.fix_scale, min_points, eig_ratio, ra, rb, rc))
         nvalid++;
-      if (!split) g.acc[k] = a;
+      g.acc[k] = a;
       g.rec[4 * k] = ra; g.rec[4 * k + 1] = rb; g.rec[4 * k + 2] = rc;
     }
   }
+  NDT_STAMP3(4);
   block_count_add(counters, nvalid, nover);       // one add per workgroup, sharded (ndt_device.hpp)
+  NDT_STAMP3(5);
 }
 
 }  // namespace ndt
+
+#if defined(NDT_BUILD_PHASE_CLOCKS)
+extern "C" int ndt_exp_read_tile3_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ndt::g_tile3_stamps), sizeof(ndt::g_tile3_stamps));
+}
+#endif
