@@ -153,6 +153,7 @@ SIGNATURES = {
     "ndt2d_wait_stream": (C.c_int32, [_vp, _vp]),
     "ndt2d_batch_wait_stream": (C.c_int32, [_vp, _vp]),
     "ndt3d_wait_stream": (C.c_int32, [_vp, _vp]),
+    "ndt3d_set_tuning": (C.c_int32, [_vp, C.c_int32, C.c_int64]),
     "ndt2d_calibrated_covariance": (C.c_int32, [_dp, C.c_int32, _dp]),
     "ndt_magnusson_constants": (C.c_int32, [C.c_double, C.c_double, C.c_int32, _dp, _dp]),
     "ndt2d_polar_to_points_dev": (C.c_int32, [_vp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp]),

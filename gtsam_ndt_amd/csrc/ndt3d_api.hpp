@@ -22,6 +22,9 @@ struct ndt3d_handle {
   float *d_t[3] = {nullptr, nullptr, nullptr}; size_t tcap = 0;
   float *d_b[3] = {nullptr, nullptr, nullptr}; size_t bcap = 0;      // binned build scratch
   unsigned int* d_tiles = nullptr; size_t tile_cap = 0;
+  int last_ntile = 0;                 // tiles of the grid the handle holds (0: none): the launch bound of a single-sync build
+  unsigned int* h_pub3 = nullptr;     // pinned [64 + 16]: the accumulator block's first 64 words of a single-sync build, flag at [64]
+  bool one_round_trip = true;
   unsigned char* d_split3 = nullptr; size_t split3_cap = 0;   // shared tiles' hand-off (ndt3d_build.hpp Split3Bufs): part table | slab pool
   float *d_s[3] = {nullptr, nullptr, nullptr}; size_t scap = 0;
   ndt::AlignStatic3* d_static = nullptr;
@@ -73,6 +76,57 @@ int32_t upload_static3(ndt3d_handle* h) {
   return NDT_OK;
 }
 
+// The device words and buffers of a binned build of n points over at most `ntile` tiles.
+// One block of device words carries everything a build adds into, so that ONE fill clears it (round 2: four) and one
+// publish brings the results back:  counter shards [32] | outside count (u64) | pad to 64 (the shared tiles' slab cursor at
+// word 40, a device-decided geometry from word kGeom3Word) | tile totals [ntile] | tickets of the shared tiles [ntile] |
+// tile starts [ntile + 1] | scatter cursors [ntile] | number of (tile, share) workgroups [1] | their list [wg_bound]
+struct Build3Bufs {
+  int* d_cnt; unsigned long long* d_out;
+  unsigned int *d_total, *d_ticket, *d_start, *d_cursor, *d_wgtotal, *d_wgmap;
+  size_t wg_bound, zero_words;
+  ndt::Split3Bufs sb;
+};
+int32_t ensure_build3_bufs(ndt3d_handle* h, size_t n, int ntile, bool binned, Build3Bufs* B) {
+  using namespace ndt;
+  B->wg_bound = (size_t)ntile + n / (size_t)kTile3SubMin + 1;
+  const size_t tneed = 64 + 4 * (size_t)ntile + 4 + 1 + B->wg_bound;
+  if (tneed > h->tile_cap) {
+    if (h->d_tiles) (void)hipFree(h->d_tiles);
+    h->d_tiles = nullptr; h->tile_cap = 0;
+    HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
+    h->tile_cap = tneed;
+  }
+  B->d_cnt = reinterpret_cast<int*>(h->d_tiles);
+  B->d_out = reinterpret_cast<unsigned long long*>(h->d_tiles + 32);
+  B->d_total = h->d_tiles + 64;
+  B->d_ticket = B->d_total + ntile;
+  B->d_start = B->d_ticket + ntile;
+  B->d_cursor = B->d_start + ntile + 1;
+  B->d_wgtotal = B->d_cursor + ntile;
+  B->d_wgmap = B->d_wgtotal + 1;
+  B->zero_words = 64 + 2 * (size_t)ntile;
+  B->sb = Split3Bufs{};
+  if (!binned) return NDT_OK;
+  { const int32_t st = ensure3(h->d_b, &h->bcap, n); if (st != NDT_OK) return st; }
+  // the shared tiles' slabs: a tile of p > kTile3SubMin points is shared by ceil(p / kTile3SubMin) workgroups, so there
+  // are at most n / SubMin shared tiles and at most 2 n / SubMin slabs
+  const size_t slabs = 2 * (n / (size_t)kTile3SubMin) + 2;
+  const size_t off_pool = ((size_t)ntile * kTile3Split * sizeof(unsigned int) + 15) / 16 * 16;
+  const size_t need = off_pool + slabs * kSlabWords * sizeof(unsigned long long);
+  if (need > h->split3_cap) {
+    if (h->d_split3) (void)hipFree(h->d_split3);
+    h->d_split3 = nullptr; h->split3_cap = 0;
+    HIP_TRY(hipMalloc((void**)&h->d_split3, need + need / 4));
+    h->split3_cap = need + need / 4;
+  }
+  B->sb.cursor = h->d_tiles + 40;                      // (cleared with the block)
+  B->sb.part = reinterpret_cast<unsigned int*>(h->d_split3);
+  B->sb.pool = reinterpret_cast<unsigned long long*>(h->d_split3 + off_pool);
+  B->sb.capacity = (unsigned int)(slabs > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : slabs);
+  return NDT_OK;
+}
+
 // a2 + a3 for n points into the grid whose geometry and storage are set: binned LDS build, or
 // scattered global atomics for maps beyond the tile histogram.  merge = add to the cached sums
 // (incremental submap update) instead of starting from zero.
@@ -85,62 +139,32 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
   const long long ntile_ll = (long long)ntx * nty * ntz;
   const bool binned = ntile_ll <= kBinMaxTiles && n <= 0xFFFFFFFFull;
   const int ntile = binned ? (int)ntile_ll : 0;
-  // One block of device words carries everything a build adds into, so that ONE fill launch clears it (round 2: four) and
-  // one publish brings the results back:  counter shards [32] | outside count (u64) | pad to 64 | tile totals [ntile] |
-  // tickets of the shared tiles [ntile] | tile starts [ntile + 1] | scatter cursors [ntile]
-  // | number of (tile, share) workgroups [1] | their list [ntile + n / kTile3SubMin + 1]
-  const size_t wg_bound = (size_t)ntile + n / (size_t)kTile3SubMin + 1;
-  const size_t tneed = 64 + 4 * (size_t)ntile + 4 + 1 + wg_bound;
-  if (tneed > h->tile_cap) {
-    if (h->d_tiles) (void)hipFree(h->d_tiles);
-    h->d_tiles = nullptr; h->tile_cap = 0;
-    HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
-    h->tile_cap = tneed;
-  }
-  int* d_cnt = reinterpret_cast<int*>(h->d_tiles);
-  unsigned long long* d_out = reinterpret_cast<unsigned long long*>(h->d_tiles + 32);
-  unsigned int* d_total = h->d_tiles + 64;
-  unsigned int* d_ticket = d_total + ntile;
-  unsigned int* d_start = d_ticket + ntile;
-  unsigned int* d_cursor = d_start + ntile + 1;
-  unsigned int* d_wgtotal = d_cursor + ntile;
-  unsigned int* d_wgmap = d_wgtotal + 1;
-  HIP_TRY(hipMemsetAsync(h->d_tiles, 0, (64 + 2 * (size_t)ntile) * sizeof(unsigned int), h->stream));
+  Build3Bufs B{};
+  { const int32_t bs = ensure_build3_bufs(h, n, ntile, binned, &B); if (bs != NDT_OK) return bs; }
+  int* d_cnt = B.d_cnt;
+  unsigned long long* d_out = B.d_out;
+  unsigned int *d_total = B.d_total, *d_ticket = B.d_ticket, *d_start = B.d_start, *d_cursor = B.d_cursor, *d_wgtotal = B.d_wgtotal,
+               *d_wgmap = B.d_wgmap;
+  const size_t wg_bound = B.wg_bound;
+  const Split3Bufs sb = B.sb;
+  HIP_TRY(hipMemsetAsync(h->d_tiles, 0, B.zero_words * sizeof(unsigned int), h->stream));
   if (binned) {
     // binned build (ndt3d_build.hpp)
-    int32_t st = ensure3(h->d_b, &h->bcap, n);
-    if (st != NDT_OK) return st;
-    // the shared tiles' slabs: a tile of p > kTile3SubMin points is shared by ceil(p / kTile3SubMin) workgroups, so there
-    // are at most n / SubMin shared tiles and at most 2 n / SubMin slabs
-    Split3Bufs sb{};
-    {
-      const size_t slabs = 2 * (n / (size_t)kTile3SubMin) + 2;
-      const size_t off_pool = ((size_t)ntile * kTile3Split * sizeof(unsigned int) + 15) / 16 * 16;
-      const size_t need = off_pool + slabs * kSlabWords * sizeof(unsigned long long);
-      if (need > h->split3_cap) {
-        if (h->d_split3) (void)hipFree(h->d_split3);
-        h->d_split3 = nullptr; h->split3_cap = 0;
-        HIP_TRY(hipMalloc((void**)&h->d_split3, need + need / 4));
-        h->split3_cap = need + need / 4;
-      }
-      sb.cursor = h->d_tiles + 40;                     // (in the pad of the accumulator block: cleared by the fill above)
-      sb.part = reinterpret_cast<unsigned int*>(h->d_split3);
-      sb.pool = reinterpret_cast<unsigned long long*>(h->d_split3 + off_pool);
-      sb.capacity = (unsigned int)(slabs > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : slabs);
-    }
     const BinGeom3 bg{g.ox, g.oy, g.oz, g.inv_c, g.W, g.H, g.D, ntx, nty, ntile};
     size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
-                       dz, n, bg, d_total, d_out);
-    hipLaunchKernelGGL(k_tile_scan3, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, d_wgtotal, d_wgmap);
+                       dz, n, bg, d_total, d_out, (const GeomDev3*)nullptr);
+    hipLaunchKernelGGL(k_tile_scan3, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, d_wgtotal, d_wgmap,
+                       (const GeomDev3*)nullptr);
     hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
-                       dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2]);
+                       dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2], (const GeomDev3*)nullptr);
     // (no fill of the grid's sums: the workgroup that finishes a tile writes every voxel's sums, empty ones included)
     hipLaunchKernelGGL(k_tile_accumulate3, dim3((unsigned)wg_bound), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1],
                        h->d_b[2], d_start, g, ntx, nty, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, d_cnt, d_ticket, sb,
-                       (const unsigned int*)d_wgtotal, (const unsigned int*)d_wgmap);
+                       (const unsigned int*)d_wgtotal, (const unsigned int*)d_wgmap, (const GeomDev3*)nullptr, (const Grid3Dev*)nullptr);
     HIP_TRY(hipGetLastError());
+    h->last_ntile = ntile;
   } else {
     if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));
     hipLaunchKernelGGL(k_accumulate3, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, g, d_out);
@@ -210,12 +234,92 @@ int32_t setup_geometry3(ndt3d_handle* h, const float lo[3], const float hi[3]) {
   return NDT_OK;
 }
 
+// ndt3d_set_target with ONE host round trip (the 3D twin of the 2D build's set_target_single_sync): a handle that already
+// holds a grid enqueues the whole build at once - bounding-box partials, k_geometry3 (clears the accumulators, reduces the
+// box, decides the grid: it must fit the handle's storage and a launch bound of twice the cached grid's tiles), count,
+// scan, scatter, tile kernel with the geometry read from device memory - and one publish of the results AND the box.  If
+// the grid does not fit, ok = 0 makes every kernel return and the caller builds the usual way with the box it now has.
+// The host recomputes the geometry from the same box afterwards and compares.
+int32_t set_target3_single_sync(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n, bool* done,
+                                unsigned int* hb_out, bool* have_bounds) {
+  using namespace ndt;
+  *done = false; *have_bounds = false;
+  if (!h->one_round_trip || h->cell_capacity == 0 || h->last_ntile <= 0 || n > 0xFFFFFFFFull || !h->grid.rec || !h->grid.acc) return NDT_OK;
+  long long tb = 2ll * h->last_ntile + 16;
+  if (tb > kBinMaxTiles) tb = kBinMaxTiles;
+  const int tile_bound = (int)tb;
+  if (!h->h_pub3) HIP_TRY(hipHostMalloc((void**)&h->h_pub3, 80 * sizeof(unsigned int), hipHostMallocDefault));
+  if (!h->d_parts3) HIP_TRY(hipMalloc((void**)&h->d_parts3, 256 * 8 * sizeof(float)));
+  Build3Bufs B{};
+  { const int32_t bs = ensure_build3_bufs(h, n, tile_bound, true, &B); if (bs != NDT_OK) return bs; }
+  int sbk = stream_blocks(n);
+  if (sbk > 256) sbk = 256;
+  const GeomDev3* dg = reinterpret_cast<const GeomDev3*>(h->d_tiles + kGeom3Word);
+  Grid3Dev* dgrid = &h->d_static->grid;
+  HIP_TRY(hipEventSynchronize(h->upload_ev));              // (an upload of d_static still in flight would overwrite the header)
+  hipLaunchKernelGGL(k_bounds3_parts, dim3(sbk), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_parts3);
+  hipLaunchKernelGGL(k_geometry3, dim3(1), dim3(1024), 0, h->stream, (const float*)h->d_parts3, sbk, h->prm.cell_size,
+                     (unsigned long long)h->cell_capacity, tile_bound, dgrid, h->d_tiles, (int)B.zero_words);
+  const BinGeom3 none{};
+  size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), tile_bound * sizeof(unsigned int), h->stream, dx, dy, dz, n,
+                     none, B.d_total, B.d_out, dg);
+  hipLaunchKernelGGL(k_tile_scan3, dim3(1), dim3(1024), 0, h->stream, B.d_total, B.d_start, B.d_cursor, tile_bound, B.d_wgtotal, B.d_wgmap, dg);
+  hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * tile_bound * sizeof(unsigned int), h->stream, dx, dy, dz,
+                     n, none, B.d_cursor, h->d_b[0], h->d_b[1], h->d_b[2], dg);
+  hipLaunchKernelGGL(k_tile_accumulate3, dim3((unsigned)B.wg_bound), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1], h->d_b[2],
+                     B.d_start, h->grid, 0, 0, 0, h->prm.min_points, h->prm.eig_ratio, B.d_cnt, B.d_ticket, B.sb,
+                     (const unsigned int*)B.d_wgtotal, (const unsigned int*)B.d_wgmap, dg, (const Grid3Dev*)dgrid);
+  HIP_TRY(hipGetLastError());
+  unsigned int* hp = h->h_pub3;
+  {
+    int* flag = reinterpret_cast<int*>(hp + 64);
+    h->publish_seq = h->publish_seq == 0x7fffffff ? 1 : h->publish_seq + 1;
+    hipLaunchKernelGGL(k_build_publish, dim3(1), dim3(64), 0, h->stream, (const unsigned int*)h->d_tiles, hp, 64, flag, h->publish_seq);
+    HIP_TRY(hipGetLastError());
+    bool seen = false;
+    const int want = h->publish_seq;
+    HIP_TRY(spin_until(h->stream, [&]() { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want; }, &seen));
+    if (!seen) {
+      HIP_TRY(hipMemcpyAsync(hp, h->d_tiles, 256, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+  }
+  const GeomDev3* hg = reinterpret_cast<const GeomDev3*>(hp + kGeom3Word);
+  for (int j = 0; j < 6; ++j) hb_out[j] = hg->bounds[j];
+  *have_bounds = true;
+  if (!hg->ok) return NDT_OK;                              // does not fit storage or bound (or no finite point): the usual way
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) { lo[a] = ordered_to_float(hg->bounds[2 * a]); hi[a] = ordered_to_float(hg->bounds[2 * a + 1]); }
+  // the host's view of the same geometry, from the same box; the storage is large enough, nothing is reallocated
+  if (setup_geometry3(h, lo, hi) != NDT_OK) return NDT_OK;
+  const Grid3Dev& g = h->grid;
+  if (g.W != hg->bin.W || g.H != hg->bin.H || g.D != hg->bin.D || g.ox != hg->bin.ox || g.oy != hg->bin.oy || g.oz != hg->bin.oz) return NDT_OK;
+  h->last_ntile = hg->bin.ntile;
+  int n_valid_sum = 0, n_over_sum = 0;
+  sum_count_shards(reinterpret_cast<const int*>(hp), &n_valid_sum, &n_over_sum);
+  h->n_valid = n_valid_sum;
+  if (n_over_sum > 0) { set_error("a target cell holds more than 2^20 points"); return NDT_ERR_CAPACITY; }
+  *done = true;
+  return NDT_OK;
+}
+
 int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
   using namespace ndt;
   TraceRange range("ndt3d_set_target: voxel grid build");
   h->has_target = false;
   unsigned int* hb = (unsigned int*)h->h_small;
-  {
+  unsigned int fast_bounds[6];
+  bool done = false, have_bounds = false;
+  { const int32_t fs = set_target3_single_sync(h, dx, dy, dz, n, &done, fast_bounds, &have_bounds); if (fs != NDT_OK) return fs; }
+  if (done) {
+    h->has_target = true;
+    return upload_static3(h);
+  }
+  if (have_bounds) {
+    for (int j = 0; j < 6; ++j) hb[j] = fast_bounds[j];    // the single-sync attempt measured the box already
+  } else {
     // bounding box: one partial per workgroup, then one wave reduces them into pinned host memory and raises a flag
     if (!h->d_parts3) HIP_TRY(hipMalloc((void**)&h->d_parts3, 256 * 8 * sizeof(float)));
     int sb = stream_blocks(n);
@@ -458,11 +562,17 @@ int32_t ndt3d_destroy(ndt3d_handle* h) {
   void* dev[] = {h->d_parts3, h->d_bounds, h->d_counters, h->d_outside, h->d_static, h->d_call, h->d_dyn, h->d_t[0], h->d_t[1], h->d_t[2],
                  h->d_s[0], h->d_s[1], h->d_s[2], h->d_b[0], h->d_b[1], h->d_b[2], h->d_tiles, h->d_split3, h->grid.rec, h->grid.acc, h->d_dyn_multi};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag, h->h_state_multi};
+  void* host[] = {h->h_static, h->h_state, h->h_small, h->h_flag, h->h_state_multi, h->h_pub3};
   for (void* p : host) if (p) (void)hipHostFree(p);
   if (h->upload_ev) (void)hipEventDestroy(h->upload_ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+  return NDT_OK;
+}
+
+int32_t ndt3d_set_tuning(ndt3d_handle* h, int32_t knob, int64_t value) {
+  if (!h || knob != NDT_TUNE_SINGLE_SYNC_BUILD) return NDT_ERR_INVALID_ARG;
+  h->one_round_trip = value != 0;
   return NDT_OK;
 }
 

@@ -32,11 +32,88 @@ __device__ __forceinline__ int tile_of3(const BinGeom3& g, float px, float py, f
   return in ? ((((int)fz >> kT3z) * g.nty + ((int)fy >> kT3y)) * g.ntx + ((int)fx >> kT3x)) : -1;
 }
 
+// ---- a build whose geometry is decided on the device (one host round trip instead of two: ndt3d_api.hpp
+// set_target3_single_sync, the 3D twin of the 2D build's single-sync path) ---------------------------------------------
+// The decision lives in the pad of the build's accumulator block (words kGeom3Word ..), so that ONE publish brings the
+// counters, the outside count, the bounding box and the geometry back.
+struct GeomDev3 {
+  BinGeom3 bin;               // 10 words
+  int ok;                     // 0: no finite point, or the grid fits neither the handle's storage nor the launch bounds
+  unsigned int bounds[6];     // ordered-float bounding box, for the host
+};
+constexpr int kGeom3Word = 42;
+static_assert(sizeof(GeomDev3) == 17 * 4 && kGeom3Word + 17 <= 64, "GeomDev3 sits in the pad of the accumulator block");
+
+// a1 in 3D on the device: the arithmetic of setup_geometry3() on the host (oracle/ndt3d.py grid_geometry3), which
+// recomputes it from the same bounds afterwards and compares.  One lane.
+__device__ inline bool decide_geometry3(const float mn[3], const float mx[3], double c, unsigned long long cell_capacity,
+                                        int tile_bound, BinGeom3* bin, Grid3Dev* grid) {
+#pragma clang fp contract(off)
+  const float inv_c = (float)(1.0 / c);
+  float o[3];
+  int dims[3];
+  double ncell_d = 1.0;
+  for (int a = 0; a < 3; ++a) {
+    o[a] = (float)((floor((double)mn[a] / c) - 1.0) * c);
+    const float f = (mx[a] - o[a]) * inv_c;
+    const double k = floor((double)f);
+    if (!(k >= 0.0) || k > 1e7) return false;
+    dims[a] = (int)k + 2;
+    ncell_d *= dims[a];
+  }
+  if (ncell_d > (double)cell_capacity) return false;       // (the handle's storage never exceeds the 2^27 cells of setup_geometry3)
+  const int ntx = (dims[0] + (1 << kT3x) - 1) >> kT3x, nty = (dims[1] + (1 << kT3y) - 1) >> kT3y, ntz = (dims[2] + (1 << kT3z) - 1) >> kT3z;
+  if ((long long)ntx * nty * ntz > (long long)tile_bound) return false;
+  bin->ox = o[0]; bin->oy = o[1]; bin->oz = o[2]; bin->inv_c = inv_c;
+  bin->W = dims[0]; bin->H = dims[1]; bin->D = dims[2]; bin->ntx = ntx; bin->nty = nty; bin->ntile = ntx * nty * ntz;
+  grid->ox = o[0]; grid->oy = o[1]; grid->oz = o[2]; grid->inv_c = inv_c;
+  grid->W = dims[0]; grid->H = dims[1]; grid->D = dims[2]; grid->pad = 0;
+  grid->cell = c;
+  grid->fix_scale = 4194304.0 / c;
+  static_assert(kFixShift == 22, "fix_scale literal");
+  return true;
+}
+
+// One workgroup: clears the build's accumulator block (instead of a fill launch), reduces the bounding-box partials of
+// k_bounds3_parts and decides the geometry.  block = the accumulator block, zero_words of it are cleared (all but the
+// GeomDev3 words, which lane 0 writes).
+__global__ __launch_bounds__(1024) void k_geometry3(const float* __restrict__ parts, int nparts, double cell,
+                                                     unsigned long long cell_capacity, int tile_bound, Grid3Dev* __restrict__ dgrid,
+                                                     unsigned int* __restrict__ block, int zero_words) {
+  for (int i = threadIdx.x; i < zero_words; i += 1024)
+    if (i < kGeom3Word || i >= kGeom3Word + 17) block[i] = 0u;
+  if (threadIdx.x >= 64) return;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < nparts; i += 64) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], parts[8 * i + 2 * a]); mx[a] = fmaxf(mx[a], parts[8 * i + 2 * a + 1]); }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+  if (threadIdx.x == 0) {
+    GeomDev3* out = reinterpret_cast<GeomDev3*>(block + kGeom3Word);
+    bool none = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const bool na = !(mn[a] <= mx[a]);                   // no finite point: k_bounds3's "empty" encoding
+      none = none || na;
+      out->bounds[2 * a] = na ? 0xFFFFFFFFu : float_to_ordered(mn[a]);
+      out->bounds[2 * a + 1] = na ? 0u : float_to_ordered(mx[a]);
+    }
+    BinGeom3 bin{};
+    const bool ok = !none && decide_geometry3(mn, mx, cell, cell_capacity, tile_bound, &bin, dgrid);
+    out->bin = bin;
+    out->ok = ok ? 1 : 0;
+  }
+}
+
 __global__ __launch_bounds__(kBinThreads) void k_tile_count3(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ z, size_t n, BinGeom3 g,
                                                               unsigned int* __restrict__ tile_total,
-                                                              unsigned long long* __restrict__ n_outside) {
+                                                              unsigned long long* __restrict__ n_outside,
+                                                              const GeomDev3* __restrict__ dg) {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_hist[];
+  if (dg) { if (!dg->ok) return; g = dg->bin; }            // geometry from the device (the LDS covers the host's tile bound)
   for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) s_hist[t] = 0u;
   __syncthreads();
   unsigned int outside = 0;
@@ -57,8 +134,9 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_scatter3(const float* __re
                                                                 const float* __restrict__ z, size_t n, BinGeom3 g,
                                                                 unsigned int* __restrict__ tile_cursor,
                                                                 float* __restrict__ bx, float* __restrict__ by,
-                                                                float* __restrict__ bz) {
+                                                                float* __restrict__ bz, const GeomDev3* __restrict__ dg) {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_mem[];
+  if (dg) { if (!dg->ok) return; g = dg->bin; }
   unsigned int* s_hist = s_mem;
   unsigned int* s_base = s_mem + g.ntile;
   const size_t chunk = (size_t)kBinThreads * 4;
@@ -123,8 +201,10 @@ __device__ __forceinline__ int tile3_subs(unsigned int points) {
 // 15 us into the kernel (in-kernel clocks).  One workgroup; ntile <= kBinMaxTiles.
 __global__ __launch_bounds__(1024) void k_tile_scan3(const unsigned int* __restrict__ tile_total, unsigned int* __restrict__ tile_start,
                                                       unsigned int* __restrict__ tile_cursor, int ntile,
-                                                      unsigned int* __restrict__ wg_total, unsigned int* __restrict__ wg_map) {
+                                                      unsigned int* __restrict__ wg_total, unsigned int* __restrict__ wg_map,
+                                                      const GeomDev3* __restrict__ dg) {
   __shared__ unsigned int s_wave[2][16];
+  if (dg) { if (!dg->ok) return; ntile = dg->bin.ntile; }
   const int per = (ntile + 1023) / 1024;
   const int t0 = threadIdx.x * per;
   unsigned int local = 0, lwg = 0;
@@ -175,7 +255,8 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
                                                                    double eig_ratio, int* __restrict__ counters,
                                                                    unsigned int* __restrict__ tile_ticket, Split3Bufs sb,
                                                                    const unsigned int* __restrict__ wg_total,
-                                                                   const unsigned int* __restrict__ wg_map) {
+                                                                   const unsigned int* __restrict__ wg_map,
+                                                                   const GeomDev3* __restrict__ dg, const Grid3Dev* __restrict__ dgrid) {
   // The point loop adds into kCopies3 private copies of the tile's sums, chosen by lane: neighbouring points of a scan fall
   // into the same voxel, so a wave's 64 atomics went to one or two LDS words and were performed one after the other - the
   // fullest tiles' loops took 12-18 us (in-kernel clocks, tools/quick_tile3_stamps.py) and held up every other workgroup
@@ -187,6 +268,12 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
   __shared__ unsigned int s_n[kTile3Cells];
   __shared__ int s_last;
   __shared__ unsigned int s_slab;
+  if (dg) {        // geometry from the device; storage (g.rec, g.acc) from the launch
+    if (!dg->ok) return;
+    ntx = dg->bin.ntx; nty = dg->bin.nty;
+    g.ox = dgrid->ox; g.oy = dgrid->oy; g.oz = dgrid->oz; g.inv_c = dgrid->inv_c;
+    g.W = dgrid->W; g.H = dgrid->H; g.D = dgrid->D; g.cell = dgrid->cell; g.fix_scale = dgrid->fix_scale;
+  }
   if (blockIdx.x >= __builtin_amdgcn_readfirstlane(*wg_total)) return;       // (the launch covers the host's bound)
   const unsigned int entry = __builtin_amdgcn_readfirstlane(wg_map[blockIdx.x]);
   const int tile = (int)(entry & 0xFFFFFFu), sub = (int)(entry >> 24);

@@ -561,12 +561,15 @@ def default_params3d(**overrides) -> L.Params2D:
 class NdtMatcher3D:
     """3D SE(3) variant (BASELINE config 5); mirrors ndt3d_* of include/ndt_hip.h."""
 
-    def __init__(self, device: int = 0, **overrides):
+    def __init__(self, device: int = 0, tuning: dict | None = None, **overrides):
+        """tuning: execution-strategy knobs by name (L.TUNING; 3D handles know "single_sync_build")."""
         self._lib = L.load()
         self.params = default_params3d(**overrides)
         h = C.c_void_p()
         L.check(self._lib.ndt3d_create(C.byref(self.params), int(device), C.byref(h)), "ndt3d_create")
         self._h = h
+        for k, v in (tuning or {}).items():
+            L.check(self._lib.ndt3d_set_tuning(self._h, L.TUNING[k], int(v)), "ndt3d_set_tuning")
 
     def close(self):
         if getattr(self, "_h", None):

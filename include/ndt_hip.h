@@ -515,6 +515,11 @@ int32_t ndt3d_align_trace(ndt3d_handle* h, const float* sx, const float* sy, con
 void* ndt3d_stream(ndt3d_handle* h);
 /* as ndt2d_wait_stream: order the handle's stream behind the producer of the device arrays */
 int32_t ndt3d_wait_stream(ndt3d_handle* h, void* producer_stream);
+/* Execution-strategy knobs of a 3D handle (as ndt2d_set_tuning: they choose between code paths that build the same grid).
+ *   NDT_TUNE_SINGLE_SYNC_BUILD  1 (default): ndt3d_set_target on a handle that already holds a grid decides the new grid's
+ *                               geometry on the device and pays one host round trip; 0: the bounding box comes to the host
+ *                               first (two round trips).  Other knobs: NDT_ERR_INVALID_ARG. */
+int32_t ndt3d_set_tuning(ndt3d_handle* h, int32_t knob, int64_t value);
 
 /* ---- 3D loop-closure candidate batch ------------------------------------------------------------ */
 /* The 3D twin of ndt2d_batch: independent 3D scan pairs aligned concurrently, one persistent

@@ -104,3 +104,48 @@ def test_single_sync_build_falls_back_when_the_launch_bound_is_too_small(gpu_lib
         _equal(_grid_state(m), _grid_state(ref))
         a, b = m.align(wide["sx"], wide["sy"], wide["init"]), ref.align(wide["sx"], wide["sy"], wide["init"])
         assert a.pose == b.pose and a.iterations == b.iterations
+
+
+# ---- 3D: ndt3d_set_target with one host round trip (k_geometry3) ---------------------------------------------------
+def _grid_state3(m):
+    info = m.grid_info()
+    return (info.ox, info.oy, info.oz, info.width, info.height, info.depth, info.n_valid), m.save_map()
+
+
+def test_single_sync_build_3d_equals_two_round_trips(gpu_lib):
+    """Second and later ndt3d_set_target calls on a handle decide the geometry on the device: the grid (the whole map
+    buffer: exact sums per voxel) and the alignments on it equal the two-round-trip build's bit for bit; a cloud that
+    outgrows the storage falls back inside the call; one without a finite point is refused."""
+    from gtsam_ndt_amd import synth3d
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    from oracle import ndt3d as o3
+    d = synth3d.make_pair3d(n_elev=32, n_azim=512)
+    T = (d["tx"], d["ty"], d["tz"])
+    S = (d["sx"], d["sy"], d["sz"])
+    shifted = (d["tx"] + np.float32(2.3), d["ty"] - np.float32(1.1), d["tz"] + np.float32(0.4))
+    part = tuple(a[:4000] for a in T)
+    wide = tuple(np.concatenate([a, a[:2000] * np.float32(1.5 if k < 2 else 1.0)]) for k, a in enumerate(T))   # larger extent: more voxels than the storage
+    seq = [T, shifted, part, T, wide, T, S]
+    with NdtMatcher3D() as fast, NdtMatcher3D(tuning={"single_sync_build": 0}) as slow:
+        for cloud in seq:
+            fi, si = fast.set_target(*cloud), slow.set_target(*cloud)
+            assert (fi.width, fi.height, fi.depth, fi.n_valid) == (si.width, si.height, si.depth, si.n_valid)
+            a, b = _grid_state3(fast), _grid_state3(slow)
+            assert a[0] == b[0]
+            np.testing.assert_array_equal(a[1], b[1])
+            rf, rs = fast.align(*S, d["init"]), slow.align(*S, d["init"])
+            assert rf.pose == rs.pose and rf.iterations == rs.iterations and np.array_equal(rf.H, rs.H)
+        # against the oracle's geometry and counts once more, on the single-sync path
+        info = fast.set_target(*shifted)
+        g = o3.build_grid3(*shifted, o3.Ndt3Params())
+        assert (info.width, info.height, info.depth, info.n_valid) == (*g.dims, g.n_valid)
+        # the incremental update after a single-sync build works on the host's copy of the geometry
+        fast.set_target(*T); slow.set_target(*T)
+        assert fast.add_target_points(*part) == slow.add_target_points(*part)
+        np.testing.assert_array_equal(_grid_state3(fast)[1], _grid_state3(slow)[1])
+        nan = np.full(10, np.nan, np.float32)
+        with pytest.raises(RuntimeError):
+            fast.set_target(nan, nan, nan)
+        info = fast.set_target(*T)
+        g = o3.build_grid3(*T, o3.Ndt3Params())
+        assert (info.width, info.height, info.depth, info.n_valid) == (*g.dims, g.n_valid)
