@@ -154,7 +154,7 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
     size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
-                       dz, n, bg, d_total, d_out, (const GeomDev3*)nullptr);
+                       dz, n, bg, d_total, d_out, Geom3Args{});
     hipLaunchKernelGGL(k_tile_scan3, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, d_wgtotal, d_wgmap,
                        (const GeomDev3*)nullptr);
     hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
@@ -235,9 +235,10 @@ int32_t setup_geometry3(ndt3d_handle* h, const float lo[3], const float hi[3]) {
 }
 
 // ndt3d_set_target with ONE host round trip (the 3D twin of the 2D build's set_target_single_sync): a handle that already
-// holds a grid enqueues the whole build at once - bounding-box partials, k_geometry3 (clears the accumulators, reduces the
-// box, decides the grid: it must fit the handle's storage and a launch bound of twice the cached grid's tiles), count,
-// scan, scatter, tile kernel with the geometry read from device memory - and one publish of the results AND the box.  If
+// holds a grid enqueues the whole build at once - bounding-box partials (its workgroup 0 clears the accumulators), the count
+// kernel whose prologue reduces the box and decides the grid (it must fit the handle's storage and a launch bound of twice
+// the cached grid's tiles), scan, scatter, tile kernel with the geometry read from device memory - and one publish of the
+// results AND the box.  If
 // the grid does not fit, ok = 0 makes every kernel return and the caller builds the usual way with the box it now has.
 // The host recomputes the geometry from the same box afterwards and compares.
 int32_t set_target3_single_sync(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n, bool* done,
@@ -257,14 +258,17 @@ int32_t set_target3_single_sync(ndt3d_handle* h, const float* dx, const float* d
   const GeomDev3* dg = reinterpret_cast<const GeomDev3*>(h->d_tiles + kGeom3Word);
   Grid3Dev* dgrid = &h->d_static->grid;
   HIP_TRY(hipEventSynchronize(h->upload_ev));              // (an upload of d_static still in flight would overwrite the header)
-  hipLaunchKernelGGL(k_bounds3_parts, dim3(sbk), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_parts3);
-  hipLaunchKernelGGL(k_geometry3, dim3(1), dim3(1024), 0, h->stream, (const float*)h->d_parts3, sbk, h->prm.cell_size,
-                     (unsigned long long)h->cell_capacity, tile_bound, dgrid, h->d_tiles, (int)B.zero_words);
+  hipLaunchKernelGGL(k_bounds3_parts, dim3(sbk), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_parts3, h->d_tiles, (int)B.zero_words,
+                     kGeom3Word, (int)(sizeof(GeomDev3) / 4));
+  Geom3Args ga{};
+  ga.parts = h->d_parts3; ga.nparts = sbk; ga.tile_bound = tile_bound; ga.cell = h->prm.cell_size;
+  ga.cell_capacity = (unsigned long long)h->cell_capacity; ga.grid = dgrid;
+  ga.out = reinterpret_cast<GeomDev3*>(h->d_tiles + kGeom3Word);
   const BinGeom3 none{};
   size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), tile_bound * sizeof(unsigned int), h->stream, dx, dy, dz, n,
-                     none, B.d_total, B.d_out, dg);
+                     none, B.d_total, B.d_out, ga);
   hipLaunchKernelGGL(k_tile_scan3, dim3(1), dim3(1024), 0, h->stream, B.d_total, B.d_start, B.d_cursor, tile_bound, B.d_wgtotal, B.d_wgmap, dg);
   hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * tile_bound * sizeof(unsigned int), h->stream, dx, dy, dz,
                      n, none, B.d_cursor, h->d_b[0], h->d_b[1], h->d_b[2], dg);
@@ -326,7 +330,7 @@ int32_t set_target3_impl(ndt3d_handle* h, const float* dx, const float* dy, cons
     if (sb > 256) sb = 256;
     int* flag = reinterpret_cast<int*>(static_cast<char*>(h->h_small) + 192);
     h->publish_seq = h->publish_seq == 0x7fffffff ? 1 : h->publish_seq + 1;
-    hipLaunchKernelGGL(k_bounds3_parts, dim3(sb), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_parts3);
+    hipLaunchKernelGGL(k_bounds3_parts, dim3(sb), dim3(kBlock), 0, h->stream, dx, dy, dz, n, h->d_parts3, (unsigned int*)nullptr, 0, 0, 0);
     hipLaunchKernelGGL(k_bounds3_publish, dim3(1), dim3(64), 0, h->stream, (const float*)h->d_parts3, sb, hb, flag, h->publish_seq);
     HIP_TRY(hipGetLastError());
     bool seen = false;

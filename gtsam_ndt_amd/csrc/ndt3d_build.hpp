@@ -74,46 +74,69 @@ __device__ inline bool decide_geometry3(const float mn[3], const float mx[3], do
   return true;
 }
 
-// One workgroup: clears the build's accumulator block (instead of a fill launch), reduces the bounding-box partials of
-// k_bounds3_parts and decides the geometry.  block = the accumulator block, zero_words of it are cleared (all but the
-// GeomDev3 words, which lane 0 writes).
-__global__ __launch_bounds__(1024) void k_geometry3(const float* __restrict__ parts, int nparts, double cell,
-                                                     unsigned long long cell_capacity, int tile_bound, Grid3Dev* __restrict__ dgrid,
-                                                     unsigned int* __restrict__ block, int zero_words) {
-  for (int i = threadIdx.x; i < zero_words; i += 1024)
-    if (i < kGeom3Word || i >= kGeom3Word + 17) block[i] = 0u;
-  if (threadIdx.x >= 64) return;
+// The geometry decision is the prologue of k_tile_count3 (as k_chunk_sort's in 2D): EVERY workgroup reduces the
+// bounding-box partials of k_bounds3_parts (a few KB) and applies the rule - the same inputs, the same arithmetic, the same
+// grid everywhere - and workgroup 0 also writes it where the later kernels, the alignments and the host read it.  A
+// one-workgroup kernel of its own for this cost 4 us of the build plus a kernel boundary.
+struct Geom3Args {
+  const float* parts;          // null: the geometry comes with the launch (BinGeom3 argument)
+  int nparts;
+  int tile_bound;
+  double cell;
+  unsigned long long cell_capacity;
+  Grid3Dev* grid;              // the device context's grid header
+  GeomDev3* out;               // in the accumulator block (which k_bounds3_parts cleared, all but these words)
+};
+
+// wave 0 of a workgroup; returns ok, the geometry in *bin (valid in lane 0 only: broadcast through LDS by the caller)
+__device__ __forceinline__ bool reduce_and_decide3(const Geom3Args& ga, BinGeom3* bin, bool write) {
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = threadIdx.x; i < nparts; i += 64) {
+  for (int i = threadIdx.x & 63; i < ga.nparts; i += 64) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], parts[8 * i + 2 * a]); mx[a] = fmaxf(mx[a], parts[8 * i + 2 * a + 1]); }
+    for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], ga.parts[8 * i + 2 * a]); mx[a] = fmaxf(mx[a], ga.parts[8 * i + 2 * a + 1]); }
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
-  if (threadIdx.x == 0) {
-    GeomDev3* out = reinterpret_cast<GeomDev3*>(block + kGeom3Word);
+  bool ok = false;
+  if ((threadIdx.x & 63) == 0) {
     bool none = false;
+    unsigned int b[6];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const bool na = !(mn[a] <= mx[a]);                   // no finite point: k_bounds3's "empty" encoding
       none = none || na;
-      out->bounds[2 * a] = na ? 0xFFFFFFFFu : float_to_ordered(mn[a]);
-      out->bounds[2 * a + 1] = na ? 0u : float_to_ordered(mx[a]);
+      b[2 * a] = na ? 0xFFFFFFFFu : float_to_ordered(mn[a]);
+      b[2 * a + 1] = na ? 0u : float_to_ordered(mx[a]);
     }
-    BinGeom3 bin{};
-    const bool ok = !none && decide_geometry3(mn, mx, cell, cell_capacity, tile_bound, &bin, dgrid);
-    out->bin = bin;
-    out->ok = ok ? 1 : 0;
+    Grid3Dev scratch_grid;                                 // (only workgroup 0 writes the shared header)
+    ok = !none && decide_geometry3(mn, mx, ga.cell, ga.cell_capacity, ga.tile_bound, bin, write ? ga.grid : &scratch_grid);
+    if (write) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ga.out->bounds[j] = b[j];
+      ga.out->bin = *bin;
+      ga.out->ok = ok ? 1 : 0;
+    }
   }
+  return ok;
 }
 
 __global__ __launch_bounds__(kBinThreads) void k_tile_count3(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ z, size_t n, BinGeom3 g,
                                                               unsigned int* __restrict__ tile_total,
-                                                              unsigned long long* __restrict__ n_outside,
-                                                              const GeomDev3* __restrict__ dg) {
+                                                              unsigned long long* __restrict__ n_outside, Geom3Args ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_hist[];
-  if (dg) { if (!dg->ok) return; g = dg->bin; }            // geometry from the device (the LDS covers the host's tile bound)
+  if (ga.parts) {                                          // geometry decided here (the LDS covers the host's tile bound)
+    __shared__ BinGeom3 s_bin;
+    __shared__ int s_ok;
+    if (threadIdx.x < 64) {
+      BinGeom3 bin{};
+      const bool ok = reduce_and_decide3(ga, &bin, blockIdx.x == 0);
+      if (threadIdx.x == 0) { s_bin = bin; s_ok = ok ? 1 : 0; }
+    }
+    __syncthreads();
+    if (!s_ok) return;                                     // uniform: the host repeats the build the usual way
+    g = s_bin;
+  }
   for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) s_hist[t] = 0u;
   __syncthreads();
   unsigned int outside = 0;

@@ -148,8 +148,14 @@ __global__ __launch_bounds__(kBlock) void k_bounds3(const float* __restrict__ x,
 // stores), then one wave reduces the partials and writes the six ordered bounds straight into pinned host memory, a flag
 // behind them (the host spins on it, as for the alignments).  k_bounds3's six atomics per workgroup all land on ONE
 // 64-byte line and serialise at the memory side: 128 workgroups x 6 x ~10 ns were most of its 12 us.
+// zero (may be null): the accumulator block of a build whose geometry is decided on the device is cleared here, one kernel
+// before anything adds to it - words [0, zero_words) except [keep_from, keep_from + keep_words) (the geometry's own words).
 __global__ __launch_bounds__(kBlock) void k_bounds3_parts(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ z, size_t n, float* __restrict__ parts /*[grid][8]*/) {
+                                                           const float* __restrict__ z, size_t n, float* __restrict__ parts /*[grid][8]*/,
+                                                           unsigned int* __restrict__ zero, int zero_words, int keep_from, int keep_words) {
+  if (zero && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < zero_words; i += kBlock)
+      if (i < keep_from || i >= keep_from + keep_words) zero[i] = 0u;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   const size_t stride = (size_t)gridDim.x * kBlock;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += 4 * stride) {          // four points in flight
