@@ -194,3 +194,65 @@ def test_random_clouds_three_iterations_batch_vs_single_pair(gpu_lib):
             assert np.abs(np.array(a.pose) - np.array(c.pose)).max() < 2e-4 * scale, (i, kw, a.pose, c.pose)
             compared += 1
     assert compared >= 40
+
+
+def test_random_clouds_3d_on_one_reused_handle(gpu_lib):
+    """The same kind of clouds through ONE handle: from the second build on the geometry is decided on the device
+    (ndt3d_api.hpp set_target3_single_sync), with grids that shrink, grow past the storage (fallback inside the call),
+    move far away and change cell population; dense blobs put thousands of points into single tiles (shared tiles: slabs,
+    lane-private LDS copies).  Geometry, every voxel's count and the number of valid voxels must be the oracle's."""
+    from gtsam_ndt_amd.matcher import NdtMatcher3D
+    from oracle import ndt3d as o3
+    rng = np.random.default_rng(4242)
+    kw = dict(cell_size=1.0, min_points=5, eig_ratio=1e-2)
+    prm = o3.Ndt3Params(**kw)
+    with NdtMatcher3D(**kw) as m:
+        for i in range(20):
+            centre = rng.uniform(-200, 200, 3) if i % 3 == 0 else rng.uniform(-3, 3, 3)
+            spread = float(rng.choice([0.5, 2.0, 6.0, 12.0]))
+            n = int(rng.choice([7, 300, 3000, 30000, 120000]))
+            k = int(rng.integers(1, 4))
+            blobs = rng.normal(size=(k, 3)) * spread + centre
+            sc = rng.uniform(0.05, 1.0, size=(k, 3))
+            w = rng.integers(0, k, n)
+            p = (blobs[w] + rng.normal(size=(n, 3)) * sc[w]).astype(np.float32)
+            if n > 50:
+                p[::17, 0] = np.nan                                        # no-return points
+            fin = np.isfinite(p).all(axis=1)
+            g = o3.build_grid3(p[fin, 0].copy(), p[fin, 1].copy(), p[fin, 2].copy(), prm)
+            info = m.set_target(p[:, 0].copy(), p[:, 1].copy(), p[:, 2].copy())
+            assert (info.width, info.height, info.depth) == g.dims, i
+            assert (info.ox, info.oy, info.oz) == tuple(np.float32(v) for v in g.o), i
+            count, _, _ = m.grid()
+            np.testing.assert_array_equal(count.astype(np.int64), g.count, err_msg=f"case {i}")
+            assert info.n_valid == g.n_valid, i
+
+
+def test_random_pairs_through_the_overlapping_grid_batch(gpu_lib):
+    """The batch with four overlapping grids against the single-pair path with the same option on random clouds: one
+    evaluation at the start pose (the four grids themselves: hits, score, Hessian)."""
+    from gtsam_ndt_amd import _lib as L
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMatcher2D
+    checked = n_ok = 0
+    for i, tx, ty, sx, sy, pose, kw in _cases(40, seed=991):
+        if (np.isfinite(tx) & np.isfinite(ty)).sum() == 0:
+            continue
+        kw = dict(kw, overlap_grids=4)
+        with NdtMatcher2D(**kw) as m:
+            info = m.set_target(tx, ty)
+            if info.n_valid == 0 or 4 * info.width * info.height > (1 << 18):
+                continue
+            H, gr, score, n_hit = m.evaluate(sx, sy, pose)
+        with NdtBatch2D(fixed_iterations=1, **kw) as b:
+            rb = b.align([(tx, ty)], [(sx, sy)], [pose])[0]
+        if rb.status in (L.NDT_OK, L.NDT_NOT_CONVERGED):
+            assert rb.n_hit == n_hit, (i, rb.n_hit, n_hit)
+            hs = max(np.abs(H).max(), 1e-30)
+            assert np.abs(rb.H - H).max() / hs < 1e-4, (i, kw)
+            assert abs(rb.score - score) <= 1e-4 * max(score, 1e-6)
+            n_ok += 1
+        else:       # (random sources against random targets mostly miss the map: the status must say so)
+            assert rb.status in (L.NDT_TOO_FEW_HITS, L.NDT_DEGENERATE_HESSIAN), (i, rb.status)
+            assert n_hit < 3 or rb.status == L.NDT_DEGENERATE_HESSIAN, (i, n_hit, rb.status)
+        checked += 1
+    assert checked >= 15 and n_ok >= 3
