@@ -132,3 +132,16 @@ def test_overlapping_grids_through_the_sorted_build(Matcher):
             r = m.align(d["sx"], d["sy"], d["init"])
             out[variant] = (nv, m.grid_info().n_valid, r.pose, r.iterations)
     assert out[0] == out[1] == out[2]
+
+
+@pytest.mark.parametrize("n", [5_000, 131_073, 600_000])
+def test_clouds_in_spatial_order(Matcher, n):
+    """A scan in bearing order (and a submap update in the same order): whole chunks fall into one tile - few runs of
+    thousands of points, the blocks-of-256 tail of the gather kernel's wave-per-run loop."""
+    rng = np.random.default_rng(n + 5)
+    t = np.sort(rng.uniform(0, 160, n))                    # along the walls of a 40 m room, in order
+    x = np.where(t < 40, t, np.where(t < 80, 40.0, np.where(t < 120, 120 - t, 0.0))) + rng.normal(0, 0.02, n)
+    y = np.where(t < 40, 0.0, np.where(t < 80, t - 40, np.where(t < 120, 40.0, 160 - t))) + rng.normal(0, 0.02, n)
+    x, y = x.astype(np.float32), y.astype(np.float32)
+    m = n // 3
+    _check(Matcher, x, y, adds=[(x[:m] + np.float32(0.13), y[:m], None), (x[m:2 * m], y[m:2 * m], (0.2, -0.1, 0.01))])
