@@ -359,6 +359,34 @@ def lidar_batch_rate(dev, dev_index, n_pairs: int = 4096, npts: int = 1000, uniq
             "pair_iterations_per_s": round(n_pairs * K_GN / (best * 1e-3), 1), "pairs_ok": ok}
 
 
+def overlap_batch_rate(dev, dev_index, n_pairs: int = 256, npts: int = 100_000):
+    """The loop-closure batch with Biber's four overlapping grids (overlap_grids = 4: every pair on the global-table
+    variant, the four grids taking turns in LDS) on config-4 pairs generated in HBM; one pair is
+    checked against the single-pair path with the same option."""
+    from gtsam_ndt_amd import synth_dev
+    from gtsam_ndt_amd.matcher import NdtBatch2D, NdtMatcher2D
+    t = synth_dev.config4_batch(0, n_pairs, npts, npts, device=dev)
+    with NdtBatch2D(device=dev_index, fixed_iterations=K_GN, overlap_grids=4) as b:
+        side = torch.cuda.ExternalStream(b.stream)
+        best = None
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            out = b.align_dev(t["tx"], t["ty"], t["toff"], t["sx"], t["sy"], t["soff"], t["init"])
+            e1.record(side)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        rows = NdtBatch2D.decode(out)
+    with NdtMatcher2D(device=dev_index, fixed_iterations=K_GN, overlap_grids=4) as m:
+        m.set_target(t["tx"][:npts], t["ty"][:npts])
+        r0 = m.align(t["sx"][:npts], t["sy"][:npts], tuple(t["init"][0].tolist()))
+    err = max(abs(u - v) for u, v in zip(rows[0].pose, r0.pose))
+    return {"workload": f"{n_pairs} config-4 pairs ({npts}/{npts} points), overlap_grids = 4, fixed {K_GN} iterations per pair",
+            "ms_per_batch": round(best, 4), "pair_iterations_per_s": round(n_pairs * K_GN / (best * 1e-3), 1),
+            "pairs_ok": sum(r.status == 0 and r.iterations == K_GN for r in rows), "pose_err_vs_single_pair": float(f"{err:.3g}")}
+
+
 def load_traffic():
     """HBM bytes per k_iterate launch from the committed PMC profile (profiles/), or None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -1023,6 +1051,7 @@ def main():
             out["configs_1_2"] = [single_pair_rate(dev, dev_index, c, a.steps, a.warmup) for c in (1, 2)]
         if a.all_configs:
             out["batch_lidar_sized"] = lidar_batch_rate(dev, dev_index)
+            out["batch_overlap_grids"] = overlap_batch_rate(dev, dev_index)
             # the same kernel with enough work per launch to leave the latency regime: a 1M-point source
             out["config3_with_1M_point_source"] = single_pair_rate(dev, dev_index, 3, max(5, a.steps // 5), 2, n_src=1_000_000)
             if not a.no_3d:
