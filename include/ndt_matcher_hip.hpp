@@ -487,6 +487,8 @@ class NdtMatcherHip3 {
   NdtMatcherHip3& operator=(const NdtMatcherHip3&) = delete;
 
   void setTarget(const float* x, const float* y, const float* z, size_t n) { check(ndt3d_set_target(h_, x, y, z, n), "ndt3d_set_target"); }
+  // execution-strategy knobs of a 3D handle (NDT_TUNE_SINGLE_SYNC_BUILD)
+  void setTuning(int32_t knob, int64_t value) { check(ndt3d_set_tuning(h_, knob, value), "ndt3d_set_tuning"); }
   // incremental voxel-grid update: returns the number of points outside the cached extent
   size_t addTargetPoints(const float* x, const float* y, const float* z, size_t n) {
     size_t outside = 0;

@@ -87,6 +87,17 @@ int main(int argc, char** argv) {
     ndt::NdtBatchHip bp(ndt::NdtBatchHip::standardPyramid(), 0);
     const auto rp = bp.align({t}, {s}, {ndt::Pose2{guess.x + 0.5, guess.y - 0.4, guess.theta + 0.04}});
     std::printf("pyramid %.17g %.17g %.17g %d %d\n", rp[0].pose.x, rp[0].pose.y, rp[0].pose.theta, rp[0].iterations, rp[0].status);
+    {   // Biber's four overlapping grids: the single-pair path and the batch path with the same option
+      ndt2d_params po = ndt::NdtMatcherHip::defaultParams();
+      po.overlap_grids = 4;
+      ndt::NdtMatcherHip mo(po);
+      mo.setTarget(tx, ty);
+      const ndt::MatchResult ro = mo.align(sx, sy, guess);
+      ndt::NdtBatchHip bo(po);
+      const auto rbo = bo.align({t}, {s}, {guess});
+      std::printf("overlap %.17g %.17g %.17g %d %d %.17g %.17g %.17g %d %d\n", ro.pose.x, ro.pose.y, ro.pose.theta, ro.iterations,
+                  ro.status, rbo[0].pose.x, rbo[0].pose.y, rbo[0].pose.theta, rbo[0].iterations, rbo[0].status);
+    }
     ndt::NdtMultiHip mm(ndt::NdtMatcherHip::defaultParams(), {0, 0});   // two contexts on device 0
     const auto rm = mm.align({t, t, t}, {s, s, s}, {guess, guess, guess});
     std::printf("multi %.17g %.17g %.17g %d %d\n", rm[2].pose.x, rm[2].pose.y, rm[2].pose.theta, rm[2].iterations, rm[2].status);

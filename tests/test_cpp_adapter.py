@@ -78,6 +78,12 @@ def test_adapter_matches_oracle(exe, tmp_path, gpu_lib):
         rp = bp.align([(d["tx"], d["ty"])], [(d["sx"], d["sy"])], [guess])[0]
     got = [float(v) for v in lines["pyramid"][:3]]
     assert got == list(rp.pose) and int(lines["pyramid"][3]) == rp.iterations and int(lines["pyramid"][4]) == rp.status
+    # Biber's four overlapping grids through the adapter: single-pair path and batch path agree
+    ov = [float(v) for v in lines["overlap"]]
+    assert int(ov[4]) == 0 and int(ov[9]) == 0 and max(abs(ov[k] - ov[5 + k]) for k in range(3)) < 2e-5
+    prm4 = o.NdtParams(overlap=4)
+    ref4 = o.align(o.build_grids(d["tx"], d["ty"], prm4), d["sx"], d["sy"], d["init"], prm4)
+    assert max(abs(ov[k] - ref4["pose"][k]) for k in range(3)) < 1e-4
     assert abs(float(lines["infocov"][0]) - 1.0) < 1e-6
     assert abs(float(lines["localcov"][0]) - 1.0) < 1e-9 and abs(float(lines["localcov"][1]) - 1.0) < 1e-12
     # the 3D adapter on a self-generated room: the known motion (0.20, -0.15, 0.05, yaw 0.02) comes back
