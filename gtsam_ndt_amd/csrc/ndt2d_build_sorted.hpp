@@ -407,8 +407,8 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(const float2* __
   // A wave per run, four runs in flight: wave w takes the runs w, w + 16, ... of this tile.  The loads of four runs
   // are issued before any point is summed - one load per lane and run covers a run of up to 64 points, which is
   // nearly every run of a large cloud (a tile's share of a 4096-point chunk); a loop with one dependent load per
-  // trip ran at the memory latency (10 us per tile, seen with in-kernel clocks).  Longer runs (a sorted scan puts
-  // whole chunks into one tile) go on in blocks of 256 points, again with four loads in flight.
+  // trip ran at the memory latency (10 us per tile, seen with in-kernel clocks).  Longer runs go on below, again with
+  // four loads in flight.
   // (workgroup `sub` of the nsub that share the tile takes the runs sub, sub + nsub, ...; wave w every 16th of those)
   const int kstep = 16 * nsub;
   for (int k0 = sub + nsub * wave; k0 < nchunks; k0 += 4 * kstep) {
@@ -427,19 +427,26 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(const float2* __
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if ((unsigned)lane < len[j]) add_point(p[j]);
+    // the rest of a long run: every lane takes a CONTIGUOUS slice of it, so the lanes of one instruction are a slice
+    // apart.  Long runs come from clouds in spatial order (a bearing-ordered scan puts whole chunks into one tile), where
+    // neighbours in the array share a cell: lane = point mod 64 put a wave's 64 atomics on one or two LDS words.
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      for (unsigned int off = 64; off < len[j]; off += 256) {        // uniform trip count per run
-        float2 t[4];
+      if (len[j] > 64u) {                                            // uniform
+        const unsigned int slice = (len[j] - 64u + 63u) >> 6;
+        const unsigned int first = 64u + (unsigned)lane * slice;
+        constexpr int kF = 4;                                        // loads in flight per lane (8: the same time)
+        for (unsigned int i0 = 0; i0 < slice; i0 += kF) {            // uniform trip count per run
+          float2 t[kF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned int o = off + 64 * u + lane;
-          t[u] = make_float2(0.f, 0.f);
-          if (o < len[j]) t[u] = r[j][o];
+          for (int u = 0; u < kF; ++u) {
+            t[u] = make_float2(0.f, 0.f);
+            if (i0 + u < slice && first + i0 + u < len[j]) t[u] = r[j][first + i0 + u];
+          }
+#pragma unroll
+          for (int u = 0; u < kF; ++u)
+            if (i0 + u < slice && first + i0 + u < len[j]) add_point(t[u]);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (off + 64 * u + lane < len[j]) add_point(t[u]);
       }
     }
   }
