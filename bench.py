@@ -188,6 +188,40 @@ def build_legs(m, tx, ty, sx, sy, pose, reps: int = 30):
     return grid, upd
 
 
+def ordered_build_leg(dev, dev_index, reps: int = 24):
+    """The grid build on points in the order a front end delivers them instead of the generator's shuffled order: the
+    1M-point config-3 submap room by room, each room's points by bearing around the room's centre (a submap that is a
+    sequence of scans), and the 100k-point scan by bearing around the sensor ("the order of the
+    points").  Same grids bit for bit (exact integer sums); host call to return."""
+    from gtsam_ndt_amd import synth
+    from gtsam_ndt_amd.matcher import NdtMatcher2D
+    d = synth.make_pair(3)
+
+    def by_bearing(x, y, cx, cy):
+        o = np.argsort(np.arctan2(y - cy, x - cx), kind="stable")
+        return x[o].copy(), y[o].copy()
+
+    x, y, L = d["tx"], d["ty"], 50.0
+    i, j = np.floor((x + 100.0) / L).clip(0, 3).astype(int), np.floor((y + 100.0) / L).clip(0, 3).astype(int)
+    xs, ys = [], []
+    for r in range(16):
+        sel = (j * 4 + i) == r
+        a, b = by_bearing(x[sel], y[sel], (r % 4) * L - 100.0 + 0.5 * L, (r // 4) * L - 100.0 + 0.5 * L)
+        xs.append(a); ys.append(b)
+    tx, ty = (torch.from_numpy(np.concatenate(v)).to(dev) for v in (xs, ys))
+    sx, sy = (torch.from_numpy(v).to(dev) for v in by_bearing(d["sx"], d["sy"], 0.0, 0.0))
+    torch.cuda.synchronize()
+    with NdtMatcher2D(device=dev_index) as m:
+        tb, tu = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter(); info = m.set_target(tx, ty); tb.append(time.perf_counter() - t0)
+        for _ in range(reps):
+            t0 = time.perf_counter(); m.add_target_points(sx, sy, pose=d["pose"]); tu.append(time.perf_counter() - t0)
+    return {"workload": "config 3 with the submap room by room in bearing order and the scan in bearing order (the shuffled order is grid_build / submap_update)",
+            "set_target_ms_per_call": round(1e3 * float(np.median(tb[3:])), 4), "update_ms_per_call": round(1e3 * float(np.median(tu[3:])), 4),
+            "n_valid": int(info.n_valid)}
+
+
 def multi_start_rate(dev_index, tx, ty, sx, sy, init, m: int, steps: int, warmup: int):
     """ndt2d_align_multi_start_dev on the headline pair: m starts around the initial guess carried by one
     launch chain, fixed K iterations each (every start bit-identical to its single-start alignment).
@@ -1052,6 +1086,7 @@ def main():
         if a.all_configs:
             out["batch_lidar_sized"] = lidar_batch_rate(dev, dev_index)
             out["batch_overlap_grids"] = overlap_batch_rate(dev, dev_index)
+            out["grid_build_ordered"] = ordered_build_leg(dev, dev_index)
             # the same kernel with enough work per launch to leave the latency regime: a 1M-point source
             out["config3_with_1M_point_source"] = single_pair_rate(dev, dev_index, 3, max(5, a.steps // 5), 2, n_src=1_000_000)
             if not a.no_3d:
