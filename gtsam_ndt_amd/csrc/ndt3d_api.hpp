@@ -25,6 +25,7 @@ struct ndt3d_handle {
   int last_ntile = 0;                 // tiles of the grid the handle holds (0: none): the launch bound of a single-sync build
   unsigned int* h_pub3 = nullptr;     // pinned [64 + 16]: the accumulator block's first 64 words of a single-sync build, flag at [64]
   bool one_round_trip = true;
+  size_t tiles_clean = 0;             // leading words of d_tiles known to be zero (the last build's publish cleared them)
   unsigned char* d_split3 = nullptr; size_t split3_cap = 0;   // shared tiles' hand-off (ndt3d_build.hpp Split3Bufs): part table | slab pool
   float *d_s[3] = {nullptr, nullptr, nullptr}; size_t scap = 0;
   ndt::AlignStatic3* d_static = nullptr;
@@ -96,6 +97,7 @@ int32_t ensure_build3_bufs(ndt3d_handle* h, size_t n, int ntile, bool binned, Bu
     h->d_tiles = nullptr; h->tile_cap = 0;
     HIP_TRY(hipMalloc((void**)&h->d_tiles, tneed * sizeof(unsigned int)));
     h->tile_cap = tneed;
+    h->tiles_clean = 0;
   }
   B->d_cnt = reinterpret_cast<int*>(h->d_tiles);
   B->d_out = reinterpret_cast<unsigned long long*>(h->d_tiles + 32);
@@ -147,16 +149,17 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
                *d_wgmap = B.d_wgmap;
   const size_t wg_bound = B.wg_bound;
   const Split3Bufs sb = B.sb;
-  HIP_TRY(hipMemsetAsync(h->d_tiles, 0, B.zero_words * sizeof(unsigned int), h->stream));
+  // (the publish of the build before cleared the block, unless this one needs more of it or that one did not finish)
+  const bool clean = h->tiles_clean >= B.zero_words;
+  h->tiles_clean = 0;
+  if (!clean) HIP_TRY(hipMemsetAsync(h->d_tiles, 0, B.zero_words * sizeof(unsigned int), h->stream));
   if (binned) {
     // binned build (ndt3d_build.hpp)
     const BinGeom3 bg{g.ox, g.oy, g.oz, g.inv_c, g.W, g.H, g.D, ntx, nty, ntile};
     size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
-                       dz, n, bg, d_total, d_out, Geom3Args{});
-    hipLaunchKernelGGL(k_tile_scan3, dim3(1), dim3(1024), 0, h->stream, d_total, d_start, d_cursor, ntile, d_wgtotal, d_wgmap,
-                       (const GeomDev3*)nullptr);
+                       dz, n, bg, d_total, d_out, Geom3Args{}, Scan3Out{h->d_tiles + 41, d_start, d_cursor, d_wgtotal, d_wgmap});
     hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
                        dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2], (const GeomDev3*)nullptr);
     // (no fill of the grid's sums: the workgroup that finishes a tile writes every voxel's sums, empty ones included)
@@ -179,17 +182,18 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
   {
     int* flag = reinterpret_cast<int*>(static_cast<char*>(h->h_small) + 192);
     h->publish_seq = h->publish_seq == 0x7fffffff ? 1 : h->publish_seq + 1;
-    hipLaunchKernelGGL(k_build_publish, dim3(1), dim3(64), 0, h->stream, (const unsigned int*)h->d_tiles, (unsigned int*)hc, 34, flag,
-                       h->publish_seq);
+    hipLaunchKernelGGL(k_build_publish_clear3, dim3(1), dim3(256), 0, h->stream, h->d_tiles, (unsigned int*)hc, 34, flag, h->publish_seq,
+                       (int)B.zero_words);
     HIP_TRY(hipGetLastError());
     bool seen = false;
     const int want = h->publish_seq;
     HIP_TRY(spin_until(h->stream, [&]() { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want; }, &seen));
-    if (!seen) {
-      HIP_TRY(hipMemcpyAsync(hc, h->d_tiles, 136, hipMemcpyDeviceToHost, h->stream));
+    if (!seen) {       // a second of silence: the kernel's own stores are the only copy (it clears the block behind them)
       HIP_TRY(hipStreamSynchronize(h->stream));
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) { set_error("the voxel-grid build did not report its end"); return NDT_ERR_HIP; }
     }
   }
+  h->tiles_clean = B.zero_words;
   if (h_outside) *h_outside = *ho;
   int n_valid_sum = 0, n_over_sum = 0;
   sum_count_shards(hc, &n_valid_sum, &n_over_sum);
@@ -253,6 +257,7 @@ int32_t set_target3_single_sync(ndt3d_handle* h, const float* dx, const float* d
   if (!h->d_parts3) HIP_TRY(hipMalloc((void**)&h->d_parts3, 256 * 8 * sizeof(float)));
   Build3Bufs B{};
   { const int32_t bs = ensure_build3_bufs(h, n, tile_bound, true, &B); if (bs != NDT_OK) return bs; }
+  h->tiles_clean = 0;                                      // (k_bounds3_parts clears the block for this build)
   int sbk = stream_blocks(n);
   if (sbk > 256) sbk = 256;
   const GeomDev3* dg = reinterpret_cast<const GeomDev3*>(h->d_tiles + kGeom3Word);
@@ -268,8 +273,7 @@ int32_t set_target3_single_sync(ndt3d_handle* h, const float* dx, const float* d
   size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), tile_bound * sizeof(unsigned int), h->stream, dx, dy, dz, n,
-                     none, B.d_total, B.d_out, ga);
-  hipLaunchKernelGGL(k_tile_scan3, dim3(1), dim3(1024), 0, h->stream, B.d_total, B.d_start, B.d_cursor, tile_bound, B.d_wgtotal, B.d_wgmap, dg);
+                     none, B.d_total, B.d_out, ga, Scan3Out{h->d_tiles + 41, B.d_start, B.d_cursor, B.d_wgtotal, B.d_wgmap});
   hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * tile_bound * sizeof(unsigned int), h->stream, dx, dy, dz,
                      n, none, B.d_cursor, h->d_b[0], h->d_b[1], h->d_b[2], dg);
   hipLaunchKernelGGL(k_tile_accumulate3, dim3((unsigned)B.wg_bound), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1], h->d_b[2],
@@ -280,16 +284,17 @@ int32_t set_target3_single_sync(ndt3d_handle* h, const float* dx, const float* d
   {
     int* flag = reinterpret_cast<int*>(hp + 64);
     h->publish_seq = h->publish_seq == 0x7fffffff ? 1 : h->publish_seq + 1;
-    hipLaunchKernelGGL(k_build_publish, dim3(1), dim3(64), 0, h->stream, (const unsigned int*)h->d_tiles, hp, 64, flag, h->publish_seq);
+    hipLaunchKernelGGL(k_build_publish_clear3, dim3(1), dim3(256), 0, h->stream, h->d_tiles, hp, 64, flag, h->publish_seq, (int)B.zero_words);
     HIP_TRY(hipGetLastError());
     bool seen = false;
     const int want = h->publish_seq;
     HIP_TRY(spin_until(h->stream, [&]() { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want; }, &seen));
     if (!seen) {
-      HIP_TRY(hipMemcpyAsync(hp, h->d_tiles, 256, hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) { set_error("the voxel-grid build did not report its end"); return NDT_ERR_HIP; }
     }
   }
+  h->tiles_clean = B.zero_words;
   const GeomDev3* hg = reinterpret_cast<const GeomDev3*>(hp + kGeom3Word);
   for (int j = 0; j < 6; ++j) hb_out[j] = hg->bounds[j];
   *have_bounds = true;

@@ -120,11 +120,71 @@ __device__ __forceinline__ bool reduce_and_decide3(const Geom3Args& ga, BinGeom3
   return ok;
 }
 
+// workgroups that share a tile of `points` points
+__device__ __forceinline__ int tile3_subs(unsigned int points) {
+  const int nsub = (int)((points + kTile3SubMin - 1) / kTile3SubMin);
+  return nsub < 1 ? 1 : (nsub > kTile3Split ? kTile3Split : nsub);
+}
+static_assert(kBinMaxTiles <= (1 << 24) && kTile3Split <= 256, "wg_map packs tile | share << 24");
+
+// What follows the count: the exclusive scan of the tile totals (starts and scatter cursors) and, beside it, of the
+// workgroups each tile gets: wg_map lists the (tile, share) pairs one after the other - tile | share << 24 - so that
+// k_tile_accumulate3 is launched with one workgroup per entry (at most ntile + n / kTile3SubMin) instead of
+// ntile x kTile3Split, most of which had nothing to do and still had to be dispatched: 2904 workgroups for the 363 tiles
+// of a config-5 scan, the last of them starting 15 us into the kernel (in-kernel clocks).
+// Run by ONE workgroup of kBinThreads threads - the workgroup of k_tile_count3 that finishes last (a one-workgroup kernel
+// of its own was 3.9 us of the build plus a kernel boundary); the totals were added by agent-scope atomics and are read
+// with agent-scope loads.  ntile <= kBinMaxTiles.
+struct Scan3Out {
+  unsigned int* done;          // arrivals of k_tile_count3's workgroups (in the accumulator block: cleared with it)
+  unsigned int* tile_start;    // [ntile + 1]
+  unsigned int* tile_cursor;   // [ntile]
+  unsigned int* wg_total;      // [1]
+  unsigned int* wg_map;        // [ntile + n / kTile3SubMin + 1]
+};
+__device__ __forceinline__ void tile3_scan_block(const unsigned int* __restrict__ tile_total, int ntile, const Scan3Out& so) {
+  __shared__ unsigned int s_wv[2][kBinThreads / 64];
+  const int per = (ntile + kBinThreads - 1) / kBinThreads;
+  const int t0 = threadIdx.x * per;
+  unsigned int local = 0, lwg = 0;
+  for (int k = 0; k < per; ++k)
+    if (t0 + k < ntile) {
+      const unsigned int c = __hip_atomic_load(tile_total + t0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      local += c; lwg += (unsigned int)tile3_subs(c);
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int inc = local, iwg = lwg;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned int v = __shfl_up(inc, d, 64), w = __shfl_up(iwg, d, 64);
+    if (lane >= d) { inc += v; iwg += w; }
+  }
+  if (lane == 63) { s_wv[0][wave] = inc; s_wv[1][wave] = iwg; }
+  __syncthreads();
+  unsigned int base = 0, bwg = 0;
+  for (int w = 0; w < wave; ++w) { base += s_wv[0][w]; bwg += s_wv[1][w]; }
+  unsigned int run = base + inc - local, rwg = bwg + iwg - lwg;
+  for (int k = 0; k < per; ++k) {
+    if (t0 + k < ntile) {
+      const unsigned int c = __hip_atomic_load(tile_total + t0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      so.tile_start[t0 + k] = run;
+      so.tile_cursor[t0 + k] = run;
+      run += c;
+      const int ns = tile3_subs(c);
+      for (int sb = 0; sb < ns; ++sb) so.wg_map[rwg + sb] = (unsigned int)(t0 + k) | ((unsigned int)sb << 24);
+      rwg += (unsigned int)ns;
+    }
+  }
+  if (threadIdx.x == kBinThreads - 1) { so.tile_start[ntile] = run; *so.wg_total = rwg; }
+}
+
 __global__ __launch_bounds__(kBinThreads) void k_tile_count3(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ z, size_t n, BinGeom3 g,
                                                               unsigned int* __restrict__ tile_total,
-                                                              unsigned long long* __restrict__ n_outside, Geom3Args ga) {
+                                                              unsigned long long* __restrict__ n_outside, Geom3Args ga,
+                                                              Scan3Out so) {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_hist[];
+  __shared__ int s_last;
   if (ga.parts) {                                          // geometry decided here (the LDS covers the host's tile bound)
     __shared__ BinGeom3 s_bin;
     __shared__ int s_ok;
@@ -151,6 +211,14 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_count3(const float* __rest
     if (c) atomicAdd(&tile_total[t], c);
   }
   if (n_outside && outside) atomicAdd(n_outside, (unsigned long long)outside);
+  // the workgroup whose adds come last scans the totals (every adding wave drains its atomics, the workgroup meets, one
+  // lane takes the ticket: MI355X_MICROARCH.md "Valid forms", agent atomics on both sides)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(so.done, 1u) == gridDim.x - 1u ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;                               // uniform
+  tile3_scan_block(tile_total, g.ntile, so);
 }
 
 __global__ __launch_bounds__(kBinThreads) void k_tile_scatter3(const float* __restrict__ x, const float* __restrict__ y,
@@ -211,55 +279,6 @@ struct Split3Bufs {
                                    // workgroups and only tiles of more than SubMin points are shared
 };
 
-// workgroups that share a tile of `points` points
-__device__ __forceinline__ int tile3_subs(unsigned int points) {
-  const int nsub = (int)((points + kTile3SubMin - 1) / kTile3SubMin);
-  return nsub < 1 ? 1 : (nsub > kTile3Split ? kTile3Split : nsub);
-}
-
-// Exclusive scan of the tile totals (k_tile_scan) and, beside it, of the workgroups each tile gets: wg_map lists the
-// (tile, share) pairs one after the other - tile | share << 24 - so that k_tile_accumulate3 is launched with one
-// workgroup per entry (at most ntile + n / kTile3SubMin) instead of ntile x kTile3Split, most of which had nothing to
-// do and still had to be dispatched: 2904 workgroups for the 363 tiles of a config-5 scan, the last of them starting
-// 15 us into the kernel (in-kernel clocks).  One workgroup; ntile <= kBinMaxTiles.
-__global__ __launch_bounds__(1024) void k_tile_scan3(const unsigned int* __restrict__ tile_total, unsigned int* __restrict__ tile_start,
-                                                      unsigned int* __restrict__ tile_cursor, int ntile,
-                                                      unsigned int* __restrict__ wg_total, unsigned int* __restrict__ wg_map,
-                                                      const GeomDev3* __restrict__ dg) {
-  __shared__ unsigned int s_wave[2][16];
-  if (dg) { if (!dg->ok) return; ntile = dg->bin.ntile; }
-  const int per = (ntile + 1023) / 1024;
-  const int t0 = threadIdx.x * per;
-  unsigned int local = 0, lwg = 0;
-  for (int k = 0; k < per; ++k)
-    if (t0 + k < ntile) { const unsigned int c = tile_total[t0 + k]; local += c; lwg += (unsigned int)tile3_subs(c); }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned int inc = local, iwg = lwg;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned int v = __shfl_up(inc, d, 64), w = __shfl_up(iwg, d, 64);
-    if (lane >= d) { inc += v; iwg += w; }
-  }
-  if (lane == 63) { s_wave[0][wave] = inc; s_wave[1][wave] = iwg; }
-  __syncthreads();
-  unsigned int base = 0, bwg = 0;
-  for (int w = 0; w < wave; ++w) { base += s_wave[0][w]; bwg += s_wave[1][w]; }
-  unsigned int run = base + inc - local, rwg = bwg + iwg - lwg;
-  for (int k = 0; k < per; ++k) {
-    if (t0 + k < ntile) {
-      const unsigned int c = tile_total[t0 + k];
-      tile_start[t0 + k] = run;
-      tile_cursor[t0 + k] = run;
-      run += c;
-      const int ns = tile3_subs(c);
-      for (int sb = 0; sb < ns; ++sb) wg_map[rwg + sb] = (unsigned int)(t0 + k) | ((unsigned int)sb << 24);
-      rwg += (unsigned int)ns;
-    }
-  }
-  if (threadIdx.x == 1023) { tile_start[ntile] = run; *wg_total = rwg; }
-}
-static_assert(kBinMaxTiles <= (1 << 24) && kTile3Split <= 256, "wg_map packs tile | share << 24");
-
 #if defined(NDT_BUILD_PHASE_CLOCKS)
 __device__ unsigned long long g_tile3_stamps[4096][8];       // tools-only: 100 MHz clock per phase, per workgroup
 #define NDT_STAMP3(k) do { if (threadIdx.x == 0) g_tile3_stamps[blockIdx.x & 4095][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
   // (grid.y): each sums its share in LDS and leaves it as a slab (Split3Bufs); the last one to arrive adds the slabs up
   // (exact integers: any split gives the same bits) and finalises the tile.
   const unsigned int p0 = tile_start[tile], p1 = tile_start[tile + 1];
-  const int nsub = tile3_subs(p1 - p0);              // (sub < nsub: k_tile_scan3 listed the shares by the same rule)
+  const int nsub = tile3_subs(p1 - p0);              // (sub < nsub: tile3_scan_block listed the shares by the same rule)
   NDT_STAMP3(0);
   const bool split = nsub > 1;
   // init: zeros, or the cached sums of this tile's voxels (merge = incremental submap update; a shared tile's cached
@@ -476,6 +495,20 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
   NDT_STAMP3(4);
   block_count_add(counters, nvalid, nover);       // one add per workgroup, sharded (ndt_device.hpp)
   NDT_STAMP3(5);
+}
+
+// The end of a 3D build on the host's side (as k_build_publish) - and, behind the flag, the accumulator block is cleared for
+// the NEXT build, which then starts without a fill launch (the block's words are dead once they are on the host).  One
+// workgroup; wave 0 publishes.
+__global__ __launch_bounds__(256) void k_build_publish_clear3(unsigned int* __restrict__ block, unsigned int* __restrict__ host_dst,
+                                                               int nwords, int* __restrict__ host_flag, int seq, int clear_words) {
+  if (threadIdx.x < 64) {
+    for (int i = threadIdx.x; i < nwords; i += 64) __hip_atomic_store(host_dst + i, block[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();                                   // (every published word has been read)
+  for (int i = threadIdx.x; i < clear_words; i += 256) block[i] = 0u;
 }
 
 }  // namespace ndt

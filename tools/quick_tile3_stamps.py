@@ -1,5 +1,5 @@
 """Scratch: per-phase clocks of k_tile_accumulate3 (needs tools/bin/libndt_phase_clocks.so: the library built with
--DNDT_BUILD_PHASE_CLOCKS).  One row of the stamp table per workgroup (a (tile, share) pair of k_tile_scan3's list)."""
+-DNDT_BUILD_PHASE_CLOCKS).  One row of the stamp table per workgroup (a (tile, share) pair of tile3_scan_block's list)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
