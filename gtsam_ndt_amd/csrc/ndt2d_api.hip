@@ -1243,8 +1243,18 @@ const void* body_kernel(int) {              // the split chain evaluates one sta
 // of m scans (each with its initial pose).  sxs / sys / ns have one entry when shared, m otherwise.
 int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const* sys, const size_t* ns, bool shared,
                     const double* init_poses, int32_t m, ndt2d_result* results) {
-  if (h->prm.overlap_grids == 4) { set_error("multi-start / multi-scan run on the single grid only"); return NDT_ERR_INVALID_ARG; }
   if (!h->has_target) return NDT_ERR_NO_TARGET;
+  if (h->prm.overlap_grids == 4) {
+    // Biber's four overlapping grids live on k_iterate's chain only (the multi kernels would need a second set of
+    // instantiations for an option whose cost is four lookups per point anyway): the m alignments run one after the other,
+    // each bit for bit its single call - what the contract of these entry points promises - without the chain's gain.
+    for (int32_t k = 0; k < m; ++k) {
+      const int32_t st = ndt2d_align_dev(h, shared ? sxs[0] : sxs[k], shared ? sys[0] : sys[k], shared ? ns[0] : ns[k],
+                                         &init_poses[3 * k], &results[k]);
+      if (st != NDT_OK) return st;
+    }
+    return NDT_OK;
+  }
   TraceRange range(shared ? "ndt2d_align_multi_start" : "ndt2d_align_multi_scan");
   HIP_TRY(hipSetDevice(h->device));
   { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }

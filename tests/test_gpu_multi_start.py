@@ -152,11 +152,14 @@ def test_argument_checks(gpu_lib, pair2):
         with pytest.raises(L.NdtError) as e:
             mm.align_multi_start(sx, sy, [d["init"]] * 65)
         assert e.value.code == L.NDT_ERR_INVALID_ARG
+    # overlapping grids: the entry points run their alignments one by one on the single-pair chain - the same contract
     with NdtMatcher2D(overlap_grids=4) as mm:
         mm.set_target(d["tx"], d["ty"])
-        with pytest.raises(L.NdtError) as e:
-            mm.align_multi_start(sx, sy, _starts(d["init"], 2))
-        assert e.value.code == L.NDT_ERR_INVALID_ARG
+        starts = _starts(d["init"], 3)
+        multi = mm.align_multi_start(sx, sy, starts)
+        scans = mm.align_multi_scan([(sx, sy)] * 2, starts[:2])
+        single = [mm.align(sx, sy, st) for st in starts]
+        assert all(_same(a, b) for a, b in zip(multi, single)) and all(_same(a, b) for a, b in zip(scans, single))
 
 
 def _scans_of_config3(n_scans, n_pts, ragged=False):
