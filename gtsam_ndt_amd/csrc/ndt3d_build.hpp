@@ -200,10 +200,20 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_count3(const float* __rest
   for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) s_hist[t] = 0u;
   __syncthreads();
   unsigned int outside = 0;
-  for (size_t i = (size_t)blockIdx.x * kBinThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kBinThreads) {
-    const int t = tile_of3(g, x[i], y[i], z[i]);
-    if (t >= 0) atomicAdd(&s_hist[t], 1u);
-    else outside++;
+  const size_t stride = (size_t)gridDim.x * kBinThreads;
+  for (size_t i = (size_t)blockIdx.x * kBinThreads + threadIdx.x; i < n; i += 4 * stride) {      // four points in flight
+    float px[4], py[4], pz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t ii = i + u * stride;
+      px[u] = ii < n ? x[ii] : NAN; py[u] = ii < n ? y[ii] : NAN; pz[u] = ii < n ? z[ii] : NAN;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tile_of3(g, px[u], py[u], pz[u]);
+      if (t >= 0) atomicAdd(&s_hist[t], 1u);
+      else if (i + u * stride < n) outside++;
+    }
   }
   __syncthreads();
   for (int t = threadIdx.x; t < g.ntile; t += kBinThreads) {
