@@ -133,7 +133,7 @@ int32_t ensure_build3_bufs(ndt3d_handle* h, size_t n, int ntile, bool binned, Bu
 // scattered global atomics for maps beyond the tile histogram.  merge = add to the cached sums
 // (incremental submap update) instead of starting from zero.
 int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const float* dz, size_t n, bool merge,
-                    unsigned long long* h_outside) {
+                    unsigned long long* h_outside, const ndt::Rigid3F* move = nullptr) {
   using namespace ndt;
   Grid3Dev& g = h->grid;
   const size_t ncell = (size_t)g.W * g.H * g.D;
@@ -156,12 +156,14 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
   if (binned) {
     // binned build (ndt3d_build.hpp)
     const BinGeom3 bg{g.ox, g.oy, g.oz, g.inv_c, g.W, g.H, g.D, ntx, nty, ntile};
+    Move3Args mv{};
+    if (move) { mv.T = *move; mv.use = 1; }
     size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), ntile * sizeof(unsigned int), h->stream, dx, dy,
-                       dz, n, bg, d_total, d_out, Geom3Args{}, Scan3Out{h->d_tiles + 41, d_start, d_cursor, d_wgtotal, d_wgmap});
+                       dz, n, bg, d_total, d_out, Geom3Args{}, Scan3Out{h->d_tiles + 41, d_start, d_cursor, d_wgtotal, d_wgmap}, mv);
     hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * ntile * sizeof(unsigned int), h->stream,
-                       dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2], (const GeomDev3*)nullptr);
+                       dx, dy, dz, n, bg, d_cursor, h->d_b[0], h->d_b[1], h->d_b[2], (const GeomDev3*)nullptr, mv);
     // (no fill of the grid's sums: the workgroup that finishes a tile writes every voxel's sums, empty ones included)
     hipLaunchKernelGGL(k_tile_accumulate3, dim3((unsigned)wg_bound), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1],
                        h->d_b[2], d_start, g, ntx, nty, merge ? 1 : 0, h->prm.min_points, h->prm.eig_ratio, d_cnt, d_ticket, sb,
@@ -169,6 +171,14 @@ int32_t accumulate3(ndt3d_handle* h, const float* dx, const float* dy, const flo
     HIP_TRY(hipGetLastError());
     h->last_ntile = ntile;
   } else {
+    if (move) {                                      // this path takes the points as they are: move them first
+      const int32_t st = ensure3(h->d_t, &h->tcap, n);
+      if (st != NDT_OK) return st;
+      hipLaunchKernelGGL(k_transform_points3, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, *move,
+                         h->d_t[0], h->d_t[1], h->d_t[2]);
+      HIP_TRY(hipGetLastError());
+      dx = h->d_t[0]; dy = h->d_t[1]; dz = h->d_t[2];
+    }
     if (!merge) HIP_TRY(hipMemsetAsync(g.acc, 0, ncell * sizeof(CellAcc3), h->stream));
     hipLaunchKernelGGL(k_accumulate3, dim3(stream_blocks(n)), dim3(kBlock), 0, h->stream, dx, dy, dz, n, g, d_out);
     HIP_TRY(hipGetLastError());
@@ -273,9 +283,9 @@ int32_t set_target3_single_sync(ndt3d_handle* h, const float* dx, const float* d
   size_t nb = (n + kBinThreads * 4 - 1) / (kBinThreads * 4);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(k_tile_count3, dim3((unsigned)nb), dim3(kBinThreads), tile_bound * sizeof(unsigned int), h->stream, dx, dy, dz, n,
-                     none, B.d_total, B.d_out, ga, Scan3Out{h->d_tiles + 41, B.d_start, B.d_cursor, B.d_wgtotal, B.d_wgmap});
+                     none, B.d_total, B.d_out, ga, Scan3Out{h->d_tiles + 41, B.d_start, B.d_cursor, B.d_wgtotal, B.d_wgmap}, Move3Args{});
   hipLaunchKernelGGL(k_tile_scatter3, dim3((unsigned)nb), dim3(kBinThreads), 2 * tile_bound * sizeof(unsigned int), h->stream, dx, dy, dz,
-                     n, none, B.d_cursor, h->d_b[0], h->d_b[1], h->d_b[2], dg);
+                     n, none, B.d_cursor, h->d_b[0], h->d_b[1], h->d_b[2], dg, Move3Args{});
   hipLaunchKernelGGL(k_tile_accumulate3, dim3((unsigned)B.wg_bound), dim3(kBinThreads), 0, h->stream, h->d_b[0], h->d_b[1], h->d_b[2],
                      B.d_start, h->grid, 0, 0, 0, h->prm.min_points, h->prm.eig_ratio, B.d_cnt, B.d_ticket, B.sb,
                      (const unsigned int*)B.d_wgtotal, (const unsigned int*)B.d_wgmap, dg, (const Grid3Dev*)dgrid);
@@ -653,24 +663,18 @@ int32_t ndt3d_add_target_points_dev(ndt3d_handle* h, const float* d_x, const flo
   { const int32_t fs = finish_align3(h); if (fs != NDT_OK) return fs; }
   if (stream) HIP_TRY(ndt::order_after(h->stream, (hipStream_t)stream));
   const float* p[3] = {d_x, d_y, d_z};
-  if (pose) {
-    const int32_t st = ensure3(h->d_t, &h->tcap, n);
-    if (st != NDT_OK) return st;
+  ndt::Rigid3F T;
+  if (pose) {       // the points are moved on the way into the build (count and scatter passes), not by a kernel of their own
     const double ca = std::cos(pose[3]), sa = std::sin(pose[3]), cb = std::cos(pose[4]), sb = std::sin(pose[4]),
                  cg = std::cos(pose[5]), sg = std::sin(pose[5]);
     const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
                          sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
                          -sb, cb * sa, cb * ca};
-    ndt::Rigid3F T;
     for (int j = 0; j < 9; ++j) T.r[j] = (float)R[j];
     for (int j = 0; j < 3; ++j) T.t[j] = (float)pose[j];
-    hipLaunchKernelGGL(ndt::k_transform_points3, dim3((unsigned)((n + ndt::kBlock - 1) / ndt::kBlock)), dim3(ndt::kBlock), 0, h->stream,
-                       d_x, d_y, d_z, n, T, h->d_t[0], h->d_t[1], h->d_t[2]);
-    HIP_TRY(hipGetLastError());
-    for (int a = 0; a < 3; ++a) p[a] = h->d_t[a];
   }
   unsigned long long outside = 0;
-  const int32_t fs = accumulate3(h, p[0], p[1], p[2], n, /*merge=*/true, &outside);
+  const int32_t fs = accumulate3(h, p[0], p[1], p[2], n, /*merge=*/true, &outside, pose ? &T : nullptr);
   if (n_outside) *n_outside = (size_t)outside;
   if (fs != NDT_OK) { h->has_target = false; return fs; }
   return NDT_OK;

@@ -78,6 +78,13 @@ __device__ inline bool decide_geometry3(const float mn[3], const float mx[3], do
 // bounding-box partials of k_bounds3_parts (a few KB) and applies the rule - the same inputs, the same arithmetic, the same
 // grid everywhere - and workgroup 0 also writes it where the later kernels, the alignments and the host read it.  A
 // one-workgroup kernel of its own for this cost 4 us of the build plus a kernel boundary.
+// the rigid motion of a submap update (k_transform_points3's arithmetic, bit for bit), applied on the way in by both passes
+// over the cloud instead of by a kernel of its own (use = 0: none)
+struct Move3Args {
+  Rigid3F T;
+  int use;
+};
+
 struct Geom3Args {
   const float* parts;          // null: the geometry comes with the launch (BinGeom3 argument)
   int nparts;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_count3(const float* __rest
                                                               const float* __restrict__ z, size_t n, BinGeom3 g,
                                                               unsigned int* __restrict__ tile_total,
                                                               unsigned long long* __restrict__ n_outside, Geom3Args ga,
-                                                              Scan3Out so) {
+                                                              Scan3Out so, Move3Args mv) {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_hist[];
   __shared__ int s_last;
   if (ga.parts) {                                          // geometry decided here (the LDS covers the host's tile bound)
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_count3(const float* __rest
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      if (mv.use) apply_rigid3(mv.T, px[u], py[u], pz[u]);
       const int t = tile_of3(g, px[u], py[u], pz[u]);
       if (t >= 0) atomicAdd(&s_hist[t], 1u);
       else if (i + u * stride < n) outside++;
@@ -235,7 +243,8 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_scatter3(const float* __re
                                                                 const float* __restrict__ z, size_t n, BinGeom3 g,
                                                                 unsigned int* __restrict__ tile_cursor,
                                                                 float* __restrict__ bx, float* __restrict__ by,
-                                                                float* __restrict__ bz, const GeomDev3* __restrict__ dg) {
+                                                                float* __restrict__ bz, const GeomDev3* __restrict__ dg,
+                                                                Move3Args mv) {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_mem[];
   if (dg) { if (!dg->ok) return; g = dg->bin; }
   unsigned int* s_hist = s_mem;
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_scatter3(const float* __re
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      if (mv.use) apply_rigid3(mv.T, px[u], py[u], pz[u]);            // (the moved point is what is stored below)
       tile[u] = tile_of3(g, px[u], py[u], pz[u]);
       rank[u] = tile[u] >= 0 ? atomicAdd(&s_hist[tile[u]], 1u) : 0u;
     }

@@ -75,6 +75,18 @@ struct AlignDyn3 {
 // p' = ((r0 x + r1 y) + r2 z) + t per row with every float32 operation rounded separately (no contraction),
 // so that a host restatement reproduces the points bit for bit.
 struct Rigid3F { float r[9]; float t[3]; };
+// the same arithmetic for kernels that move the points on the way in (the binned build of a submap update)
+__device__ __forceinline__ void apply_rigid3(const Rigid3F& T, float& x, float& y, float& z) {
+#pragma clang fp contract(off)
+  const float px = x, py = y, pz = z;
+  float o[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float a = T.r[3 * r] * px, b = T.r[3 * r + 1] * py, c = T.r[3 * r + 2] * pz;
+    o[r] = ((a + b) + c) + T.t[r];
+  }
+  x = o[0]; y = o[1]; z = o[2];
+}
 __global__ __launch_bounds__(kBlock) void k_transform_points3(const float* __restrict__ x, const float* __restrict__ y,
                                                                const float* __restrict__ z, size_t n, Rigid3F T,
                                                                float* __restrict__ ox, float* __restrict__ oy,
