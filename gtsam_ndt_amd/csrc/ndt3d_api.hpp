@@ -26,7 +26,7 @@ struct ndt3d_handle {
   unsigned int* h_pub3 = nullptr;     // pinned [64 + 16]: the accumulator block's first 64 words of a single-sync build, flag at [64]
   bool one_round_trip = true;
   size_t tiles_clean = 0;             // leading words of d_tiles known to be zero (the last build's publish cleared them)
-  unsigned char* d_split3 = nullptr; size_t split3_cap = 0;   // shared tiles' hand-off (ndt3d_build.hpp Split3Bufs): part table | slab pool
+  unsigned char* d_split3 = nullptr; size_t split3_cap = 0;   // shared tiles' hand-off (ndt3d_build.hpp Split3Bufs): the slab pool
   float *d_s[3] = {nullptr, nullptr, nullptr}; size_t scap = 0;
   ndt::AlignStatic3* d_static = nullptr;
   ndt::AlignCall3* d_call = nullptr;
@@ -79,8 +79,8 @@ int32_t upload_static3(ndt3d_handle* h) {
 
 // The device words and buffers of a binned build of n points over at most `ntile` tiles.
 // One block of device words carries everything a build adds into, so that ONE fill clears it (round 2: four) and one
-// publish brings the results back:  counter shards [32] | outside count (u64) | pad to 64 (the shared tiles' slab cursor at
-// word 40, a device-decided geometry from word kGeom3Word) | tile totals [ntile] | tickets of the shared tiles [ntile] |
+// publish brings the results back:  counter shards [32] | outside count (u64) | pad to 64 (the arrival count of k_tile_count3's
+// workgroups at word 41, a device-decided geometry from word kGeom3Word) | tile totals [ntile] | tickets of the shared tiles [ntile] |
 // tile starts [ntile + 1] | scatter cursors [ntile] | number of (tile, share) workgroups [1] | their list [wg_bound]
 struct Build3Bufs {
   int* d_cnt; unsigned long long* d_out;
@@ -111,20 +111,16 @@ int32_t ensure_build3_bufs(ndt3d_handle* h, size_t n, int ntile, bool binned, Bu
   B->sb = Split3Bufs{};
   if (!binned) return NDT_OK;
   { const int32_t st = ensure3(h->d_b, &h->bcap, n); if (st != NDT_OK) return st; }
-  // the shared tiles' slabs: a tile of p > kTile3SubMin points is shared by ceil(p / kTile3SubMin) workgroups, so there
-  // are at most n / SubMin shared tiles and at most 2 n / SubMin slabs
-  const size_t slabs = 2 * (n / (size_t)kTile3SubMin) + 2;
-  const size_t off_pool = ((size_t)ntile * kTile3Split * sizeof(unsigned int) + 15) / 16 * 16;
-  const size_t need = off_pool + slabs * kSlabWords * sizeof(unsigned long long);
+  // the shared tiles' slabs: one per workgroup of the tile kernel's launch (only the shares of shared tiles use theirs)
+  const size_t slabs = B->wg_bound;
+  const size_t need = slabs * kSlabWords * sizeof(unsigned long long);
   if (need > h->split3_cap) {
     if (h->d_split3) (void)hipFree(h->d_split3);
     h->d_split3 = nullptr; h->split3_cap = 0;
     HIP_TRY(hipMalloc((void**)&h->d_split3, need + need / 4));
     h->split3_cap = need + need / 4;
   }
-  B->sb.cursor = h->d_tiles + 40;                      // (cleared with the block)
-  B->sb.part = reinterpret_cast<unsigned int*>(h->d_split3);
-  B->sb.pool = reinterpret_cast<unsigned long long*>(h->d_split3 + off_pool);
+  B->sb.pool = reinterpret_cast<unsigned long long*>(h->d_split3);
   B->sb.capacity = (unsigned int)(slabs > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : slabs);
   return NDT_OK;
 }

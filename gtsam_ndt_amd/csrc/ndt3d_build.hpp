@@ -285,18 +285,15 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_scatter3(const float* __re
 }
 
 // What the workgroups that share a tile hand to the one that finishes it: every one of them leaves its 64 voxels' sums as
-// a slab in a pool (write-through stores; a cursor hands out the slabs), the last to arrive (a ticket per tile) adds the
+// a slab in a pool (write-through stores; slab = the workgroup's number), the last to arrive (a ticket per tile) adds the
 // others' slabs to its own sums.  Round 2 added each share to the grid's sums with ten global atomics per voxel - 640 per
 // workgroup, up to eight workgroups on the same 640 words, performed one after the other at the memory side - and read
 // the totals back; that also needed the grid's sums cleared by a fill launch before every build.
 constexpr int kCopies3 = 8;                                       // private copies of a tile's sums in k_tile_accumulate3's point loop
 constexpr int kSlabWords = 9 * kTile3Cells + kTile3Cells / 2;       // 64-bit words: 9 sums per voxel, then the counts as u32 pairs
 struct Split3Bufs {
-  unsigned int* cursor;            // next free slab (cleared with the build's other accumulators)
-  unsigned int* part;              // [tiles][kTile3Split]: slab index of the tile's workgroup `sub` (0xFFFFFFFF: the pool was full)
-  unsigned long long* pool;        // [capacity][kSlabWords]
-  unsigned int capacity;           // slabs; the host sizes it for 2 n / kTile3SubMin + 2: a tile is shared by ceil(points / SubMin)
-                                   // workgroups and only tiles of more than SubMin points are shared
+  unsigned long long* pool;        // [capacity][kSlabWords]: slab b belongs to workgroup b of k_tile_accumulate3
+  unsigned int capacity;           // slabs: the launch's workgroups (ntile + n / kTile3SubMin + 1)
 };
 
 #if defined(NDT_BUILD_PHASE_CLOCKS)
@@ -329,7 +326,6 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
   __shared__ __attribute__((aligned(16))) unsigned long long s_sum[9][kTile3Cells];
   __shared__ unsigned int s_n[kTile3Cells];
   __shared__ int s_last;
-  __shared__ unsigned int s_slab;
   if (dg) {        // geometry from the device; storage (g.rec, g.acc) from the launch
     if (!dg->ok) return;
     ntx = dg->bin.ntx; nty = dg->bin.nty;
@@ -423,10 +419,10 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
     // [r3] No fences (MI355X_MICROARCH.md "Valid forms"): every handed-over word is stored write-through (agent-scope
     // atomic stores) and loaded with agent-scope loads, every storing wave drains its stores, the workgroup meets, one
     // lane takes the tile's ticket.  A __threadfence() here is a write-back AND an invalidate of the whole L2.
-    if (threadIdx.x == 0) s_slab = atomicAdd(sb.cursor, 1u);
-    __syncthreads();
-    const unsigned int slab = s_slab;
-    const bool have = slab < sb.capacity;              // (always, by the host's sizing; a full pool is reported, not overrun)
+    // A share's slab is the one with its workgroup's number (the list of k_tile_count3's scan gives every (tile, share) its
+    // own): no cursor to take, no table to look the others' slabs up in - the shares of a tile are neighbours in the list.
+    const unsigned int slab = blockIdx.x;
+    const bool have = slab < sb.capacity;              // (always: the host sizes the pool for the launch)
     if (have) {
       unsigned long long* dst = sb.pool + (size_t)slab * kSlabWords;
       const unsigned long long* src = &s_sum[0][0];
@@ -436,8 +432,6 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
                            (unsigned long long)s_n[2 * threadIdx.x] | ((unsigned long long)s_n[2 * threadIdx.x + 1] << 32), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0)
-      __hip_atomic_store(sb.part + (size_t)tile * kTile3Split + sub, have ? slab : 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(&tile_ticket[tile], 1u) == (unsigned)(nsub - 1) ? 1 : 0;
@@ -451,8 +445,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
       unsigned int idx[kTile3Split];
 #pragma unroll
       for (int o = 0; o < kTile3Split; ++o)
-        idx[o] = (o < nsub && o != sub) ? __hip_atomic_load(sb.part + (size_t)tile * kTile3Split + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                        : 0xFFFFFFFEu;
+        idx[o] = (o < nsub && o != sub) ? blockIdx.x - (unsigned)sub + (unsigned)o : 0xFFFFFFFEu;
 #pragma unroll
       for (int o = 0; o < kTile3Split; ++o) {
 #pragma unroll
@@ -462,7 +455,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_accumulate3(const float* _
           if (idx[o] < sb.capacity && e < kSlabWords)
             w[o][j] = __hip_atomic_load(sb.pool + (size_t)idx[o] * kSlabWords + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (idx[o] == 0xFFFFFFFFu && threadIdx.x == 0) nover = 1;      // the pool was full: a share is missing, the build reports it
+        if (idx[o] != 0xFFFFFFFEu && idx[o] >= sb.capacity && threadIdx.x == 0) nover = 1;   // a pool smaller than the launch: reported, not overrun
       }
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {
