@@ -1226,7 +1226,8 @@ int32_t ndt2d_align(ndt2d_handle* h, const float* sx, const float* sy, size_t n,
 namespace {
 
 template <int MODE, int THREADS, bool SHARED>
-const void* multi_kernel(int nh) {
+const void* multi_kernel(int nh, bool four) {
+  if (four) return (const void*)&k_iterate_multi<MODE, 1, THREADS, SHARED, 4>;     // overlapping grids: one start per workgroup
   if constexpr (THREADS <= 256) {           // a 1024-thread workgroup fills its CU with one start
     if (nh == 2) return (const void*)&k_iterate_multi<MODE, 2, THREADS, SHARED>;
     if (nh == 4) return (const void*)&k_iterate_multi<MODE, 4, THREADS, SHARED>;
@@ -1235,7 +1236,8 @@ const void* multi_kernel(int nh) {
 }
 
 template <int MODE, int THREADS, bool SHARED>
-const void* body_kernel(int) {              // the split chain evaluates one start per workgroup
+const void* body_kernel(int, bool four) {   // the split chain evaluates one start per workgroup
+  if (four) return (const void*)&k_multi_body<MODE, 1, THREADS, SHARED, 4>;
   return (const void*)&k_multi_body<MODE, 1, THREADS, SHARED>;
 }
 
@@ -1244,17 +1246,6 @@ const void* body_kernel(int) {              // the split chain evaluates one sta
 int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const* sys, const size_t* ns, bool shared,
                     const double* init_poses, int32_t m, ndt2d_result* results) {
   if (!h->has_target) return NDT_ERR_NO_TARGET;
-  if (h->prm.overlap_grids == 4) {
-    // Biber's four overlapping grids live on k_iterate's chain only (the multi kernels would need a second set of
-    // instantiations for an option whose cost is four lookups per point anyway): the m alignments run one after the other,
-    // each bit for bit its single call - what the contract of these entry points promises - without the chain's gain.
-    for (int32_t k = 0; k < m; ++k) {
-      const int32_t st = ndt2d_align_dev(h, shared ? sxs[0] : sxs[k], shared ? sys[0] : sys[k], shared ? ns[0] : ns[k],
-                                         &init_poses[3 * k], &results[k]);
-      if (st != NDT_OK) return st;
-    }
-    return NDT_OK;
-  }
   TraceRange range(shared ? "ndt2d_align_multi_start" : "ndt2d_align_multi_scan");
   HIP_TRY(hipSetDevice(h->device));
   { const int32_t fs = finish_chunk_run(h); if (fs != NDT_OK) return fs; }
@@ -1283,7 +1274,8 @@ int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const
   const bool split = m >= h->split_from;
   // fused chain: six one-start workgroups fit a CU (78 VGPRs), more starts double up inside the workgroups;
   // split chain: one start per evaluation workgroup (measured best: 31.8 us per step at 64 starts, 33.0 with four)
-  const int nh = (split || wide || m <= 6) ? 1 : (m <= 12 ? 2 : 4);
+  const bool four = h->prm.overlap_grids == 4;     // Biber's four overlapping grids: every point scores against all four (NG = 4)
+  const int nh = (split || wide || m <= 6 || four) ? 1 : (m <= 12 ? 2 : 4);
   const int subsets = (m + nh - 1) / nh;
   // From kSplitFrom starts on the chain alternates two kernels per iteration (one workgroup per start solves,
   // then everybody evaluates): the 256-fold redundant prologues of the fused kernel cost more than the
@@ -1291,18 +1283,18 @@ int32_t multi_align(ndt2d_handle* h, const float* const* sxs, const float* const
   const void* func;
   if (!split) {
     if (shared)
-      func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, true>(nh) : multi_kernel<0, kIterThreadsWide, true>(nh))
-                  : (newton ? multi_kernel<1, kIterThreads, true>(nh) : multi_kernel<0, kIterThreads, true>(nh));
+      func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, true>(nh, four) : multi_kernel<0, kIterThreadsWide, true>(nh, four))
+                  : (newton ? multi_kernel<1, kIterThreads, true>(nh, four) : multi_kernel<0, kIterThreads, true>(nh, four));
     else
-      func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, false>(nh) : multi_kernel<0, kIterThreadsWide, false>(nh))
-                  : (newton ? multi_kernel<1, kIterThreads, false>(nh) : multi_kernel<0, kIterThreads, false>(nh));
+      func = wide ? (newton ? multi_kernel<1, kIterThreadsWide, false>(nh, four) : multi_kernel<0, kIterThreadsWide, false>(nh, four))
+                  : (newton ? multi_kernel<1, kIterThreads, false>(nh, four) : multi_kernel<0, kIterThreads, false>(nh, four));
   } else {
     if (shared)
-      func = wide ? (newton ? body_kernel<1, kIterThreadsWide, true>(nh) : body_kernel<0, kIterThreadsWide, true>(nh))
-                  : (newton ? body_kernel<1, kIterThreads, true>(nh) : body_kernel<0, kIterThreads, true>(nh));
+      func = wide ? (newton ? body_kernel<1, kIterThreadsWide, true>(nh, four) : body_kernel<0, kIterThreadsWide, true>(nh, four))
+                  : (newton ? body_kernel<1, kIterThreads, true>(nh, four) : body_kernel<0, kIterThreads, true>(nh, four));
     else
-      func = wide ? (newton ? body_kernel<1, kIterThreadsWide, false>(nh) : body_kernel<0, kIterThreadsWide, false>(nh))
-                  : (newton ? body_kernel<1, kIterThreads, false>(nh) : body_kernel<0, kIterThreads, false>(nh));
+      func = wide ? (newton ? body_kernel<1, kIterThreadsWide, false>(nh, four) : body_kernel<0, kIterThreadsWide, false>(nh, four))
+                  : (newton ? body_kernel<1, kIterThreads, false>(nh, four) : body_kernel<0, kIterThreads, false>(nh, four));
   }
   __atomic_store_n(&h->h_flag[0], 0, __ATOMIC_RELAXED);
   __atomic_store_n(&h->h_flag[1], 0, __ATOMIC_RELAXED);

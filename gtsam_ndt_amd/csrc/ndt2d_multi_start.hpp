@@ -91,7 +91,27 @@ struct StartPose {
 // (blockIdx.x, blockIdx.y) owns starts blockIdx.y * NH .. + NH - 1 on block blockIdx.x's points.
 // SHARED: every start aligns the same scan (multi-start: the points are loaded once per workgroup and
 // looked up under NH poses); otherwise every start has its own scan (multi-scan: one point loop per start).
-template <int MODE, int NH, int THREADS, bool SHARED = true>
+// Two points of one thread against Biber's four overlapping grids, in k_iterate's order (both image points, then per grid
+// both lookups and both sums): what keeps a start of these chains bit-identical to its single alignment with the option.
+template <int MODE>
+__device__ __forceinline__ void score_two_overlapped(const PoseF& P, const GridDev& G, const float4* __restrict__ rec, float x, float y,
+                                                     float x1, float y1, bool two, Acc2D& A) {
+  PointRec r0, r1;
+  image_point(P, x, y, r0);
+  image_point(P, x1, y1, r1);
+  const int ncell = G.W * G.H;
+#pragma unroll
+  for (int q = 0; q < kMaxGrids; ++q) {
+    const int k0 = q * ncell + image_key(P, G.gx[q], G.gy[q], r0, true);
+    const int k1 = q * ncell + image_key(P, G.gx[q], G.gy[q], r1, two);
+    r0.A = rec[2 * k0]; r0.B = rec[2 * k0 + 1];
+    r1.A = rec[2 * k1]; r1.B = rec[2 * k1 + 1];
+    accumulate_point<MODE>(P, r0, A);
+    accumulate_point<MODE>(P, r1, A);
+  }
+}
+
+template <int MODE, int NH, int THREADS, bool SHARED = true, int NG = 1>
 __global__ __launch_bounds__(THREADS) void k_iterate_multi(const AlignStatic* __restrict__ st,
                                                            const AlignCall* __restrict__ call,
                                                            AlignDynMulti* __restrict__ dyn, int parity) {
@@ -303,20 +323,26 @@ __global__ __launch_bounds__(THREADS) void k_iterate_multi(const AlignStatic* __
       if (i2 < n) { xn0 = sx[i2]; yn0 = sy[i2]; }
       if (i2 + stride < n) { xn1 = sx[i2 + stride]; yn1 = sy[i2 + stride]; }
       const bool two = (i + stride) < n;
-      PointRec r0[NH], r1[NH];
+      if constexpr (NG == 1) {
+        PointRec r0[NH], r1[NH];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (!done[h]) {                                       // uniform
-          lookup_point(P[h], rec, x, y, true, r0[h]);
-          lookup_point(P[h], rec, x1, y1, two, r1[h]);
+        for (int h = 0; h < NH; ++h) {
+          if (!done[h]) {                                     // uniform
+            lookup_point(P[h], rec, x, y, true, r0[h]);
+            lookup_point(P[h], rec, x1, y1, two, r1[h]);
+          }
         }
-      }
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (!done[h]) {
-          accumulate_point<MODE>(P[h], r0[h], A[h]);
-          accumulate_point<MODE>(P[h], r1[h], A[h]);
+        for (int h = 0; h < NH; ++h) {
+          if (!done[h]) {
+            accumulate_point<MODE>(P[h], r0[h], A[h]);
+            accumulate_point<MODE>(P[h], r1[h], A[h]);
+          }
         }
+      } else {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          if (!done[h]) score_two_overlapped<MODE>(P[h], G, rec, x, y, x1, y1, two, A[h]);       // uniform
       }
       x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
     }
@@ -340,12 +366,16 @@ __global__ __launch_bounds__(THREADS) void k_iterate_multi(const AlignStatic* __
           float xn0 = 0.f, yn0 = 0.f, xn1 = 0.f, yn1 = 0.f;
           if (i2 < nn) { xn0 = px[i2]; yn0 = py[i2]; }
           if (i2 + stride < nn) { xn1 = px[i2 + stride]; yn1 = py[i2 + stride]; }
-          PointRec r0, r1;
           const bool two = (ii + stride) < nn;
-          lookup_point(P[h], rec, u, v, true, r0);
-          lookup_point(P[h], rec, u1, v1, two, r1);
-          accumulate_point<MODE>(P[h], r0, A[h]);
-          accumulate_point<MODE>(P[h], r1, A[h]);
+          if constexpr (NG == 1) {
+            PointRec r0, r1;
+            lookup_point(P[h], rec, u, v, true, r0);
+            lookup_point(P[h], rec, u1, v1, two, r1);
+            accumulate_point<MODE>(P[h], r0, A[h]);
+            accumulate_point<MODE>(P[h], r1, A[h]);
+          } else {
+            score_two_overlapped<MODE>(P[h], G, rec, u, v, u1, v1, two, A[h]);
+          }
           u = xn0; v = yn0; u1 = xn1; v1 = yn1; ii = i2;
         }
       }
@@ -494,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void k_multi_solve(const AlignStatic* __res
   }
 }
 
-template <int MODE, int NH, int THREADS, bool SHARED>
+template <int MODE, int NH, int THREADS, bool SHARED, int NG = 1>
 __global__ __launch_bounds__(THREADS) void k_multi_body(const AlignStatic* __restrict__ st, const AlignCall* __restrict__ call,
                                                         AlignDynMulti* __restrict__ dyn, int parity) {
   constexpr int kWaves = THREADS / 64;
@@ -547,20 +577,26 @@ __global__ __launch_bounds__(THREADS) void k_multi_body(const AlignStatic* __res
       if (i2 < n) { xn0 = sx[i2]; yn0 = sy[i2]; }
       if (i2 + stride < n) { xn1 = sx[i2 + stride]; yn1 = sy[i2 + stride]; }
       const bool two = (i + stride) < n;
-      PointRec r0[NH], r1[NH];
+      if constexpr (NG == 1) {
+        PointRec r0[NH], r1[NH];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (!done[h]) {                                       // uniform
-          lookup_point(P[h], rec, x, y, true, r0[h]);
-          lookup_point(P[h], rec, x1, y1, two, r1[h]);
+        for (int h = 0; h < NH; ++h) {
+          if (!done[h]) {                                     // uniform
+            lookup_point(P[h], rec, x, y, true, r0[h]);
+            lookup_point(P[h], rec, x1, y1, two, r1[h]);
+          }
         }
-      }
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (!done[h]) {
-          accumulate_point<MODE>(P[h], r0[h], A[h]);
-          accumulate_point<MODE>(P[h], r1[h], A[h]);
+        for (int h = 0; h < NH; ++h) {
+          if (!done[h]) {
+            accumulate_point<MODE>(P[h], r0[h], A[h]);
+            accumulate_point<MODE>(P[h], r1[h], A[h]);
+          }
         }
+      } else {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          if (!done[h]) score_two_overlapped<MODE>(P[h], G, rec, x, y, x1, y1, two, A[h]);       // uniform
       }
       x = xn0; y = yn0; x1 = xn1; y1 = yn1; i = i2;
     }
@@ -583,12 +619,16 @@ __global__ __launch_bounds__(THREADS) void k_multi_body(const AlignStatic* __res
           float xn0 = 0.f, yn0 = 0.f, xn1 = 0.f, yn1 = 0.f;
           if (i2 < nn) { xn0 = px[i2]; yn0 = py[i2]; }
           if (i2 + stride < nn) { xn1 = px[i2 + stride]; yn1 = py[i2 + stride]; }
-          PointRec r0, r1;
           const bool two = (ii + stride) < nn;
-          lookup_point(P[h], rec, u, v, true, r0);
-          lookup_point(P[h], rec, u1, v1, two, r1);
-          accumulate_point<MODE>(P[h], r0, A[h]);
-          accumulate_point<MODE>(P[h], r1, A[h]);
+          if constexpr (NG == 1) {
+            PointRec r0, r1;
+            lookup_point(P[h], rec, u, v, true, r0);
+            lookup_point(P[h], rec, u1, v1, two, r1);
+            accumulate_point<MODE>(P[h], r0, A[h]);
+            accumulate_point<MODE>(P[h], r1, A[h]);
+          } else {
+            score_two_overlapped<MODE>(P[h], G, rec, u, v, u1, v1, two, A[h]);
+          }
           u = xn0; v = yn0; u1 = xn1; v1 = yn1; ii = i2;
         }
       }

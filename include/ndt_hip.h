@@ -68,8 +68,8 @@ typedef struct ndt2d_params {
   double step_max_rot;     /* ... and |dtheta| <= step_max_rot                     */
   int32_t min_hits;        /* fewer hits than this => NDT_TOO_FEW_HITS             */
   int32_t overlap_grids;   /* 0 or 1: one grid; 4: Biber's four grids shifted by half a cell, every
-                              point scores against all four (2D: ndt2d_align*, ndt2d_batch_*, ndt2d_multi_*; the
-                              multi-start / multi-scan entry points then run their alignments one by one)  */
+                              point scores against all four (every 2D entry point: ndt2d_align*, the multi-start /
+                              multi-scan chains, ndt2d_batch_*, ndt2d_multi_*)  */
   int32_t line_search;     /* 0: plain Gauss-Newton steps.  n in 1..16: backtracking line search - an
                               evaluation that scores worse than the pose its step started from (or
                               leaves the map) halves the step and retries from that pose, at most n
@@ -239,8 +239,8 @@ int32_t ndt2d_align_trace(ndt2d_handle* h, const float* sx, const float* sy, siz
  * it, keep the best score.
  * results[k] is bit for bit what ndt2d_align_dev returns for init_poses[k] on the
  * launch-per-iteration path; a start that has finished is frozen while the others go on.
- * Synchronous in the results (host memory).  With overlap_grids = 4 the m alignments run one after the other on the
- * single-pair chain (the same results, without the chain's gain). */
+ * Synchronous in the results (host memory).  overlap_grids = 4: the same chain with four lookups per point (one start per
+ * workgroup), every start still bit for bit its single alignment with the option. */
 int32_t ndt2d_align_multi_start_dev(ndt2d_handle* h, const float* d_sx, const float* d_sy, size_t n,
                                     const double* init_poses, int32_t m, ndt2d_result* results);
 /* Execution-strategy knobs of a handle.  They choose between kernels that compute the same alignment

@@ -51,7 +51,8 @@ def test_every_start_equals_its_single_start_alignment_bitwise(gpu_lib, pair2, m
 
 
 @pytest.mark.parametrize("kw", [dict(fixed_iterations=30), dict(hessian_mode=1), dict(line_search=4),
-                                dict(step_scale=3.0), dict(fixed_iterations=7, hessian_mode=1)])
+                                dict(step_scale=3.0), dict(fixed_iterations=7, hessian_mode=1),
+                                dict(overlap_grids=4), dict(overlap_grids=4, hessian_mode=1, fixed_iterations=9)])
 def test_options_keep_the_bitwise_contract(gpu_lib, pair2, kw):
     from gtsam_ndt_amd.matcher import NdtMatcher2D
     d = pair2
@@ -152,7 +153,7 @@ def test_argument_checks(gpu_lib, pair2):
         with pytest.raises(L.NdtError) as e:
             mm.align_multi_start(sx, sy, [d["init"]] * 65)
         assert e.value.code == L.NDT_ERR_INVALID_ARG
-    # overlapping grids: the entry points run their alignments one by one on the single-pair chain - the same contract
+    # overlapping grids: the same chains with four lookups per point - the same contract
     with NdtMatcher2D(overlap_grids=4) as mm:
         mm.set_target(d["tx"], d["ty"])
         starts = _starts(d["init"], 3)
@@ -181,7 +182,8 @@ def _scans_of_config3(n_scans, n_pts, ragged=False):
     return scans, inits, truth
 
 
-@pytest.mark.parametrize("m,kw", [(3, {}), (7, {}), (13, dict(fixed_iterations=9)), (5, dict(hessian_mode=1))])
+@pytest.mark.parametrize("m,kw", [(3, {}), (7, {}), (13, dict(fixed_iterations=9)), (5, dict(hessian_mode=1)),
+                                  (6, dict(overlap_grids=4)), (14, dict(overlap_grids=4, fixed_iterations=8))])
 def test_multi_scan_every_scan_equals_its_own_alignment_bitwise(gpu_lib, m, kw):
     """ndt2d_align_multi_scan_dev: m different scans (ragged sizes) against one submap in one chain; scan k's
     result is bit for bit its own ndt2d_align_dev result, and the pose is the one the scan was taken at."""
@@ -198,7 +200,7 @@ def test_multi_scan_every_scan_equals_its_own_alignment_bitwise(gpu_lib, m, kw):
                 assert a.status == 0 and np.abs(np.array(a.pose) - np.array(truth[k])).max() < 5e-3
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(fixed_iterations=11), dict(hessian_mode=1), dict(line_search=3)])
+@pytest.mark.parametrize("kw", [dict(), dict(fixed_iterations=11), dict(hessian_mode=1), dict(line_search=3), dict(overlap_grids=4)])
 def test_split_chain_equals_fused_chain_bitwise(gpu_lib, pair2, kw):
     """From 12 starts on a call runs two kernels per iteration (one workgroup per start solves, then everybody
     evaluates) instead of the fused kernel; both chains, forced for every size, give the same bits - the single-
